@@ -1,0 +1,127 @@
+"""
+Halo index plumbing (host, integer, run once).
+
+``compute_scatterer_data(index_map, comm)`` keeps the call surface and the
+return format of the reference cuda/utils.py:8-78:
+
+    owners_data = [owners_idx (list of int64 arrays), owners_size, unique_owners]
+    ghosts_data = [ghosts_idx (list of int64 arrays), ghosts_size, unique_ghosts]
+
+  * ``owners_*``: my ghost dofs grouped by the rank that owns them;
+    ``owners_idx[i]`` are positions inside my ghost block (0-based, add
+    ``nlocal`` for the vector index) of the ghosts owned by ``unique_owners[i]``
+    (cuda/utils.py:23-37).
+  * ``ghosts_*``: my owned dofs that are ghosts on other ranks;
+    ``ghosts_idx[i]`` are my local indices that ``unique_ghosts[i]`` ghosts, in
+    the order that rank packs them (cuda/utils.py:40-73: the ghosting rank sends
+    the global indices, the owner subtracts ``local_range[0]``).
+
+The numba-cpu drivers use the same data flattened with offsets
+(numba-cpu/test_operators.py:196-225): ``[idx_flat, size, offsets, ranks]``;
+``to_flat`` / ``to_lists`` convert between the two.
+
+The reference does the index exchange with ``MPI.COMM_WORLD.Isend/Irecv``
+(cuda/utils.py:54-71) and finds the ghosting ranks with an O(ranks x nlocal)
+Python loop (:43-47); here the exchange goes through the package's comm object
+(torch.distributed) and the loop is a ``bincount``.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+
+
+def _owners_side(index_map):
+    owners = np.asarray(index_map.owners)
+    unique_owners, owners_size = np.unique(owners, return_counts=True)
+    order = np.argsort(owners, kind="stable").astype(np.int64)
+    offsets = np.concatenate(([0], np.cumsum(owners_size))).astype(np.int64)
+    return unique_owners.astype(np.int32), owners_size.astype(np.int64), offsets, order
+
+
+def _ghosting_ranks(index_map):
+    dest = index_map.index_to_dest_ranks()
+    arr = np.asarray(dest.array)
+    if arr.size == 0:
+        return np.zeros(0, dtype=np.int32), np.zeros(0, dtype=np.int64)
+    unique_ghosts, ghosts_size = np.unique(arr, return_counts=True)
+    return unique_ghosts.astype(np.int32), ghosts_size.astype(np.int64)
+
+
+def compute_scatterer_data_all(index_maps):
+    """All ranks at once, in one process (tests / single-process simulation).
+
+    Returns ``(owners_data_all, ghosts_data_all)`` in the flat 4-element format
+    ``[idx_flat, size, offsets, ranks]`` per rank.
+    """
+    R = len(index_maps)
+    owners_all, ghosts_all = [], []
+    sent = {}
+    for r, im in enumerate(index_maps):
+        uo, osz, ooff, order = _owners_side(im)
+        owners_all.append([order, osz, ooff, uo])
+        gl = np.asarray(im.ghosts)[order]
+        for i, o in enumerate(uo):
+            sent[(r, int(o))] = gl[ooff[i] : ooff[i + 1]]
+    for r, im in enumerate(index_maps):
+        ug, gsz = _ghosting_ranks(im)
+        goff = np.concatenate(([0], np.cumsum(gsz))).astype(np.int64)
+        idx = np.empty(int(goff[-1]), dtype=np.int64)
+        for i, g in enumerate(ug):
+            recv = sent[(int(g), r)]
+            assert recv.size == gsz[i], "halo plan mismatch between ghosting rank and owner"
+            idx[goff[i] : goff[i + 1]] = recv - im.local_range[0]
+        ghosts_all.append([idx, gsz, goff, ug])
+    return owners_all, ghosts_all
+
+
+def compute_scatterer_data_flat(index_map, comm=None):
+    """One rank's halo plan, flat format; the index exchange uses ``comm``
+    (``.rank``, ``.size``, ``.alltoallv_int64(send, send_counts, recv_counts)``)."""
+    uo, osz, ooff, order = _owners_side(index_map)
+    ug, gsz = _ghosting_ranks(index_map)
+    goff = np.concatenate(([0], np.cumsum(gsz))).astype(np.int64)
+    size = 1 if comm is None else comm.size
+    if size == 1:
+        if uo.size or ug.size:
+            raise ValueError("index_map has ghosts but no communicator was given")
+        return [order, osz, ooff, uo], [np.zeros(0, dtype=np.int64), gsz, goff, ug]
+    send_counts = np.zeros(size, dtype=np.int64)
+    recv_counts = np.zeros(size, dtype=np.int64)
+    send_counts[uo] = osz
+    recv_counts[ug] = gsz
+    send = np.asarray(index_map.ghosts, dtype=np.int64)[order]  # grouped by owner rank, ascending
+    recv = comm.alltoallv_int64(send, send_counts, recv_counts)  # grouped by source rank, ascending
+    idx = recv - index_map.local_range[0]
+    if idx.size and (idx.min() < 0 or idx.max() >= index_map.size_local):
+        raise ValueError("received a ghost index outside this rank's owned range")
+    return [order, osz, ooff, uo], [idx, gsz, goff, ug]
+
+
+def to_lists(data_flat):
+    """flat ``[idx, size, offsets, ranks]`` -> cuda-style ``[list_of_idx, size, ranks]``."""
+    idx, size, off, ranks = data_flat
+    return [[np.ascontiguousarray(idx[off[i] : off[i + 1]]) for i in range(len(ranks))], size, ranks]
+
+
+def to_flat(data):
+    """Accept either format, return the flat one."""
+    if len(data) == 4:
+        idx, size, off, ranks = data
+        return [np.asarray(idx, dtype=np.int64), np.asarray(size, dtype=np.int64), np.asarray(off, dtype=np.int64), np.asarray(ranks, dtype=np.int32)]
+    idx_list, size, ranks = data
+    size = np.asarray(size, dtype=np.int64)
+    off = np.concatenate(([0], np.cumsum(size))).astype(np.int64)
+    conv = []
+    for a in idx_list:
+        if hasattr(a, "detach"):  # device tensor handed over by a cuda-style driver
+            a = a.detach().cpu().numpy()
+        conv.append(np.asarray(a, dtype=np.int64))
+    idx = np.concatenate(conv) if conv else np.zeros(0, dtype=np.int64)
+    return [idx, size, off, np.asarray(ranks, dtype=np.int32)]
+
+
+def compute_scatterer_data(index_map, comm=None):
+    """cuda/utils.py:8-78 call surface (3-element list format)."""
+    od, gd = compute_scatterer_data_flat(index_map, comm)
+    return to_lists(od), to_lists(gd)
