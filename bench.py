@@ -1,0 +1,276 @@
+#!/usr/bin/env python3
+"""
+Headline benchmark (BASELINE.json): DOF/s of the fp64 stiffness-operator apply,
+P = 4 hexahedral box, on N MI355X GPUs of one node.
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+One "step" = one apply ``y += K x`` over the whole (partitioned) mesh:
+forward halo of x, stiffness kernel over all local cells, reverse halo of y
+(the halo legs exist only for N > 1).  ``y`` is zeroed outside the timed region
+and accumulated into, as in the reference's protocol
+(numba-cpu/time_operators.py:227-233, cuda/time_operators.py:272-282).
+
+Workload at N = 1: BASELINE config 3 -- P = 4, 54^3 = 157 464 perturbed
+(non-affine) cells, 10 218 313 dofs, general per-quadrature-point G
+(945 MB).  N > 1: weak scaling, 54^3 cells per GPU in 2x1x1 / 2x2x1 / 2x2x2
+blocks (config 4 at N = 8: 108^3 cells, 81.2 M dofs).
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra
+objects: ``roofline`` (dominant kernel vs the HBM roofline, live HIP-event
+timing) and ``cpu_baseline`` (the oracle's C restatement of the reference's
+numba-cpu operator timed on this box's host cores; rank 0, N = 1 only).
+"""
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (guides/MI355X_MICROARCH.md)
+
+
+def stiffness_bytes_per_cell(P, T):
+    """Algorithmic HBM bytes per cell: G + dofmap + x once + y RMW + constant."""
+    n = P + 1
+    nd = n**3
+    return 6 * nd * T + 4 * nd + T * P**3 + 2 * T * P**3 + T
+
+
+def log(msg):
+    print(f"[bench] {msg}", file=sys.stderr, flush=True)
+
+
+def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
+    """Time the oracle (C restatement of numba-cpu/operators.py:71-227) on the host
+    cores of this box, on the same mesh the GPU ran.  Reported, never shipped."""
+    from oracle import oracle_c
+
+    try:
+        oracle_c.build(native=True)  # -march=native on the box that does the timing
+        O = oracle_c.OracleLib(native=True)
+    except Exception as e:  # no compiler on the box: fall back to the portable build
+        log(f"native oracle build failed ({e}); using the portable build")
+        O = oracle_c.OracleLib()
+    mesh = pb["mesh"]
+    ncores = min(O.max_threads(), len(os.sched_getaffinity(0)))
+    y = np.zeros(mesh.ndofs)
+    # bounded sample for the serial leg: a contiguous slab of cells
+    ns = min(mesh.ncells, 40000)
+    res = {}
+    for name, threads, ncell, reps in (("omp", ncores, mesh.ncells, reps_omp), ("serial", 1, ns, reps_serial)):
+        O.stiffness_apply(P, pb["D"], pb["x"], pb["cc"][:ncell], y, pb["G"][:ncell], mesh.dofmap[:ncell], threads=threads)
+        ts = []
+        for _ in range(reps):
+            y[:] = 0.0
+            t0 = time.perf_counter()
+            O.stiffness_apply(P, pb["D"], pb["x"], pb["cc"][:ncell], y, pb["G"][:ncell], mesh.dofmap[:ncell], threads=threads)
+            ts.append(time.perf_counter() - t0)
+        dofs = ncell * P**3  # asymptotic dofs per cell, so slabs compare with the full box
+        res[name] = dict(t=float(np.mean(ts)), dof_per_s=dofs / float(np.mean(ts)), ncell=int(ncell), threads=int(threads))
+    return {
+        "value": res["omp"]["dof_per_s"],
+        "unit": "DOF/s",
+        "cores": res["omp"]["threads"],
+        "kind": "port",
+        "sample": f"full workload ({res['omp']['ncell']} cells), {reps_omp} reps, OpenMP over {res['omp']['threads']} threads; "
+        f"serial leg: {res['serial']['ncell']} cells x {reps_serial} reps",
+        "single_thread_value": res["serial"]["dof_per_s"],
+        "ms_per_apply": res["omp"]["t"] * 1e3,
+        "impl": "oracle/fus_oracle.c (C restatement of numba-cpu/operators.py, -O3 -ffast-math -march=native)",
+    }
+
+
+def load_traffic(P, ncell):
+    """Per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/), or None."""
+    path = os.path.join(ROOT, "profiles", "traffic_latest.json")
+    try:
+        with open(path) as f:
+            t = json.load(f)
+        if int(t.get("P", -1)) == P and int(t.get("ncell", -1)) == ncell:
+            return float(t["hbm_bytes_per_launch"])
+    except Exception:
+        pass
+    return None
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=100)
+    ap.add_argument("--warmup", type=int, default=10)
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--cells", type=int, default=54, help="cells per direction PER GPU")
+    ap.add_argument("--dtype", default="f64", choices=["f64", "f32"])
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--variant", type=int, default=None)
+    ap.add_argument("--xcd-remap", type=int, default=None)
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+
+    import fusgpu_loader
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group("nccl", device_id=device)
+
+    lib = fusgpu_loader.submodule("_lib")
+    ops = fusgpu_loader.submodule("operators")
+    boxmesh = fusgpu_loader.submodule("boxmesh")
+    gll = fusgpu_loader.submodule("gll")
+    pre = fusgpu_loader.submodule("precompute")
+    lib.load()
+    if args.variant is not None:
+        lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, args.variant)
+    if args.xcd_remap is not None:
+        lib.set_tuning(lib.TUNE_XCD_REMAP, args.xcd_remap)
+
+    P = args.degree
+    n = P + 1
+    dt = np.float64 if args.dtype == "f64" else np.float32
+    T = np.dtype(dt).itemsize
+    grid = boxmesh.default_grid(world)
+    gcells = tuple(args.cells * g for g in grid)
+
+    t0 = time.time()
+    mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, perturb=0.16, seed=0, dtype=dt)
+    pts, wts, D = gll.tabulate_1d(P, dt)
+    wts3 = gll.tensor_weights_3d(wts).astype(dt)
+    dphi_g = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts), dt)
+    G = np.zeros((mesh.ncells, n**3, 6), dtype=dt)
+    pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), mesh.ncells, dphi_g, wts3)
+    xyz = mesh.dof_coordinates()
+    x = (100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])).astype(dt)
+    del xyz
+    cc = np.random.default_rng(1234).standard_normal(mesh.ncells).astype(dt)
+    if rank == 0:
+        log(f"setup {time.time() - t0:.1f}s: P={P} cells/GPU={mesh.ncells} local dofs={mesh.ndofs} "
+            f"global dofs={mesh.ndofs_global} grid={grid} G={G.nbytes / 1e6:.0f} MB")
+
+    x_d = torch.from_numpy(x).to(device)
+    y_d = torch.zeros(mesh.ndofs, dtype=x_d.dtype, device=device)
+    cc_d = torch.from_numpy(cc).to(device)
+    G_d = torch.from_numpy(G).to(device)
+    dm_d = torch.from_numpy(mesh.dofmap).to(device)
+    op = ops.stiffness_operator(P, D.flatten(), dt)
+
+    halo = None
+    if world > 1:
+        scat = fusgpu_loader.submodule("scatterer")
+        halo = scat.HaloApply(mesh, op, dist.group.WORLD, device, dt)
+
+    def step():
+        if halo is None:
+            op(x_d, cc_d, y_d, G_d, dm_d)
+        else:
+            halo.apply(x_d, cc_d, y_d, G_d, dm_d)
+
+    for _ in range(args.warmup):
+        step()
+    y_d.zero_()
+    ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t_start = time.perf_counter()
+    for i in range(args.steps):
+        ev0[i].record()
+        step()
+        ev1[i].record()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t_start
+    if world > 1:
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        elapsed = float(tt.item())
+    ms_per_step = elapsed / args.steps * 1e3
+    ev_ms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
+
+    if halo is not None:
+        kern_ms = halo.kernel_ms_estimate(ev_ms)
+    else:
+        kern_ms = float(ev_ms.mean())  # N = 1: the step IS the stiffness kernel launch
+
+    ndofs_global = mesh.ndofs_global
+    value = ndofs_global / (elapsed / args.steps)
+    bpc = stiffness_bytes_per_cell(P, T)
+    achieved = mesh.ncells * bpc / (kern_ms * 1e-3) / 1e9
+
+    out = {
+        "metric": "stiffness_apply_dof_per_s",
+        "value": value,
+        "unit": "DOF/s",
+        "n_gpus": world,
+        "steps": args.steps,
+        "warmup": args.warmup,
+        "ms_per_step": ms_per_step,
+        "higher_is_better": True,
+        "scaling": "weak",
+        "vs_baseline": None,
+        "dtype": args.dtype,
+        "data": "synthetic",
+        "config": {
+            "workload": f"stiffness apply y+=Kx, P={P} GLL hex box, {gcells[0]}x{gcells[1]}x{gcells[2]} perturbed cells, "
+            f"{ndofs_global} dofs" + (" (BASELINE config 3)" if (world == 1 and P == 4 and args.cells == 54) else ""),
+            "degree": P,
+            "cells_per_gpu": mesh.ncells,
+            "global_dofs": ndofs_global,
+            "partition": f"{grid[0]}x{grid[1]}x{grid[2]} blocks",
+            "geometry": "general per-quadrature-point G[ncell][n^3][6] (no affine shortcut)",
+            "stiffness_variant": lib.get_tuning(lib.TUNE_STIFFNESS_VARIANT),
+            "xcd_remap": lib.get_tuning(lib.TUNE_XCD_REMAP),
+        },
+        "roofline": {
+            "bound": "hbm",
+            "achieved": achieved,
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
+            "frac": achieved / HBM_PEAK_GBS,
+            "traffic": load_traffic(P, mesh.ncells),
+            "kernel": "fus::stiffness_col_kernel",
+            "kernel_ms": kern_ms,
+            "algorithmic_bytes_per_cell": bpc,
+            "cells_per_launch": mesh.ncells,
+            "pct_of_hbm_roofline_dofs": 100.0 * achieved / HBM_PEAK_GBS,
+        },
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            pb = dict(mesh=mesh, D=D, x=x.astype(np.float64), cc=cc.astype(np.float64), G=G.astype(np.float64))
+            if dt != np.float64:
+                D = D.astype(np.float64)
+                pb["D"] = D
+            try:
+                out["cpu_baseline"] = cpu_baseline(P, pb)
+            except Exception as e:
+                log(f"cpu_baseline failed: {e!r}")
+                out["cpu_baseline"] = None
+        else:
+            out["cpu_baseline"] = None
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

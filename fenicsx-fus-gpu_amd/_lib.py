@@ -1,0 +1,135 @@
+"""
+ctypes binding of ``csrc/libfusgpu.so`` (C ABI declared in include/fus_gpu.h).
+
+There is no CPU fallback: if the HIP library has not been built, or no GPU is
+visible when a kernel is requested, this module raises.
+"""
+
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "csrc", "libfusgpu.so")
+
+_i64, _int, _vp = C.c_int64, C.c_int, C.c_void_p
+
+# every symbol include/fus_gpu.h declares -> (argtypes); restype is int unless noted
+_SUFFIXES = (("f64", C.c_double), ("f32", C.c_float))
+
+
+def _signatures():
+    sig = {
+        "fus_abi_version": [],
+        "fus_device_info": [_int, C.c_char_p, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_int)],
+        "fus_set_tuning": [_int, _int],
+        "fus_get_tuning": [_int],
+    }
+    for suf, ct in _SUFFIXES:
+        sig[f"fus_stiffness_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
+        sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
+        sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]
+        sig[f"fus_copy_{suf}"] = [_vp, _vp, _i64, _vp]
+        sig[f"fus_fill_{suf}"] = [ct, _vp, _i64, _vp]
+        sig[f"fus_pointwise_divide_{suf}"] = [_vp, _vp, _vp, _i64, _vp]
+        sig[f"fus_square_{suf}"] = [_vp, _vp, _i64, _vp]
+        sig[f"fus_pack_fwd_{suf}"] = [_vp, _vp, _vp, _i64, _vp]
+        sig[f"fus_unpack_fwd_{suf}"] = [_vp, _vp, _vp, _i64, _i64, _vp]
+        sig[f"fus_pack_rev_{suf}"] = [_vp, _vp, _vp, _i64, _i64, _vp]
+        sig[f"fus_unpack_rev_{suf}"] = [_vp, _vp, _vp, _i64, _vp]
+    return sig
+
+
+SIGNATURES = _signatures()
+
+TUNE_STIFFNESS_VARIANT = 1
+TUNE_XCD_REMAP = 2
+TUNE_MASS_VARIANT = 3
+
+_lib = None
+
+
+class FusGpuError(RuntimeError):
+    pass
+
+
+def load():
+    """Load libfusgpu.so (once). Raises if it has not been built."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise FusGpuError(
+            f"{LIB_PATH} not found: the HIP extension has not been built "
+            "(run `python -c 'import __graft_entry__ as g; g.build()'` or `make -C fenicsx-fus-gpu_amd/csrc`). "
+            "There is no CPU fallback."
+        )
+    lib = C.CDLL(LIB_PATH)
+    for name, argtypes in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
+        fn.argtypes = argtypes
+        fn.restype = _int
+    lib.fus_error_string.argtypes = [_int]
+    lib.fus_error_string.restype = C.c_char_p
+    _lib = lib
+    return lib
+
+
+def check(rc: int, what: str = ""):
+    if rc != 0:
+        msg = load().fus_error_string(rc).decode()
+        raise FusGpuError(f"{what or 'libfusgpu call'} failed: {msg} (code {rc})")
+
+
+def torch_dtype(float_type):
+    dt = np.dtype(float_type)
+    if dt == np.float64:
+        return torch.float64
+    if dt == np.float32:
+        return torch.float32
+    raise TypeError(f"float_type must be np.float32 or np.float64, got {float_type!r}")
+
+
+def suffix(dtype: torch.dtype) -> str:
+    if dtype == torch.float64:
+        return "f64"
+    if dtype == torch.float32:
+        return "f32"
+    raise TypeError(f"unsupported dtype {dtype}")
+
+
+def require_device_tensor(t, dtype, name: str):
+    """Type checks mirroring what numba would reject at dispatch time."""
+    if not isinstance(t, torch.Tensor):
+        raise TypeError(f"{name}: expected a device array (torch.Tensor on the GPU), got {type(t).__name__}")
+    if t.dtype != dtype:
+        raise TypeError(f"{name}: expected dtype {dtype}, got {t.dtype}")
+    if not t.is_cuda:
+        raise FusGpuError(f"{name}: tensor is on {t.device}; the operators only run on the GPU (no CPU fallback)")
+    if not t.is_contiguous():
+        raise ValueError(f"{name}: array must be C-contiguous")
+    return t
+
+
+def stream_ptr():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def device_info(device: int = 0):
+    lib = load()
+    name = C.create_string_buffer(256)
+    cu, hbm, lds = _int(0), _i64(0), _int(0)
+    check(lib.fus_device_info(device, name, C.byref(cu), C.byref(hbm), C.byref(lds)), "fus_device_info")
+    return {"name": name.value.decode(), "compute_units": cu.value, "hbm_bytes": hbm.value, "lds_bytes_per_cu": lds.value}
+
+
+def set_tuning(key: int, value: int):
+    check(load().fus_set_tuning(key, value), "fus_set_tuning")
+
+
+def get_tuning(key: int) -> int:
+    return load().fus_get_tuning(key)

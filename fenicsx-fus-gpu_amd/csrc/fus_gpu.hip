@@ -1,0 +1,191 @@
+// libfusgpu.so -- C ABI (include/fus_gpu.h) over the CDNA4 kernels in this directory.
+// Build: see Makefile (hipcc --offload-arch=gfx950).
+#include "../../include/fus_gpu.h"
+
+#include <hip/hip_runtime.h>
+
+#include <atomic>
+#include <cstdio>
+#include <cstring>
+
+#include "halo.hpp"
+#include "mass.hpp"
+#include "stiffness.hpp"
+#include "vecops.hpp"
+
+namespace {
+
+std::atomic<int> g_stiffness_variant{0};
+std::atomic<int> g_xcd_remap{1};
+std::atomic<int> g_mass_variant{0};
+
+inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
+
+inline bool misaligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
+
+template <typename T, int P>
+hipError_t stiffness_dispatch_variant(const T* x, const T* cc, T* y, const T* G, const int32_t* dofmap,
+                                      const T* dphi, int64_t ncell, hipStream_t s) {
+  const int variant = g_stiffness_variant.load(std::memory_order_relaxed);
+  const int remap = g_xcd_remap.load(std::memory_order_relaxed);
+  constexpr int CPB256 = fus::default_cells_per_block<P>(256);
+  constexpr int CPB128 = fus::default_cells_per_block<P>(128);
+  switch (variant) {
+    case 1:  // ~128-thread workgroups
+      return fus::launch_stiffness_col<T, P, CPB128>(x, cc, y, G, dofmap, dphi, ncell, remap, s);
+    default:  // ~256-thread workgroups
+      return fus::launch_stiffness_col<T, P, CPB256>(x, cc, y, G, dofmap, dphi, ncell, remap, s);
+  }
+}
+
+template <typename T>
+int stiffness_apply(const T* x, const T* cc, T* y, const T* G, const int32_t* dofmap, const T* dphi, int P,
+                    int64_t ncell, void* stream) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
+  if (ncell == 0) return FUS_OK;
+  if (!x || !cc || !y || !G || !dofmap || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  if (misaligned(G, 2 * sizeof(T)) || misaligned(x, sizeof(T)) || misaligned(y, sizeof(T)) ||
+      misaligned(dofmap, sizeof(int32_t)))
+    return FUS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipErrorInvalidValue;
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    e = stiffness_dispatch_variant<T, PP>(x, cc, y, G, dofmap, dphi, ncell, s); \
+    break;
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return hip_rc(e);
+}
+
+template <typename T>
+int mass_apply(const T* x, const T* consts, T* y, const T* detJ, const int32_t* dofmap, int N, int64_t nent,
+               void* stream) {
+  if (nent < 0 || N < 1) return FUS_ERR_INVALID_ARGUMENT;
+  if (nent == 0) return FUS_OK;
+  if (!x || !consts || !y || !detJ || !dofmap) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::launch_mass<T>(x, consts, y, detJ, dofmap, N, nent, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T, typename Op, bool UA, bool UB>
+int ew(const T* a, const T* b, T* out, int64_t n, Op op, void* stream) {
+  if (n < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (n == 0) return FUS_OK;
+  if (!out || (UA && !a) || (UB && !b)) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::launch_ew<T, Op, UA, UB>(a, b, out, n, op, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T, int MODE>
+int halo(const T* in, T* out, const int64_t* index, int64_t count, int64_t offset, void* stream) {
+  if (count < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (count == 0) return FUS_OK;
+  if (!in || !out || !index) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::launch_halo<T, MODE>(in, out, index, count, offset, static_cast<hipStream_t>(stream)));
+}
+
+}  // namespace
+
+extern "C" {
+
+int fus_abi_version(void) { return 1; }
+
+const char* fus_error_string(int code) {
+  switch (code) {
+    case FUS_OK: return "ok";
+    case FUS_ERR_INVALID_ARGUMENT: return "invalid argument (null pointer, negative size or misaligned buffer)";
+    case FUS_ERR_UNSUPPORTED_DEGREE: return "unsupported polynomial degree";
+    case FUS_ERR_UNSUPPORTED_ENTITY: return "unsupported entity size";
+    case FUS_ERR_NO_DEVICE: return "no HIP device";
+    default:
+      if (code <= FUS_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(FUS_ERR_HIP_BASE - code));
+      return "unknown error";
+  }
+}
+
+int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_bytes, int* lds_bytes_per_cu) {
+  int count = 0;
+  if (hipGetDeviceCount(&count) != hipSuccess || device < 0 || device >= count) return FUS_ERR_NO_DEVICE;
+  hipDeviceProp_t p;
+  if (hipGetDeviceProperties(&p, device) != hipSuccess) return FUS_ERR_NO_DEVICE;
+  if (name) {
+    std::snprintf(name, 256, "%s (%s)", p.name, p.gcnArchName);
+  }
+  if (compute_units) *compute_units = p.multiProcessorCount;
+  if (hbm_bytes) *hbm_bytes = (int64_t)p.totalGlobalMem;
+  if (lds_bytes_per_cu) *lds_bytes_per_cu = (int)p.maxSharedMemoryPerMultiProcessor;
+  return FUS_OK;
+}
+
+int fus_set_tuning(int key, int value) {
+  switch (key) {
+    case FUS_TUNE_STIFFNESS_VARIANT: g_stiffness_variant = value; return FUS_OK;
+    case FUS_TUNE_XCD_REMAP: g_xcd_remap = value ? 1 : 0; return FUS_OK;
+    case FUS_TUNE_MASS_VARIANT: g_mass_variant = value; return FUS_OK;
+  }
+  return FUS_ERR_INVALID_ARGUMENT;
+}
+
+int fus_get_tuning(int key) {
+  switch (key) {
+    case FUS_TUNE_STIFFNESS_VARIANT: return g_stiffness_variant;
+    case FUS_TUNE_XCD_REMAP: return g_xcd_remap;
+    case FUS_TUNE_MASS_VARIANT: return g_mass_variant;
+  }
+  return FUS_ERR_INVALID_ARGUMENT;
+}
+
+int fus_stiffness_apply_f64(const double* x, const double* cc, double* y, const double* G, const int32_t* dofmap,
+                            const double* dphi, int P, int64_t ncell, void* stream) {
+  return stiffness_apply<double>(x, cc, y, G, dofmap, dphi, P, ncell, stream);
+}
+int fus_stiffness_apply_f32(const float* x, const float* cc, float* y, const float* G, const int32_t* dofmap,
+                            const float* dphi, int P, int64_t ncell, void* stream) {
+  return stiffness_apply<float>(x, cc, y, G, dofmap, dphi, P, ncell, stream);
+}
+
+int fus_mass_apply_f64(const double* x, const double* c, double* y, const double* detJ, const int32_t* dofmap, int N,
+                       int64_t nent, void* stream) {
+  return mass_apply<double>(x, c, y, detJ, dofmap, N, nent, stream);
+}
+int fus_mass_apply_f32(const float* x, const float* c, float* y, const float* detJ, const int32_t* dofmap, int N,
+                       int64_t nent, void* stream) {
+  return mass_apply<float>(x, c, y, detJ, dofmap, N, nent, stream);
+}
+
+#define FUS_VEC(T, SUF)                                                                                       \
+  int fus_axpy_##SUF(T alpha, const T* x, T* y, int64_t n, void* s) {                                         \
+    return ew<T, fus::OpAxpy<T>, true, true>(x, y, y, n, fus::OpAxpy<T>{alpha}, s);                           \
+  }                                                                                                           \
+  int fus_copy_##SUF(const T* a, T* b, int64_t n, void* s) {                                                  \
+    return ew<T, fus::OpCopy<T>, true, false>(a, nullptr, b, n, fus::OpCopy<T>{}, s);                         \
+  }                                                                                                           \
+  int fus_fill_##SUF(T alpha, T* x, int64_t n, void* s) {                                                     \
+    return ew<T, fus::OpFill<T>, false, false>(nullptr, nullptr, x, n, fus::OpFill<T>{alpha}, s);             \
+  }                                                                                                           \
+  int fus_pointwise_divide_##SUF(const T* a, const T* b, T* c, int64_t n, void* s) {                          \
+    return ew<T, fus::OpDiv<T>, true, true>(a, b, c, n, fus::OpDiv<T>{}, s);                                  \
+  }                                                                                                           \
+  int fus_square_##SUF(const T* a, T* b, int64_t n, void* s) {                                                \
+    return ew<T, fus::OpSquare<T>, true, false>(a, nullptr, b, n, fus::OpSquare<T>{}, s);                     \
+  }                                                                                                           \
+  int fus_pack_fwd_##SUF(const T* in, T* out, const int64_t* idx, int64_t cnt, void* s) {                     \
+    return halo<T, fus::PACK>(in, out, idx, cnt, 0, s);                                                       \
+  }                                                                                                           \
+  int fus_unpack_fwd_##SUF(const T* in, T* out, const int64_t* idx, int64_t cnt, int64_t N, void* s) {        \
+    return halo<T, fus::UNPACK_SET>(in, out, idx, cnt, N, s);                                                 \
+  }                                                                                                           \
+  int fus_pack_rev_##SUF(const T* in, T* out, const int64_t* idx, int64_t cnt, int64_t N, void* s) {          \
+    return halo<T, fus::PACK>(in, out, idx, cnt, N, s);                                                       \
+  }                                                                                                           \
+  int fus_unpack_rev_##SUF(const T* in, T* out, const int64_t* idx, int64_t cnt, void* s) {                   \
+    return halo<T, fus::UNPACK_ADD>(in, out, idx, cnt, 0, s);                                                 \
+  }
+FUS_VEC(double, f64)
+FUS_VEC(float, f32)
+#undef FUS_VEC
+
+}  // extern "C"

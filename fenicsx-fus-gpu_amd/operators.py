@@ -1,0 +1,237 @@
+"""
+Operator call surface of the reference, over libfusgpu.so (hand-written HIP for
+gfx950).  Both flavours of the reference are served by the same objects:
+
+numba-cpu flavour (numba-cpu/operators.py):
+    mass_operator(N, float_type)            -> op(x, entity_constants, y, entity_detJ, entity_dofmap)   :19-68
+    stiffness_operator(P, dphi, float_type) -> op(x, cell_constants, y, G, dofmap)                      :71-227
+    axpy(local_size)                        -> kernel(alpha, x, y)                                      :230-251
+    copy(a, b); fill(alpha, x); pointwise_divide(a, b, c)                                               :254-300
+
+cuda flavour (cuda/operators.py), launched as ``kernel[grid, block](args...)``:
+    mass_operator[g, b](x, entity_constants, y, detJ_entity, entity_dofmap)                             :18-70
+    stiffness_operator(P, float_type)       -> op[g, b](x, consts, y, G, dofmap, dphi)                  :73-192
+    axpy[g, b](alpha, x, y); copy[g, b](a, b); fill[g, b](alpha, x);
+    pointwise_divide[g, b](a, b, c); square[g, b](a, b)                                                 :195-274
+
+The launch configuration given in ``[grid, block]`` is accepted and ignored: the
+library chooses its own geometry for CDNA4.  Arrays are device arrays (torch
+tensors on the GPU, e.g. from ``device.to_device``); ``y`` / outputs are
+modified in place; launches are asynchronous on torch's current HIP stream.
+Argument errors raise (TypeError / ValueError) like a numba dispatch failure;
+there is no CPU fallback.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+
+_req = _lib.require_device_tensor
+
+
+class _Launchable:
+    """``obj[grid, block](...)`` == ``obj.launch(...)`` (launch config ignored)."""
+
+    def __getitem__(self, launch_config):
+        return self.launch
+
+
+# --------------------------------------------------------------------------- mass
+def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None):
+    lib = _lib.load()
+    dt = x.dtype if isinstance(x, torch.Tensor) else None
+    _req(x, dt, "x")
+    _req(entity_constants, dt, "entity_constants")
+    _req(y, dt, "y")
+    _req(entity_detJ, dt, "entity_detJ")
+    _req(entity_dofmap, torch.int32, "entity_dofmap")
+    if entity_dofmap.dim() != 2 or entity_detJ.shape != entity_dofmap.shape:
+        raise ValueError("entity_dofmap must be [num_entities, N] and entity_detJ must have the same shape")
+    nent, n_per = entity_dofmap.shape
+    if N is not None and n_per != N:
+        raise ValueError(f"operator was built for N={N} dofs per entity, dofmap has {n_per}")
+    if entity_constants.numel() != nent:
+        raise ValueError("entity_constants must have one value per entity")
+    fn = getattr(lib, f"fus_mass_apply_{_lib.suffix(dt)}")
+    _lib.check(
+        fn(x.data_ptr(), entity_constants.data_ptr(), y.data_ptr(), entity_detJ.data_ptr(), entity_dofmap.data_ptr(),
+           int(n_per), int(nent), _lib.stream_ptr()),
+        "fus_mass_apply",
+    )
+
+
+class _MassOperator(_Launchable):
+    def __call__(self, N: int, float_type):
+        tdt = _lib.torch_dtype(float_type)
+        N = int(N)
+
+        def operator(x, entity_constants, y, entity_detJ, entity_dofmap):
+            if isinstance(x, torch.Tensor) and x.dtype != tdt:
+                raise TypeError(f"x: expected dtype {tdt}, got {x.dtype}")
+            _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N)
+
+        return operator
+
+    @staticmethod
+    def launch(x, entity_constants, y, detJ_entity, entity_dofmap):
+        _mass_apply(x, entity_constants, y, detJ_entity, entity_dofmap)
+
+
+mass_operator = _MassOperator()
+
+
+# ---------------------------------------------------------------------- stiffness
+class _StiffnessOperator(_Launchable):
+    """Returned by ``stiffness_operator``; callable both ways."""
+
+    def __init__(self, P: int, float_type, dphi=None):
+        self.P = int(P)
+        if not (1 <= self.P <= 10):
+            raise ValueError(f"polynomial degree {P} outside the supported range 1..10")
+        self.n = self.P + 1
+        self.dtype = _lib.torch_dtype(float_type)
+        self._fn = getattr(_lib.load(), f"fus_stiffness_apply_{_lib.suffix(self.dtype)}")
+        self._dphi = None
+        self._dphi_src = None
+        if dphi is not None:
+            self._dphi = self._table(dphi)
+
+    def _table(self, dphi):
+        """Accept the flat ``[q*n+i]`` (numba-cpu) or 2-D ``[q, i]`` (cuda) table, host or device."""
+        if isinstance(dphi, torch.Tensor):
+            t = dphi
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(np.asarray(dphi)))
+        if t.numel() != self.n * self.n:
+            raise ValueError(f"dphi must have {self.n * self.n} entries for P={self.P}, got {t.numel()}")
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return t.to(device=dev, dtype=self.dtype).contiguous().reshape(-1)
+
+    def _apply(self, x, cell_constants, y, G, dofmap, dphi_t):
+        dt = self.dtype
+        _req(x, dt, "x")
+        _req(cell_constants, dt, "cell_constants")
+        _req(y, dt, "y")
+        _req(G, dt, "G")
+        _req(dofmap, torch.int32, "dofmap")
+        nd = self.n**3
+        if dofmap.dim() != 2 or dofmap.shape[1] != nd:
+            raise ValueError(f"dofmap must be [ncell, {nd}] for P={self.P}")
+        ncell = dofmap.shape[0]
+        if G.numel() != ncell * nd * 6:
+            raise ValueError(f"G must be [ncell, {nd}, 6]")
+        if cell_constants.numel() != ncell:
+            raise ValueError("cell_constants must have one value per cell")
+        _lib.check(
+            self._fn(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(), dofmap.data_ptr(),
+                     dphi_t.data_ptr(), self.P, int(ncell), _lib.stream_ptr()),
+            "fus_stiffness_apply",
+        )
+
+    # numba-cpu flavour: op(x, cell_constants, y, G, dofmap)
+    def __call__(self, x, cell_constants, y, G, dofmap):
+        if self._dphi is None:
+            raise TypeError("this operator was built cuda-style (no dphi); launch it as op[grid, block](..., dphi)")
+        self._apply(x, cell_constants, y, G, dofmap, self._dphi)
+
+    # cuda flavour: op[grid, block](x, consts, y, G, dofmap, dphi)
+    def launch(self, x, entity_constants, y, G_entity, entity_dofmap, dphi):
+        if dphi is not self._dphi_src:  # convert/cache the table once per distinct object
+            self._dphi_cuda = self._table(dphi)
+            self._dphi_src = dphi
+        self._apply(x, entity_constants, y, G_entity, entity_dofmap, self._dphi_cuda)
+
+
+def stiffness_operator(P, *args):
+    """``stiffness_operator(P, dphi, float_type)`` (numba-cpu/operators.py:71) or
+    ``stiffness_operator(P, float_type)`` (cuda/operators.py:73)."""
+    if len(args) == 2:
+        dphi, float_type = args
+        return _StiffnessOperator(P, float_type, dphi)
+    if len(args) == 1:
+        return _StiffnessOperator(P, args[0])
+    raise TypeError("stiffness_operator(P, dphi, float_type) or stiffness_operator(P, float_type)")
+
+
+# -------------------------------------------------------------------- vector ops
+def _vec(name, *tensors):
+    dt = tensors[0].dtype if isinstance(tensors[0], torch.Tensor) else None
+    for i, t in enumerate(tensors):
+        _req(t, dt, f"arg{i}")
+    n = tensors[0].numel()
+    return getattr(_lib.load(), f"fus_{name}_{_lib.suffix(dt)}"), n
+
+
+def _axpy(alpha, x, y, n=None):
+    fn, size = _vec("axpy", x, y)
+    n = min(x.numel(), y.numel()) if n is None else int(n)
+    if n > x.numel() or n > y.numel():
+        raise ValueError("axpy: n exceeds the vector length")
+    _lib.check(fn(float(alpha), x.data_ptr(), y.data_ptr(), n, _lib.stream_ptr()), "fus_axpy")
+
+
+class _Axpy(_Launchable):
+    def __call__(self, local_size: int):
+        n = int(local_size)
+
+        def kernel(alpha, x, y):
+            _axpy(alpha, x, y, n)
+
+        return kernel
+
+    @staticmethod
+    def launch(alpha, x, y):
+        _axpy(alpha, x, y)
+
+
+class _Copy(_Launchable):
+    @staticmethod
+    def launch(a, b):
+        fn, n = _vec("copy", a, b)
+        if b.numel() < n:
+            raise ValueError("copy: output shorter than input")
+        _lib.check(fn(a.data_ptr(), b.data_ptr(), n, _lib.stream_ptr()), "fus_copy")
+
+    __call__ = launch
+
+
+class _Fill(_Launchable):
+    @staticmethod
+    def launch(alpha, x):
+        fn, n = _vec("fill", x)
+        _lib.check(fn(float(alpha), x.data_ptr(), n, _lib.stream_ptr()), "fus_fill")
+
+    __call__ = launch
+
+
+class _PointwiseDivide(_Launchable):
+    @staticmethod
+    def launch(a, b, c):
+        fn, _ = _vec("pointwise_divide", a, b, c)
+        n = c.numel()
+        if a.numel() < n or b.numel() < n:
+            raise ValueError("pointwise_divide: inputs shorter than output")
+        _lib.check(fn(a.data_ptr(), b.data_ptr(), c.data_ptr(), n, _lib.stream_ptr()), "fus_pointwise_divide")
+
+    __call__ = launch
+
+
+class _Square(_Launchable):
+    @staticmethod
+    def launch(a, b):
+        fn, n = _vec("square", a, b)
+        if b.numel() < n:
+            raise ValueError("square: output shorter than input")
+        _lib.check(fn(a.data_ptr(), b.data_ptr(), n, _lib.stream_ptr()), "fus_square")
+
+    __call__ = launch
+
+
+axpy = _Axpy()
+copy = _Copy()
+fill = _Fill()
+pointwise_divide = _PointwiseDivide()
+square = _Square()

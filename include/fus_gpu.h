@@ -1,0 +1,115 @@
+/*
+ * fus_gpu.h -- C ABI of libfusgpu.so: MI355X (gfx950) matrix-free operator-application path
+ * for the FEniCSx-FUS acoustic wave solver.
+ *
+ * The reference has no FFI of its own: its "boundary" is the numba JIT call of Python closures.
+ * Every entry point below names the reference interface it replaces (file:line, relative to the
+ * reference checkout).  All pointers are DEVICE pointers (plain HIP allocations); all buffers are
+ * caller-owned; nothing is allocated, freed or synchronised per call; every launch is asynchronous
+ * on ``stream`` (a hipStream_t passed as void*, NULL = the default stream).
+ *
+ * Return value: FUS_OK (0) or a negative error code; fus_error_string() describes it.
+ * Layouts are exactly the reference's:
+ *   x, y            T[nlocal + nghost]                  dof vectors (owned first, then ghosts)
+ *   cell_constants  T[ncell]
+ *   G               T[ncell][n^3][6]  C-contiguous      (G00,G01,G02,G11,G12,G22) * w * |detJ|
+ *   detJ            T[nent][N]
+ *   dofmap          int32[ncell][n^3]                   tensor-product local order l = i n^2 + j n + k
+ *   dphi            T[n][n]  ([q][i], row-major; the flat and the 2-D form are the same bytes)
+ * with n = P + 1.
+ */
+#ifndef FUS_GPU_H
+#define FUS_GPU_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define FUS_OK 0
+#define FUS_ERR_INVALID_ARGUMENT (-1) /* null pointer, negative size, misaligned buffer */
+#define FUS_ERR_UNSUPPORTED_DEGREE (-2) /* P outside [FUS_MIN_DEGREE, FUS_MAX_DEGREE] */
+#define FUS_ERR_UNSUPPORTED_ENTITY (-3)
+#define FUS_ERR_NO_DEVICE (-4)
+#define FUS_ERR_HIP_BASE (-1000) /* -(1000 + hipError_t) for launch/runtime failures */
+
+#define FUS_MIN_DEGREE 1
+#define FUS_MAX_DEGREE 10 /* the reference's quadrature-degree map covers P = 2..10 */
+
+/* Library / device queries. */
+int fus_abi_version(void);
+const char* fus_error_string(int code);
+/* name: >= 256 bytes or NULL; returns FUS_OK or FUS_ERR_NO_DEVICE. */
+int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_bytes, int* lds_bytes_per_cu);
+
+/* Tuning knobs (process-global, not part of the numerical contract).  Keys: */
+#define FUS_TUNE_STIFFNESS_VARIANT 1 /* 0 = default; see DESIGN.md for the variants */
+#define FUS_TUNE_XCD_REMAP 2         /* 1 = give each XCD a contiguous range of cell batches */
+#define FUS_TUNE_MASS_VARIANT 3
+int fus_set_tuning(int key, int value);
+int fus_get_tuning(int key);
+
+/*
+ * Stiffness operator apply   y += sum_cells P_c^T D^T ( c_c G_c (D x_c) )
+ * replaces  numba-cpu/operators.py:71-227  stiffness_operator(P, dphi, float_type) -> operator(x, cell_constants, y, G, dofmap)
+ *      and  cuda/operators.py:73-192       stiffness_operator(P, float_type) -> operator[grid, block](x, consts, y, G, dofmap, dphi)
+ * y is accumulated into (caller zeroes it).  Out-of-range dofmap entries are undefined behaviour, as
+ * in the reference (no bounds checks under njit / CUDA).
+ */
+int fus_stiffness_apply_f64(const double* x, const double* cell_constants, double* y, const double* G,
+                            const int32_t* dofmap, const double* dphi, int P, int64_t ncell, void* stream);
+int fus_stiffness_apply_f32(const float* x, const float* cell_constants, float* y, const float* G,
+                            const int32_t* dofmap, const float* dphi, int P, int64_t ncell, void* stream);
+
+/*
+ * Mass operator apply (cells: N = n^3; boundary facets: N = n^2; any N >= 1)
+ *   y[dofmap[e][i]] += x[dofmap[e][i]] * detJ[e][i] * entity_constants[e]
+ * replaces  numba-cpu/operators.py:19-68  mass_operator(N, float_type) -> operator(x, entity_constants, y, entity_detJ, entity_dofmap)
+ *      and  cuda/operators.py:18-70       mass_operator[grid, block](x, entity_constants, y, detJ_entity, entity_dofmap)
+ */
+int fus_mass_apply_f64(const double* x, const double* entity_constants, double* y, const double* entity_detJ,
+                       const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, void* stream);
+int fus_mass_apply_f32(const float* x, const float* entity_constants, float* y, const float* entity_detJ,
+                       const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, void* stream);
+
+/*
+ * Streaming vector kernels of the RK4 stage.
+ * replace  cuda/operators.py:195-274 (axpy, copy, fill, pointwise_divide, square)
+ *     and  numba-cpu/operators.py:230-300
+ */
+int fus_axpy_f64(double alpha, const double* x, double* y, int64_t n, void* stream);           /* y = alpha x + y */
+int fus_axpy_f32(float alpha, const float* x, float* y, int64_t n, void* stream);
+int fus_copy_f64(const double* a, double* b, int64_t n, void* stream);                         /* b = a */
+int fus_copy_f32(const float* a, float* b, int64_t n, void* stream);
+int fus_fill_f64(double alpha, double* x, int64_t n, void* stream);                            /* x = alpha */
+int fus_fill_f32(float alpha, float* x, int64_t n, void* stream);
+int fus_pointwise_divide_f64(const double* a, const double* b, double* c, int64_t n, void* stream); /* c = a / b */
+int fus_pointwise_divide_f32(const float* a, const float* b, float* c, int64_t n, void* stream);
+int fus_square_f64(const double* a, double* b, int64_t n, void* stream);                       /* b = a^2 */
+int fus_square_f32(const float* a, float* b, int64_t n, void* stream);
+
+/*
+ * Halo pack / unpack (all neighbours in ONE launch: ``index`` is the concatenation of the
+ * per-neighbour index lists, the send/recv buffer is the concatenation of the per-neighbour
+ * messages).  N = nlocal (offset of the ghost block in a dof vector).
+ * replace  cuda/scatterer.py:18-101 (pack_fwd, unpack_fwd, pack_rev, unpack_rev; one launch per neighbour there)
+ *     and  numba-cpu/scatterer.py:18-75 (pack, unpack_fwd, unpack_rev)
+ *   pack_fwd   : out[i] = in[index[i]]
+ *   unpack_fwd : out[index[i] + N] = in[i]
+ *   pack_rev   : out[i] = in[index[i] + N]
+ *   unpack_rev : out[index[i]] += in[i]          (atomic: two neighbours may hit one owned dof)
+ */
+int fus_pack_fwd_f64(const double* in, double* out, const int64_t* index, int64_t count, void* stream);
+int fus_pack_fwd_f32(const float* in, float* out, const int64_t* index, int64_t count, void* stream);
+int fus_unpack_fwd_f64(const double* in, double* out, const int64_t* index, int64_t count, int64_t N, void* stream);
+int fus_unpack_fwd_f32(const float* in, float* out, const int64_t* index, int64_t count, int64_t N, void* stream);
+int fus_pack_rev_f64(const double* in, double* out, const int64_t* index, int64_t count, int64_t N, void* stream);
+int fus_pack_rev_f32(const float* in, float* out, const int64_t* index, int64_t count, int64_t N, void* stream);
+int fus_unpack_rev_f64(const double* in, double* out, const int64_t* index, int64_t count, void* stream);
+int fus_unpack_rev_f32(const float* in, float* out, const int64_t* index, int64_t count, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* FUS_GPU_H */

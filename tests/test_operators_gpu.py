@@ -1,0 +1,219 @@
+"""GPU parity tests: HIP kernels (through the C ABI) vs the oracle and vs the
+golden vectors produced by the reference itself.  Design follows the reference's
+own tests (cuda/test_operators.py:213-356: mass, stiffness, boundary-facet mass,
+rel-l2 against a trusted assembly) with the dolfinx assembly replaced by the
+oracle / golden data."""
+
+import numpy as np
+import pytest
+
+from conftest import TOL, build_problem, golden_files, pkg, rel_l2, rel_max
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(0)
+    return pkg("device"), pkg("operators")
+
+
+def _check(got, ref, dtype, what):
+    tol = TOL[np.dtype(dtype)]
+    e2, em = rel_l2(got, ref), rel_max(got, ref)
+    assert e2 < tol["l2"] and em < tol["mx"], f"{what}: rel l2 {e2:.3e} (tol {tol['l2']}), rel max {em:.3e}"
+
+
+@pytest.mark.parametrize("path", golden_files("ops_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_golden_reference_outputs(gpu, path):
+    """Every golden case: same inputs the reference consumed, compare to what it produced."""
+    dev, ops = gpu
+    d = np.load(path)
+    P, dt = int(d["P"]), d["x"].dtype
+    n = P + 1
+    x, dm = dev.to_device(d["x"]), dev.to_device(d["dofmap"])
+    cc = dev.to_device(d["cell_constants"])
+    # stiffness (numba-cpu flavour)
+    y = dev.to_device(d["y0"])
+    ops.stiffness_operator(P, d["dphi_1d"].flatten(), dt)(x, cc, y, dev.to_device(d["ref_G"]), dm)
+    _check(y.copy_to_host(), d["ref_y_stiffness"], dt, "stiffness")
+    # stiffness (cuda flavour, 2-D dphi, launch config ignored)
+    y = dev.to_device(d["y0"])
+    op = ops.stiffness_operator(P, dt)
+    op[dm.shape[0], (n, n, n)](x, cc, y, dev.to_device(d["ref_G"]), dm, dev.to_device(d["dphi_1d"]))
+    _check(y.copy_to_host(), d["ref_y_stiffness"], dt, "stiffness (cuda flavour)")
+    # cell mass
+    y = dev.to_device(d["y0"])
+    ops.mass_operator(n**3, dt)(x, cc, y, dev.to_device(d["ref_detJ"]), dm)
+    _check(y.copy_to_host(), d["ref_y_mass"], dt, "mass")
+    # boundary-facet mass (cuda flavour)
+    y = dev.to_device(d["y0"])
+    ops.mass_operator[7, 128](x, dev.to_device(d["facet_constants"]), y, dev.to_device(d["ref_detJ_f"]),
+                              dev.to_device(d["bfacet_dofmap"]))
+    _check(y.copy_to_host(), d["ref_y_facet_mass"], dt, "facet mass")
+    # vector ops
+    va, vb = dev.to_device(d["va"]), dev.to_device(d["vb"])
+    yb = dev.to_device(d["vb"])
+    ops.axpy(va.numel())(float(d["alpha"]), va, yb)
+    _check(yb.copy_to_host(), d["ref_y_axpy"], dt, "axpy")
+    out = dev.device_array(va.shape, dt)
+    ops.pointwise_divide(va, vb, out)
+    _check(out.copy_to_host(), d["ref_y_divide"], dt, "pointwise_divide")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", list(range(1, 11)))
+def test_stiffness_all_degrees_vs_oracle(gpu, oracle_c, P, dtype):
+    """P = 1..10 on a perturbed (non-affine) mesh whose cell count is not a multiple
+    of the cells-per-workgroup batch (ragged last batch)."""
+    dev, ops = gpu
+    ncells = (3, 2, 3) if P <= 6 else (2, 1, 2)
+    pb = build_problem(P, ncells, dtype=dtype, perturb=0.16, seed=P)
+    mesh = pb["mesh"]
+    rng = np.random.default_rng(P)
+    y0 = rng.standard_normal(mesh.ndofs).astype(dtype)
+    y_ref = y0.copy()
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    y = dev.to_device(y0)
+    ops.stiffness_operator(P, pb["D"].flatten(), dtype)(
+        dev.to_device(pb["x"]), dev.to_device(pb["cc"]), y, dev.to_device(pb["G"]), dev.to_device(mesh.dofmap))
+    _check(y.copy_to_host(), y_ref, dtype, f"stiffness P={P}")
+
+
+@pytest.mark.parametrize("variant,remap", [(0, 0), (0, 1), (1, 0), (1, 1)])
+def test_stiffness_variants_cfg1(gpu, oracle_c, variant, remap):
+    """BASELINE config 1 (P=2, 18^3 cells, ~50k dofs) for every kernel variant / XCD remap."""
+    dev, ops = gpu
+    lib = pkg("_lib")
+    pb = build_problem(2, 18, perturb=0.16)
+    mesh = pb["mesh"]
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(2, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap, threads=4)
+    old = lib.get_tuning(lib.TUNE_STIFFNESS_VARIANT), lib.get_tuning(lib.TUNE_XCD_REMAP)
+    try:
+        lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, variant)
+        lib.set_tuning(lib.TUNE_XCD_REMAP, remap)
+        y = dev.to_device(np.zeros(mesh.ndofs))
+        ops.stiffness_operator(2, pb["D"].flatten(), np.float64)(
+            dev.to_device(pb["x"]), dev.to_device(pb["cc"]), y, dev.to_device(pb["G"]), dev.to_device(mesh.dofmap))
+        _check(y.copy_to_host(), y_ref, np.float64, f"variant {variant} remap {remap}")
+    finally:
+        lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, old[0])
+        lib.set_tuning(lib.TUNE_XCD_REMAP, old[1])
+
+
+def test_stiffness_p4_medium_vs_oracle(gpu, oracle_c):
+    """P=4, 12^3 perturbed cells (117k dofs): full vector compare + the reference's
+    invariants K.1 = 0 and symmetry v.Ku = u.Kv on the GPU result."""
+    dev, ops = gpu
+    pb = build_problem(4, 12, perturb=0.16)
+    mesh = pb["mesh"]
+    op = ops.stiffness_operator(4, pb["D"].flatten(), np.float64)
+    G, dm, cc = dev.to_device(pb["G"]), dev.to_device(mesh.dofmap), dev.to_device(pb["cc"])
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(4, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap, threads=4)
+    y = dev.to_device(np.zeros(mesh.ndofs))
+    op(dev.to_device(pb["x"]), cc, y, G, dm)
+    Ku = y.copy_to_host()
+    _check(Ku, y_ref, np.float64, "stiffness P=4 12^3")
+    # K * const = 0
+    y1 = dev.to_device(np.zeros(mesh.ndofs))
+    op(dev.to_device(np.full(mesh.ndofs, 3.0)), cc, y1, G, dm)
+    assert np.max(np.abs(y1.copy_to_host())) < 1e-10 * np.max(np.abs(Ku))
+    # symmetry
+    v = np.random.default_rng(5).standard_normal(mesh.ndofs)
+    y2 = dev.to_device(np.zeros(mesh.ndofs))
+    op(dev.to_device(v), cc, y2, G, dm)
+    a, b = float(v @ Ku), float(pb["x"] @ y2.copy_to_host())
+    assert abs(a - b) < 1e-11 * max(abs(a), abs(b))
+
+
+def test_empty_and_single_cell(gpu, oracle_c):
+    dev, ops = gpu
+    pb = build_problem(4, (1, 1, 1))
+    mesh = pb["mesh"]
+    op = ops.stiffness_operator(4, pb["D"].flatten(), np.float64)
+    x, cc = dev.to_device(pb["x"]), dev.to_device(pb["cc"])
+    G, dm = dev.to_device(pb["G"]), dev.to_device(mesh.dofmap)
+    y = dev.to_device(np.zeros(mesh.ndofs))
+    op(x, cc[:0], y, G[:0], dm[:0])  # zero cells: no-op
+    assert np.all(y.copy_to_host() == 0)
+    op(x, cc, y, G, dm)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(4, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    _check(y.copy_to_host(), y_ref, np.float64, "single cell")
+    m = ops.mass_operator(125, np.float64)
+    m(x, cc[:0], y, dev.to_device(pb["detJ"])[:0], dm[:0])
+
+
+def test_colliding_dofmap(gpu, oracle_c):
+    """Scatter-add under heavy collisions: every cell maps onto the same few dofs."""
+    dev, ops = gpu
+    P, n = 3, 4
+    pb = build_problem(P, (2, 2, 2), perturb=0.1)
+    rng = np.random.default_rng(3)
+    ncell = 37
+    dofmap = rng.integers(0, 50, size=(ncell, n**3), dtype=np.int32)
+    G = np.tile(pb["G"], (5, 1, 1))[:ncell].copy()
+    cc = rng.standard_normal(ncell)
+    x = rng.standard_normal(50)
+    y_ref = np.zeros(50)
+    oracle_c.stiffness_apply(P, pb["D"], x, cc, y_ref, G, dofmap)
+    y = dev.to_device(np.zeros(50))
+    ops.stiffness_operator(P, pb["D"].flatten(), np.float64)(
+        dev.to_device(x), dev.to_device(cc), y, dev.to_device(G), dev.to_device(dofmap))
+    _check(y.copy_to_host(), y_ref, np.float64, "colliding dofmap")
+
+
+def test_argument_errors(gpu):
+    dev, ops = gpu
+    import torch
+
+    pb = build_problem(2, (1, 1, 1))
+    mesh = pb["mesh"]
+    op = ops.stiffness_operator(2, pb["D"].flatten(), np.float64)
+    x, cc = dev.to_device(pb["x"]), dev.to_device(pb["cc"])
+    G, dm = dev.to_device(pb["G"]), dev.to_device(mesh.dofmap)
+    y = dev.to_device(np.zeros(mesh.ndofs))
+    with pytest.raises(TypeError):
+        op(x.float(), cc, y, G, dm)  # dtype mismatch
+    with pytest.raises(TypeError):
+        op(x, cc, y, G, dm.long())  # dofmap must be int32
+    with pytest.raises(Exception):
+        op(x.cpu(), cc, y, G, dm)  # host tensor: no CPU fallback
+    with pytest.raises(ValueError):
+        ops.stiffness_operator(11, np.float64)
+    with pytest.raises(ValueError):
+        op(x, cc, y, G[:, :5], dm)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_vector_ops(gpu, oracle_c, dtype):
+    dev, ops = gpu
+    rng = np.random.default_rng(0)
+    for n in (1, 2, 3, 255, 256, 257, 100003):
+        a = rng.standard_normal(n).astype(dtype)
+        b = (2 + rng.random(n)).astype(dtype)
+        for off in (0, 1):  # off=1: misaligned views take the scalar path
+            ad, bd = dev.to_device(a)[off:], dev.to_device(b)[off:]
+            ah, bh = a[off:].copy(), b[off:].copy()
+            if ah.size == 0:
+                continue
+            yd = bd.clone()
+            ops.axpy[1, 1](0.37, ad, yd)
+            yr = bh.copy()
+            oracle_c.axpy(0.37, ah, yr)
+            _check(yd.cpu().numpy(), yr, dtype, "axpy")
+            out = dev.device_array(ah.shape, dtype)
+            ops.copy(ad, out)
+            assert np.array_equal(out.copy_to_host(), ah)
+            ops.fill(1.5, out)
+            assert np.all(out.copy_to_host() == dtype(1.5))
+            ops.pointwise_divide[1, 1](ad, bd, out)
+            _check(out.copy_to_host(), ah / bh, dtype, "divide")
+            ops.square[1, 1](ad, out)
+            _check(out.copy_to_host(), ah * ah, dtype, "square")
