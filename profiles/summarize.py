@@ -1,0 +1,55 @@
+#!/usr/bin/env python3
+"""Condense gpurun_out/prof_<tag>/ (from profiles/run_profile.sh) into tracked files:
+  profiles/<tag>_kernel_stats.csv     rocprofv3 --kernel-trace --stats summary (verbatim)
+  profiles/<tag>_counters.json        per-launch averages of the PMC passes for the stiffness kernel
+  profiles/<tag>_bench.json           the bench line of the traced run
+  profiles/traffic_latest.json        what bench.py reports as roofline.traffic
+HBM traffic = 2 x FETCH_SIZE (gfx950 reports half the bytes of wide coalesced reads,
+guides/MI355X_MICROARCH.md 'HBM') + WRITE_SIZE, both in KiB per launch."""
+import collections
+import csv
+import json
+import os
+import shutil
+import sys
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+tag = sys.argv[1]
+kernel_key = sys.argv[2] if len(sys.argv) > 2 else "stiffness"
+src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
+out = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
+counters = {}
+for sub, name in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_tcc", "tcc")):
+    p = os.path.join(src, sub, f"{name}_counter_collection.csv")
+    if not os.path.exists(p):
+        continue
+    agg = collections.defaultdict(list)
+    for r in csv.DictReader(open(p)):
+        if kernel_key in r["Kernel_Name"]:
+            agg[r["Counter_Name"]].append(float(r["Counter_Value"]))
+            kname = r["Kernel_Name"]
+            meta = {k: r[k] for k in ("Grid_Size", "Workgroup_Size", "LDS_Block_Size", "VGPR_Count", "SGPR_Count", "Scratch_Size")}
+    for k, v in agg.items():
+        counters[k] = {"mean_per_launch": sum(v) / len(v), "launches": len(v)}
+stats = {}
+for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"))):
+    if kernel_key in r["Name"]:
+        stats = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])}
+bench = json.load(open(os.path.join(src, "bench_trace.json")))
+res = {"tag": tag, "kernel_stats": stats, "dispatch": meta, "counters": counters}
+if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
+    f, w = counters["FETCH_SIZE"]["mean_per_launch"], counters["WRITE_SIZE"]["mean_per_launch"]
+    res["hbm_bytes_per_launch"] = (2 * f + w) * 1024
+    res["fetch_bytes_corrected"] = 2 * f * 1024
+    res["write_bytes"] = w * 1024
+    ncell = bench["config"]["cells_per_gpu"]
+    res["algorithmic_bytes_per_launch"] = ncell * bench["roofline"]["algorithmic_bytes_per_cell"]
+    res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+    json.dump({"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": f"profiles/{tag}_counters.json"},
+              open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
+if "TCC_EA0_ATOMIC_sum" in counters and stats:
+    res["atomic_requests_per_s"] = counters["TCC_EA0_ATOMIC_sum"]["mean_per_launch"] / (stats["avg_ns"] * 1e-9)
+json.dump(res, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
+json.dump(bench, open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)
+print(json.dumps(res, indent=1))

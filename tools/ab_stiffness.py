@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Interleaved A/B timing of stiffness-kernel tunings in ONE process (guide rule 24):
+N variants x M rounds on the BASELINE config-3 workload; prints median / min per variant.
+
+    python tools/ab_stiffness.py [--cells 54] [--degree 4] [--rounds 7] [--reps 10] v:r [v:r ...]
+where each ``v:r`` is (stiffness variant):(xcd remap)."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=54)
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--rounds", type=int, default=7)
+    ap.add_argument("--reps", type=int, default=10)
+    ap.add_argument("--dtype", default="f64")
+    ap.add_argument("configs", nargs="*", default=["0:1", "0:0", "1:1", "1:0"])
+    a = ap.parse_args()
+    import torch
+
+    import bench
+    import fusgpu_loader
+    from conftest import build_problem
+
+    lib = fusgpu_loader.submodule("_lib")
+    ops = fusgpu_loader.submodule("operators")
+    dt = np.float64 if a.dtype == "f64" else np.float32
+    pb = build_problem(a.degree, a.cells, dtype=dt, perturb=0.16)
+    mesh = pb["mesh"]
+    dev = torch.device("cuda", 0)
+    x = torch.from_numpy(pb["x"]).to(dev)
+    cc = torch.from_numpy(pb["cc"]).to(dev)
+    G = torch.from_numpy(pb["G"]).to(dev)
+    dm = torch.from_numpy(mesh.dofmap).to(dev)
+    y = torch.zeros(mesh.ndofs, dtype=x.dtype, device=dev)
+    op = ops.stiffness_operator(a.degree, pb["D"].flatten(), dt)
+    cfgs = [tuple(int(v) for v in c.split(":")) for c in a.configs]
+    times = {c: [] for c in cfgs}
+    for rnd in range(a.rounds + 1):
+        for c in cfgs:
+            lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, c[0])
+            lib.set_tuning(lib.TUNE_XCD_REMAP, c[1])
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            op(x, cc, y, G, dm)
+            e0.record()
+            for _ in range(a.reps):
+                op(x, cc, y, G, dm)
+            e1.record()
+            torch.cuda.synchronize()
+            if rnd > 0:
+                times[c].append(e0.elapsed_time(e1) / a.reps)
+    bpc = bench.stiffness_bytes_per_cell(a.degree, np.dtype(dt).itemsize)
+    for c in cfgs:
+        t = np.array(times[c])
+        gbs = mesh.ncells * bpc / (np.median(t) * 1e-3) / 1e9
+        print(f"variant {c[0]} remap {c[1]}: median {np.median(t):.4f} ms  min {t.min():.4f} ms  "
+              f"{gbs:.0f} GB/s  ({100 * gbs / 8000:.1f}% of 8 TB/s)  {mesh.ndofs / np.median(t) / 1e6:.2f} GDOF/s")
+
+
+if __name__ == "__main__":
+    main()
