@@ -28,9 +28,12 @@ def _signatures():
         "fus_device_info": [_int, C.c_char_p, C.POINTER(_int), C.POINTER(_i64), C.POINTER(_int)],
         "fus_set_tuning": [_int, _int],
         "fus_get_tuning": [_int],
+        "fus_stiffness_plan_bytes": [_int, _i64],
+        "fus_stiffness_plan_build": [_vp, _int, _i64, _vp, _i64, _vp],
     }
     for suf, ct in _SUFFIXES:
         sig[f"fus_stiffness_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
+        sig[f"fus_stiffness_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]
         sig[f"fus_copy_{suf}"] = [_vp, _vp, _i64, _vp]
@@ -72,7 +75,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = _int
+        fn.restype = _i64 if name == "fus_stiffness_plan_bytes" else _int
     lib.fus_error_string.argtypes = [_int]
     lib.fus_error_string.restype = C.c_char_p
     _lib = lib

@@ -10,13 +10,14 @@
 
 #include "halo.hpp"
 #include "mass.hpp"
+#include "plan.hpp"
 #include "stiffness.hpp"
 #include "vecops.hpp"
 
 namespace {
 
 std::atomic<int> g_stiffness_variant{0};
-std::atomic<int> g_xcd_remap{1};
+std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab_variants.log)
 std::atomic<int> g_mass_variant{0};
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
@@ -54,6 +55,46 @@ int stiffness_apply(const T* x, const T* cc, T* y, const T* G, const int32_t* do
 #define FUS_CASE(PP) \
   case PP:           \
     e = stiffness_dispatch_variant<T, PP>(x, cc, y, G, dofmap, dphi, ncell, s); \
+    break;
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return hip_rc(e);
+}
+
+template <int P>
+int64_t plan_bytes_p(int64_t ncell) {
+  return fus::plan_view(nullptr, P, fus::plan_cells_per_batch<P>(), ncell).bytes;
+}
+
+int64_t plan_bytes(int P, int64_t ncell) {
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    return plan_bytes_p<PP>(ncell);
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return FUS_ERR_UNSUPPORTED_DEGREE;
+}
+
+template <typename T>
+int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int P,
+                            int64_t ncell, void* stream) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
+  if (ncell == 0) return FUS_OK;
+  if (!x || !cc || !y || !G || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  const int remap = g_xcd_remap.load(std::memory_order_relaxed);
+  hipError_t e = hipErrorInvalidValue;
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    e = fus::launch_stiffness_plan<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -145,6 +186,41 @@ int fus_stiffness_apply_f64(const double* x, const double* cc, double* y, const 
 int fus_stiffness_apply_f32(const float* x, const float* cc, float* y, const float* G, const int32_t* dofmap,
                             const float* dphi, int P, int64_t ncell, void* stream) {
   return stiffness_apply<float>(x, cc, y, G, dofmap, dphi, P, ncell, stream);
+}
+
+int64_t fus_stiffness_plan_bytes(int P, int64_t ncell) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  return plan_bytes(P, ncell);
+}
+
+int fus_stiffness_plan_build(const int32_t* dofmap, int P, int64_t ncell, void* workspace, int64_t workspace_bytes,
+                             void* stream) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
+  if (!workspace || misaligned(workspace, 256) || workspace_bytes < plan_bytes(P, ncell)) return FUS_ERR_INVALID_ARGUMENT;
+  if (ncell == 0) return FUS_OK;
+  if (!dofmap) return FUS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipErrorInvalidValue;
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    e = fus::launch_plan_build<PP>(dofmap, ncell, workspace, s); \
+    break;
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return hip_rc(e);
+}
+
+int fus_stiffness_apply_planned_f64(const double* x, const double* cc, double* y, const double* G, const void* ws,
+                                    const double* dphi, int P, int64_t ncell, void* stream) {
+  return stiffness_apply_planned<double>(x, cc, y, G, ws, dphi, P, ncell, stream);
+}
+int fus_stiffness_apply_planned_f32(const float* x, const float* cc, float* y, const float* G, const void* ws,
+                                    const float* dphi, int P, int64_t ncell, void* stream) {
+  return stiffness_apply_planned<float>(x, cc, y, G, ws, dphi, P, ncell, stream);
 }
 
 int fus_mass_apply_f64(const double* x, const double* c, double* y, const double* detJ, const int32_t* dofmap, int N,

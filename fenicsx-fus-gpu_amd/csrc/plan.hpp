@@ -1,0 +1,326 @@
+// Batch plan for the scatter side of the operators (built once per dofmap, on the device).
+//
+// Why: the chip executes float atomics at the memory side at ~20 G 64-byte requests/s
+// (profiles/r01a_counters.json: 37.6 requests per P=4 cell, kernel time == requests / 20 G/s).
+// A workgroup handles a batch of CPB consecutive cells; cells of a batch share faces, and in any
+// mesh numbering with locality the batch's distinct dofs form long contiguous runs.  The plan
+// stores, per batch, the SORTED list of distinct dofs and, per (cell, local dof), the 16-bit slot
+// of its dof in that list.  The apply kernel then
+//   * gathers x once per distinct dof with consecutive lanes on ascending addresses,
+//   * pre-reduces the contributions of the batch in LDS (ds_add),
+//   * issues ONE global atomic per distinct dof, consecutive lanes on ascending addresses, so a
+//     wave-instruction covers few 64-byte requests.
+//
+// Workspace layout (caller-owned device buffer, fus_stiffness_plan_bytes() bytes, 256-B aligned):
+//   [0, 256)                        header (int64: magic, P, cpb, ncell, nbatch, entries/batch)
+//   nu     int32 [nbatch]           distinct dofs of each batch            (256-B aligned)
+//   udofs  int32 [nbatch][CPB*Nd]   sorted distinct dofs, first nu[b] valid (256-B aligned)
+//   slot   uint16[nbatch][CPB*Nd]   slot of (cell, local dof) = position in udofs[b]
+// Nd = (P+1)^3; the last batch may be ragged (cells >= ncell are never touched).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "stiffness.hpp"
+
+namespace fus {
+
+constexpr int64_t kPlanMagic = 0x46555350304c414eLL;  // "FUSP0LAN"
+constexpr int kPlanHeaderBytes = 256;
+
+__host__ __device__ constexpr int next_pow2(int v) {
+  int p = 1;
+  while (p < v) p <<= 1;
+  return p;
+}
+__host__ __device__ constexpr int64_t align256(int64_t v) { return (v + 255) / 256 * 256; }
+
+template <int P>
+__host__ __device__ constexpr int plan_cells_per_batch() {
+  return default_cells_per_block<P>(256);
+}
+
+struct PlanView {
+  int64_t nbatch;
+  int64_t entries;  // CPB * Nd
+  int32_t* nu;
+  int32_t* udofs;
+  uint16_t* slot;
+  int64_t bytes;
+};
+
+inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
+  const int n = P + 1;
+  PlanView v;
+  v.entries = (int64_t)cpb * n * n * n;
+  v.nbatch = (ncell + cpb - 1) / cpb;
+  char* base = static_cast<char*>(workspace);
+  int64_t off = kPlanHeaderBytes;
+  v.nu = reinterpret_cast<int32_t*>(base + off);
+  off += align256(v.nbatch * (int64_t)sizeof(int32_t));
+  v.udofs = reinterpret_cast<int32_t*>(base + off);
+  off += align256(v.nbatch * v.entries * (int64_t)sizeof(int32_t));
+  v.slot = reinterpret_cast<uint16_t*>(base + off);
+  off += align256(v.nbatch * v.entries * (int64_t)sizeof(uint16_t));
+  v.bytes = off;
+  return v;
+}
+
+// One workgroup per batch: LDS bitonic sort of (dof << 16 | position) keys, unique flags,
+// block scan, write slots + distinct dofs.
+template <int P, int CPB>
+__global__ void __launch_bounds__(256)
+    plan_build_kernel(const int32_t* __restrict__ dofmap, int64_t ncell, int32_t* __restrict__ nu,
+                      int32_t* __restrict__ udofs, uint16_t* __restrict__ slot) {
+  constexpr int n = P + 1, Nd = n * n * n;
+  constexpr int M = CPB * Nd;
+  constexpr int M2 = next_pow2(M) < 256 ? 256 : next_pow2(M);
+  constexpr int CH = M2 / 256;  // elements per thread in the scan phase
+  static_assert(M < 65536, "slot ids are 16-bit");
+  __shared__ uint64_t keys[M2];
+  __shared__ int cnt[256];
+
+  const int tid = threadIdx.x;
+  const int64_t batch = blockIdx.x;
+  const int64_t cell0 = batch * CPB;
+  const int64_t left = ncell - cell0;
+  const int valid = (int)((left < CPB ? left : CPB) * Nd);
+  const int32_t* dm = dofmap + cell0 * Nd;
+
+  for (int i = tid; i < M2; i += 256)
+    keys[i] = (i < valid) ? (((uint64_t)(uint32_t)dm[i] << 16) | (uint64_t)i) : ~0ull;
+  __syncthreads();
+
+  for (int k = 2; k <= M2; k <<= 1) {
+    for (int j = k >> 1; j > 0; j >>= 1) {
+      for (int i = tid; i < M2; i += 256) {
+        const int l = i ^ j;
+        if (l > i) {
+          const uint64_t a = keys[i], b = keys[l];
+          const bool up = (i & k) == 0;
+          if ((a > b) == up) {
+            keys[i] = b;
+            keys[l] = a;
+          }
+        }
+      }
+      __syncthreads();
+    }
+  }
+
+  // unique flags over this thread's contiguous chunk [tid*CH, tid*CH+CH)
+  const int i0 = tid * CH;
+  int local = 0;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int i = i0 + c;
+    if (i < valid) {
+      const uint32_t d = (uint32_t)(keys[i] >> 16);
+      const bool first = (i == 0) || (d != (uint32_t)(keys[i - 1] >> 16));
+      local += first ? 1 : 0;
+    }
+  }
+  cnt[tid] = local;
+  __syncthreads();
+  for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan
+    const int v = (tid >= off) ? cnt[tid - off] : 0;
+    __syncthreads();
+    cnt[tid] += v;
+    __syncthreads();
+  }
+  int s = cnt[tid] - local;  // exclusive prefix = slot of the first new dof in this chunk
+  if (tid == 255) nu[batch] = cnt[255];
+  int32_t* ud = udofs + batch * (int64_t)M;
+  uint16_t* sl = slot + batch * (int64_t)M;
+#pragma unroll
+  for (int c = 0; c < CH; ++c) {
+    const int i = i0 + c;
+    if (i < valid) {
+      const uint64_t key = keys[i];
+      const uint32_t d = (uint32_t)(key >> 16);
+      const bool first = (i == 0) || (d != (uint32_t)(keys[i - 1] >> 16));
+      if (first) {
+        ud[s] = (int32_t)d;
+        ++s;
+      }
+      sl[key & 0xffffu] = (uint16_t)(s - 1);
+    }
+  }
+}
+
+template <int P>
+inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* workspace, hipStream_t stream) {
+  constexpr int CPB = plan_cells_per_batch<P>();
+  if (ncell <= 0) return hipSuccess;
+  PlanView v = plan_view(workspace, P, CPB, ncell);
+  if (v.nbatch > 0x7fffffffLL) return hipErrorInvalidValue;
+  int64_t hdr[6] = {kPlanMagic, P, CPB, ncell, v.nbatch, v.entries};
+  hipError_t e = hipMemcpyAsync(workspace, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL((plan_build_kernel<P, CPB>), dim3((unsigned)v.nbatch), dim3(256), 0, stream, dofmap, ncell, v.nu,
+                     v.udofs, v.slot);
+  return hipGetLastError();
+}
+
+template <typename T>
+__device__ __forceinline__ void lds_atomic_add(T* p, T v) {
+  __hip_atomic_fetch_add(p, v, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_WORKGROUP);
+}
+
+// Planned stiffness apply: same contraction structure as stiffness_col_kernel (stiffness.hpp),
+// gather / scatter through the batch plan.
+template <typename T, int P, int CPB>
+__global__ void __launch_bounds__((col_block_threads<P, CPB>()))
+    stiffness_plan_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
+                          const T* __restrict__ G, const int32_t* __restrict__ nu,
+                          const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
+                          const T* __restrict__ dphi, int64_t ncell, int xcd_remap) {
+  constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
+  constexpr int S = lds_cell_stride<T, P>();
+  constexpr int BLOCK = col_block_threads<P, CPB>();
+  constexpr int M = CPB * Nd;
+  constexpr int SPT = (M + BLOCK - 1) / BLOCK;  // distinct-dof slots per thread (upper bound)
+
+  __shared__ T sD[n2];
+  __shared__ T su[CPB * S];
+  __shared__ T sfy[CPB * S];
+  __shared__ T sfz[CPB * S];
+  __shared__ T sxy[M];  // x values of the batch's distinct dofs, later their y partial sums
+
+  const int tid = threadIdx.x;
+  const unsigned batch = remap_block(blockIdx.x, gridDim.x, xcd_remap);
+  const int lc = tid / n2;
+  const int t = tid - lc * n2;
+  const int ty = t / n, tz = t - ty * n;
+  const int64_t cell = (int64_t)batch * CPB + lc;
+  const bool active = (lc < CPB) && (cell < ncell);
+  const int nu_b = nu[batch];
+  const int32_t* ud = udofs + (int64_t)batch * M;
+
+  if (tid < n2) sD[tid] = dphi[tid];
+
+  // ---- issue every HBM load of the batch up front ---------------------------------------------
+  // (branch-free: out-of-range slots re-read slot 0, so the loads issue back to back)
+  int32_t mydof[SPT];
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    mydof[r] = ud[s < nu_b ? s : 0];
+  }
+  uint16_t sl[n];
+  T g[n][6];
+  T coeff = T(0);
+  if (active) {
+    const uint16_t* sp = slot + cell * Nd + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+    const T* Gc = G + (cell * Nd + t) * 6;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
+    coeff = cell_constants[cell];
+  }
+  T xv[SPT];
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) xv[r] = x[mydof[r]];
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    if (s < nu_b) sxy[s] = xv[r];
+  }
+  __syncthreads();
+
+  T u[n];
+  if (active) {
+    T* cu = su + lc * S + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) {
+      u[ix] = sxy[sl[ix]];
+      cu[ix * n2] = u[ix];
+    }
+  }
+  __syncthreads();
+
+  // all reads of the x values are done: the buffer becomes the y accumulator
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    if (s < nu_b) sxy[s] = T(0);
+  }
+
+  T fx[n];
+  if (active) {
+    T dy[n], dz[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      dy[i] = sD[ty * n + i];
+      dz[i] = sD[tz * n + i];
+    }
+    const T* cu_y = su + lc * S + tz;
+    const T* cu_z = su + lc * S + ty * n;
+    T* cfy = sfy + lc * S + t;
+    T* cfz = sfz + lc * S + t;
+#pragma unroll
+    for (int qx = 0; qx < n; ++qx) {
+      T vx = T(0);
+#pragma unroll
+      for (int ix = 0; ix < n; ++ix) vx += dphi[qx * n + ix] * u[ix];
+      T vy = T(0), vz = T(0);
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        vy += dy[i] * cu_y[qx * n2 + i * n];
+        vz += dz[i] * cu_z[qx * n2 + i];
+      }
+      const T* gq = g[qx];
+      fx[qx] = coeff * (gq[0] * vx + gq[1] * vy + gq[2] * vz);
+      cfy[qx * n2] = coeff * (gq[1] * vx + gq[3] * vy + gq[4] * vz);
+      cfz[qx * n2] = coeff * (gq[2] * vx + gq[4] * vy + gq[5] * vz);
+    }
+  }
+  __syncthreads();
+
+  if (active) {
+    T dyT[n], dzT[n];
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      dyT[q] = sD[q * n + ty];
+      dzT[q] = sD[q * n + tz];
+    }
+    const T* cf_y = sfy + lc * S + tz;
+    const T* cf_z = sfz + lc * S + ty * n;
+#pragma unroll
+    for (int jx = 0; jx < n; ++jx) {
+      T acc = T(0);
+#pragma unroll
+      for (int qx = 0; qx < n; ++qx) acc += dphi[qx * n + jx] * fx[qx];
+#pragma unroll
+      for (int q = 0; q < n; ++q) {
+        acc += dyT[q] * cf_y[jx * n2 + q * n];
+        acc += dzT[q] * cf_z[jx * n2 + q];
+      }
+      lds_atomic_add(&sxy[sl[jx]], acc);
+    }
+  }
+  __syncthreads();
+
+  // one global atomic per distinct dof; consecutive lanes -> ascending, mostly contiguous addresses
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sxy[s]);
+  }
+}
+
+template <typename T, int P>
+inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
+                                        const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream) {
+  constexpr int CPB = plan_cells_per_batch<P>();
+  if (ncell <= 0) return hipSuccess;
+  PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
+  constexpr int threads = col_block_threads<P, CPB>();
+  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB>), dim3((unsigned)v.nbatch), dim3(threads), 0, stream, x, cc, y,
+                     G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap);
+  return hipGetLastError();
+}
+
+}  // namespace fus

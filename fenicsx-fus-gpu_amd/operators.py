@@ -24,12 +24,51 @@ there is no CPU fallback.
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
 from . import _lib
 
 _req = _lib.require_device_tensor
+
+# The stiffness operator builds a batch plan (csrc/plan.hpp) the first time it sees a dofmap and
+# reuses it while that dofmap array is unchanged.  FUS_STIFFNESS_PLAN=0 (or use_plan(False))
+# selects the plan-free kernel that reads ``dofmap`` directly.
+_USE_PLAN = os.environ.get("FUS_STIFFNESS_PLAN", "1") != "0"
+
+
+def use_plan(flag: bool):
+    global _USE_PLAN
+    _USE_PLAN = bool(flag)
+
+
+class _PlanCache:
+    """Plan workspaces keyed on the identity of the dofmap array (pointer, shape, version)."""
+
+    def __init__(self, P: int):
+        self.P = P
+        self._plans = {}
+
+    def get(self, dofmap: torch.Tensor) -> torch.Tensor:
+        key = (dofmap.data_ptr(), tuple(dofmap.shape), dofmap._version, dofmap.device.index)
+        ws = self._plans.get(key)
+        if ws is None:
+            lib = _lib.load()
+            ncell = dofmap.shape[0]
+            nbytes = lib.fus_stiffness_plan_bytes(self.P, ncell)
+            if nbytes < 0:
+                _lib.check(int(nbytes), "fus_stiffness_plan_bytes")
+            ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dofmap.device)
+            _lib.check(
+                lib.fus_stiffness_plan_build(dofmap.data_ptr(), self.P, ncell, ws.data_ptr(), int(nbytes), _lib.stream_ptr()),
+                "fus_stiffness_plan_build",
+            )
+            if len(self._plans) >= 8:  # bounded: drop the oldest plan
+                self._plans.pop(next(iter(self._plans)))
+            self._plans[key] = ws
+        return ws
 
 
 class _Launchable:
@@ -94,6 +133,8 @@ class _StiffnessOperator(_Launchable):
         self.n = self.P + 1
         self.dtype = _lib.torch_dtype(float_type)
         self._fn = getattr(_lib.load(), f"fus_stiffness_apply_{_lib.suffix(self.dtype)}")
+        self._fn_planned = getattr(_lib.load(), f"fus_stiffness_apply_planned_{_lib.suffix(self.dtype)}")
+        self._plans = _PlanCache(self.P)
         self._dphi = None
         self._dphi_src = None
         if dphi is not None:
@@ -125,11 +166,21 @@ class _StiffnessOperator(_Launchable):
             raise ValueError(f"G must be [ncell, {nd}, 6]")
         if cell_constants.numel() != ncell:
             raise ValueError("cell_constants must have one value per cell")
-        _lib.check(
-            self._fn(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(), dofmap.data_ptr(),
-                     dphi_t.data_ptr(), self.P, int(ncell), _lib.stream_ptr()),
-            "fus_stiffness_apply",
-        )
+        if ncell == 0:
+            return
+        if _USE_PLAN:
+            ws = self._plans.get(dofmap)
+            _lib.check(
+                self._fn_planned(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(), ws.data_ptr(),
+                                 dphi_t.data_ptr(), self.P, int(ncell), _lib.stream_ptr()),
+                "fus_stiffness_apply_planned",
+            )
+        else:
+            _lib.check(
+                self._fn(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(), dofmap.data_ptr(),
+                         dphi_t.data_ptr(), self.P, int(ncell), _lib.stream_ptr()),
+                "fus_stiffness_apply",
+            )
 
     # numba-cpu flavour: op(x, cell_constants, y, G, dofmap)
     def __call__(self, x, cell_constants, y, G, dofmap):

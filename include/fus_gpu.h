@@ -63,6 +63,23 @@ int fus_stiffness_apply_f32(const float* x, const float* cell_constants, float* 
                             const int32_t* dofmap, const float* dphi, int P, int64_t ncell, void* stream);
 
 /*
+ * Batch plan for the gather/scatter side (optional fast path; same numerical contract).
+ * Built once per dofmap on the device into a caller-owned workspace; see csrc/plan.hpp for the
+ * layout.  The reference has no counterpart: its CUDA kernel issues one atomic per (cell, dof)
+ * (cuda/operators.py:190).  The planned apply reads the plan INSTEAD of ``dofmap``.
+ *   fus_stiffness_plan_bytes : workspace size in bytes for (P, ncell), or a negative error code
+ *   fus_stiffness_plan_build : fill ``workspace`` (256-byte aligned) from ``dofmap``; asynchronous
+ *   fus_stiffness_apply_planned_* : y += K x using a workspace built for the same (P, ncell) dofmap
+ */
+int64_t fus_stiffness_plan_bytes(int P, int64_t ncell);
+int fus_stiffness_plan_build(const int32_t* dofmap, int P, int64_t ncell, void* workspace, int64_t workspace_bytes,
+                             void* stream);
+int fus_stiffness_apply_planned_f64(const double* x, const double* cell_constants, double* y, const double* G,
+                                    const void* workspace, const double* dphi, int P, int64_t ncell, void* stream);
+int fus_stiffness_apply_planned_f32(const float* x, const float* cell_constants, float* y, const float* G,
+                                    const void* workspace, const float* dphi, int P, int64_t ncell, void* stream);
+
+/*
  * Mass operator apply (cells: N = n^3; boundary facets: N = n^2; any N >= 1)
  *   y[dofmap[e][i]] += x[dofmap[e][i]] * detJ[e][i] * entity_constants[e]
  * replaces  numba-cpu/operators.py:19-68  mass_operator(N, float_type) -> operator(x, entity_constants, y, entity_detJ, entity_dofmap)

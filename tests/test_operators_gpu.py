@@ -12,6 +12,15 @@ from conftest import TOL, build_problem, golden_files, pkg, rel_l2, rel_max
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(params=[True, False], ids=["plan", "noplan"])
+def plan_mode(request):
+    """Run a test on the planned (default) and the plan-free stiffness path."""
+    ops = pkg("operators")
+    ops.use_plan(request.param)
+    yield request.param
+    ops.use_plan(True)
+
+
 @pytest.fixture(scope="module")
 def gpu():
     import torch
@@ -29,7 +38,7 @@ def _check(got, ref, dtype, what):
 
 
 @pytest.mark.parametrize("path", golden_files("ops_"), ids=lambda p: p.split("/")[-1][:-4])
-def test_golden_reference_outputs(gpu, path):
+def test_golden_reference_outputs(gpu, plan_mode, path):
     """Every golden case: same inputs the reference consumed, compare to what it produced."""
     dev, ops = gpu
     d = np.load(path)
@@ -67,7 +76,7 @@ def test_golden_reference_outputs(gpu, path):
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("P", list(range(1, 11)))
-def test_stiffness_all_degrees_vs_oracle(gpu, oracle_c, P, dtype):
+def test_stiffness_all_degrees_vs_oracle(gpu, oracle_c, plan_mode, P, dtype):
     """P = 1..10 on a perturbed (non-affine) mesh whose cell count is not a multiple
     of the cells-per-workgroup batch (ragged last batch)."""
     dev, ops = gpu
@@ -89,6 +98,7 @@ def test_stiffness_variants_cfg1(gpu, oracle_c, variant, remap):
     """BASELINE config 1 (P=2, 18^3 cells, ~50k dofs) for every kernel variant / XCD remap."""
     dev, ops = gpu
     lib = pkg("_lib")
+    ops.use_plan(False)  # the variants are plan-free kernels
     pb = build_problem(2, 18, perturb=0.16)
     mesh = pb["mesh"]
     y_ref = np.zeros(mesh.ndofs)
@@ -104,9 +114,10 @@ def test_stiffness_variants_cfg1(gpu, oracle_c, variant, remap):
     finally:
         lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, old[0])
         lib.set_tuning(lib.TUNE_XCD_REMAP, old[1])
+        ops.use_plan(True)
 
 
-def test_stiffness_p4_medium_vs_oracle(gpu, oracle_c):
+def test_stiffness_p4_medium_vs_oracle(gpu, oracle_c, plan_mode):
     """P=4, 12^3 perturbed cells (117k dofs): full vector compare + the reference's
     invariants K.1 = 0 and symmetry v.Ku = u.Kv on the GPU result."""
     dev, ops = gpu
@@ -132,7 +143,7 @@ def test_stiffness_p4_medium_vs_oracle(gpu, oracle_c):
     assert abs(a - b) < 1e-11 * max(abs(a), abs(b))
 
 
-def test_empty_and_single_cell(gpu, oracle_c):
+def test_empty_and_single_cell(gpu, oracle_c, plan_mode):
     dev, ops = gpu
     pb = build_problem(4, (1, 1, 1))
     mesh = pb["mesh"]
@@ -150,7 +161,7 @@ def test_empty_and_single_cell(gpu, oracle_c):
     m(x, cc[:0], y, dev.to_device(pb["detJ"])[:0], dm[:0])
 
 
-def test_colliding_dofmap(gpu, oracle_c):
+def test_colliding_dofmap(gpu, oracle_c, plan_mode):
     """Scatter-add under heavy collisions: every cell maps onto the same few dofs."""
     dev, ops = gpu
     P, n = 3, 4

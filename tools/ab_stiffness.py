@@ -3,7 +3,7 @@
 N variants x M rounds on the BASELINE config-3 workload; prints median / min per variant.
 
     python tools/ab_stiffness.py [--cells 54] [--degree 4] [--rounds 7] [--reps 10] v:r [v:r ...]
-where each ``v:r`` is (stiffness variant):(xcd remap)."""
+where each ``v:r`` is (stiffness variant):(xcd remap); variant ``p`` = planned kernel."""
 import argparse
 import os
 import sys
@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="f64")
-    ap.add_argument("configs", nargs="*", default=["0:1", "0:0", "1:1", "1:0"])
+    ap.add_argument("configs", nargs="*", default=["p:1", "p:0", "0:1", "1:0"])
     a = ap.parse_args()
     import torch
 
@@ -42,11 +42,13 @@ def main():
     dm = torch.from_numpy(mesh.dofmap).to(dev)
     y = torch.zeros(mesh.ndofs, dtype=x.dtype, device=dev)
     op = ops.stiffness_operator(a.degree, pb["D"].flatten(), dt)
-    cfgs = [tuple(int(v) for v in c.split(":")) for c in a.configs]
+    cfgs = [tuple(-1 if v == "p" else int(v) for v in c.split(":")) for c in a.configs]
     times = {c: [] for c in cfgs}
     for rnd in range(a.rounds + 1):
         for c in cfgs:
-            lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, c[0])
+            ops.use_plan(c[0] < 0)
+            if c[0] >= 0:
+                lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, c[0])
             lib.set_tuning(lib.TUNE_XCD_REMAP, c[1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             op(x, cc, y, G, dm)
