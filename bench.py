@@ -153,7 +153,12 @@ def main():
     device = torch.device("cuda", local_rank)
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group("nccl", device_id=device)
+        opts = None
+        try:  # comm kernels must get CUs while a chip-filling operator kernel runs
+            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+        except Exception:
+            pass
+        dist.init_process_group("nccl", device_id=device, pg_options=opts)
 
     lib = fusgpu_loader.submodule("_lib")
     ops = fusgpu_loader.submodule("operators")
@@ -200,7 +205,7 @@ def main():
     halo = None
     if world > 1:
         scat = fusgpu_loader.submodule("scatterer")
-        halo = scat.HaloApply(mesh, op, dist.group.WORLD, device, dt)
+        halo = scat.HaloApply(mesh, op, scat.TorchComm(), dt, overlap=os.environ.get("FUS_HALO_OVERLAP", "1") != "0")
 
     def step():
         if halo is None:
@@ -233,7 +238,17 @@ def main():
     ev_ms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
 
     if halo is not None:
-        kern_ms = halo.kernel_ms_estimate(ev_ms)
+        # kernel time at N > 1: the three sub-launches (interior / boundary / interior) without
+        # any exchange, timed after (outside) the timed region
+        reps = 10
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        halo.apply_local_only(x_d, cc_d, y_d, G_d, dm_d)
+        e0.record()
+        for _ in range(reps):
+            halo.apply_local_only(x_d, cc_d, y_d, G_d, dm_d)
+        e1.record()
+        torch.cuda.synchronize()
+        kern_ms = e0.elapsed_time(e1) / reps
     else:
         kern_ms = float(ev_ms.mean())  # N = 1: the step IS the stiffness kernel launch
 
@@ -265,6 +280,8 @@ def main():
             "geometry": "general per-quadrature-point G[ncell][n^3][6] (no affine shortcut)",
             "stiffness_kernel": "planned (batch plan, LDS pre-reduction)" if ops._USE_PLAN else f"plan-free variant {lib.get_tuning(lib.TUNE_STIFFNESS_VARIANT)}",
             "xcd_remap": lib.get_tuning(lib.TUNE_XCD_REMAP),
+            "halo": None if halo is None else ("overlapped" if halo.overlap else "sequential"),
+            "halo_exposed_ms": None if halo is None else max(0.0, ms_per_step - kern_ms),
         },
         "roofline": {
             "bound": "hbm",

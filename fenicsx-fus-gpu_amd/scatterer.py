@@ -1,0 +1,241 @@
+"""
+Ghost-dof halo exchange: ``scatter_reverse`` / ``scatter_forward`` with the
+reference's call surface and semantics
+
+    scatter_reverse(comm, owners_data, ghosts_data, N, float_type) -> scatter(buffer)
+    scatter_forward(comm, owners_data, ghosts_data, N, float_type) -> scatter(buffer)
+        cuda/scatterer.py:104-188, 191-277   (owners_data/ghosts_data: 3-element lists)
+        numba-cpu/scatterer.py:78-141, 144-207 (4-element flat lists with offsets)
+
+  reverse: my ghost values -> their owners, ADDED there          (ghost partial sums)
+  forward: my owned values -> the ranks that ghost them, COPIED  (ghost refresh)
+both in place on ``buffer`` (length nlocal + nghost, ghosts at ``[N:]``).
+
+MI355X-first differences from the reference:
+  * one fused pack and one fused unpack launch for ALL neighbours (index lists
+    concatenated) instead of one tiny kernel per neighbour;
+  * transport = one neighbour all-to-all-v (``torch.distributed`` -> RCCL grouped
+    send/recv over xGMI) instead of per-neighbour MPI Isend/Irecv on device
+    pointers; no host-blocking device synchronisation anywhere: ordering is by
+    stream (pack -> exchange -> unpack), so the host runs ahead;
+  * split-phase ``begin()`` / ``end()`` so interior-cell operator application
+    overlaps the exchange (``HaloApply`` below).
+
+``comm`` is a ``TorchComm`` (or anything with ``.rank``, ``.size``,
+``.alltoallv``); ``kernels`` selects the pack/unpack implementation: the HIP
+kernels of libfusgpu.so by default (GPU tensors; no CPU fallback) -- tests
+inject their own for gloo-on-CPU runs.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import _lib
+from .utils import to_flat
+
+
+class TorchComm:
+    """Thin communicator over a ``torch.distributed`` process group
+    (backend "nccl" == RCCL on ROCm; "gloo" for CPU tests)."""
+
+    def __init__(self, group=None):
+        self.group = group
+        self.rank = dist.get_rank(group)
+        self.size = dist.get_world_size(group)
+        self.backend = dist.get_backend(group)
+
+    def alltoallv(self, send, send_counts, recv, recv_counts, async_op=False):
+        """Neighbour all-to-all-v: ``send`` / ``recv`` are flat tensors whose
+        consecutive segments (``*_counts[r]`` elements, zero for non-neighbours)
+        go to / come from rank r."""
+        return dist.all_to_all_single(
+            recv, send, output_split_sizes=recv_counts, input_split_sizes=send_counts, group=self.group, async_op=async_op
+        )
+
+    def alltoallv_int64(self, send_np, send_counts, recv_counts):
+        """Set-up path (index exchange of compute_scatterer_data)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        send = torch.from_numpy(np.ascontiguousarray(send_np, dtype=np.int64)).to(dev)
+        recv = torch.empty(int(np.sum(recv_counts)), dtype=torch.int64, device=dev)
+        self.alltoallv(send, [int(c) for c in send_counts], recv, [int(c) for c in recv_counts])
+        return recv.cpu().numpy()
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+
+class HipHaloKernels:
+    """pack/unpack through the C ABI (csrc/halo.hpp)."""
+
+    def __init__(self, dtype: torch.dtype):
+        lib = _lib.load()
+        suf = _lib.suffix(dtype)
+        self.dtype = dtype
+        self._pack_fwd = getattr(lib, f"fus_pack_fwd_{suf}")
+        self._unpack_fwd = getattr(lib, f"fus_unpack_fwd_{suf}")
+        self._pack_rev = getattr(lib, f"fus_pack_rev_{suf}")
+        self._unpack_rev = getattr(lib, f"fus_unpack_rev_{suf}")
+
+    def index_tensor(self, idx_np):
+        dev = torch.device("cuda", torch.cuda.current_device())
+        return torch.from_numpy(np.ascontiguousarray(idx_np, dtype=np.int64)).to(dev)
+
+    def buffer(self, n):
+        return torch.empty(int(n), dtype=self.dtype, device=torch.device("cuda", torch.cuda.current_device()))
+
+    def _chk(self, t, name):
+        _lib.require_device_tensor(t, self.dtype, name)
+
+    def pack_fwd(self, in_, out, index):
+        self._chk(in_, "buffer")
+        _lib.check(self._pack_fwd(in_.data_ptr(), out.data_ptr(), index.data_ptr(), index.numel(), _lib.stream_ptr()), "fus_pack_fwd")
+
+    def unpack_fwd(self, in_, out, index, N):
+        self._chk(out, "buffer")
+        _lib.check(self._unpack_fwd(in_.data_ptr(), out.data_ptr(), index.data_ptr(), index.numel(), int(N), _lib.stream_ptr()), "fus_unpack_fwd")
+
+    def pack_rev(self, in_, out, index, N):
+        self._chk(in_, "buffer")
+        _lib.check(self._pack_rev(in_.data_ptr(), out.data_ptr(), index.data_ptr(), index.numel(), int(N), _lib.stream_ptr()), "fus_pack_rev")
+
+    def unpack_rev(self, in_, out, index):
+        self._chk(out, "buffer")
+        _lib.check(self._unpack_rev(in_.data_ptr(), out.data_ptr(), index.data_ptr(), index.numel(), _lib.stream_ptr()), "fus_unpack_rev")
+
+
+class _Scatter:
+    """Callable returned by scatter_forward / scatter_reverse."""
+
+    def __init__(self, comm, owners_data, ghosts_data, N, float_type, reverse: bool, kernels=None):
+        self.comm = comm
+        self.N = int(N)
+        self.reverse = reverse
+        tdt = _lib.torch_dtype(float_type)
+        self.k = kernels if kernels is not None else HipHaloKernels(tdt)
+        o_idx, o_size, _, o_ranks = to_flat(owners_data)
+        g_idx, g_size, _, g_ranks = to_flat(ghosts_data)
+        size = comm.size
+        o_counts = [0] * size
+        g_counts = [0] * size
+        for r, c in zip(o_ranks, o_size):
+            o_counts[int(r)] = int(c)
+        for r, c in zip(g_ranks, g_size):
+            g_counts[int(r)] = int(c)
+        # the flat index lists are grouped by ascending neighbour rank, which is the segment
+        # order all_to_all_single uses
+        assert list(o_ranks) == sorted(o_ranks) and list(g_ranks) == sorted(g_ranks)
+        self.o_idx = self.k.index_tensor(o_idx)
+        self.g_idx = self.k.index_tensor(g_idx)
+        if reverse:  # ghosts -> owners
+            self.send_counts, self.recv_counts = o_counts, g_counts
+        else:  # owners -> ghosts
+            self.send_counts, self.recv_counts = g_counts, o_counts
+        # send/recv buffers are owned by the closure and allocated once (cuda/scatterer.py:133-138)
+        self.send = self.k.buffer(sum(self.send_counts))
+        self.recv = self.k.buffer(sum(self.recv_counts))
+        self.active = (sum(self.send_counts) + sum(self.recv_counts)) > 0 or comm.size > 1
+
+    def begin(self, buffer):
+        """Pack and post the exchange; returns a handle for ``end``."""
+        if self.reverse:
+            self.k.pack_rev(buffer, self.send, self.o_idx, self.N)
+        else:
+            self.k.pack_fwd(buffer, self.send, self.g_idx)
+        if self.comm.size == 1:
+            return None
+        return self.comm.alltoallv(self.send, self.send_counts, self.recv, self.recv_counts, async_op=True)
+
+    def end(self, buffer, work):
+        """Complete the exchange (stream-ordered for RCCL) and unpack."""
+        if work is not None:
+            work.wait()
+        if self.reverse:
+            self.k.unpack_rev(self.recv, buffer, self.g_idx)
+        else:
+            self.k.unpack_fwd(self.recv, buffer, self.o_idx, self.N)
+
+    def __call__(self, buffer):
+        self.end(buffer, self.begin(buffer))
+
+
+def scatter_reverse(comm, owners_data, ghosts_data, N, float_type, kernels=None):
+    return _Scatter(comm, owners_data, ghosts_data, N, float_type, True, kernels)
+
+
+def scatter_forward(comm, owners_data, ghosts_data, N, float_type, kernels=None):
+    return _Scatter(comm, owners_data, ghosts_data, N, float_type, False, kernels)
+
+
+class HaloApply:
+    """Distributed operator apply  y += K x  on a partitioned mesh, with the
+    halo exchange overlapped with interior-cell work (one process per GPU):
+
+        fwd.begin(x) | apply(interior half 1) | fwd.end(x)
+        apply(boundary cells)                               # the only cells touching ghost dofs
+        rev.begin(y) | apply(interior half 2) | rev.end(y)
+
+    This is the reference's per-stage sequence scatter_fwd -> stiffness ->
+    scatter_rev (cuda/demo_linear_box.py:537-553) with its host syncs removed
+    and the cells split so that both exchanges hide behind interior work.
+    ``mesh.dofmap`` must list the ghost-touching cells first
+    (``mesh.num_boundary_cells``), as ``BoxMesh`` does.
+    """
+
+    def __init__(self, mesh, op, comm, float_type, overlap=True, kernels=None, apply_fn=None):
+        from .utils import compute_scatterer_data_flat
+
+        self.mesh = mesh
+        self.op = op
+        self.comm = comm
+        od, gd = compute_scatterer_data_flat(mesh.index_map, comm)
+        self.owners_data, self.ghosts_data = od, gd
+        self.fwd = scatter_forward(comm, od, gd, mesh.nlocal, float_type, kernels)
+        self.rev = scatter_reverse(comm, od, gd, mesh.nlocal, float_type, kernels)
+        self.overlap = overlap
+        nb, nc = mesh.num_boundary_cells, mesh.ncells
+        mid = nb + (nc - nb) // 2
+        self.ranges = {"boundary": (0, nb), "interior1": (nb, mid), "interior2": (mid, nc)}
+        self._views = {}
+        self._apply_fn = apply_fn  # tests: CPU stand-in for the operator
+
+    def _sub(self, name, cc, G, dofmap):
+        key = (name, cc.data_ptr(), G.data_ptr(), dofmap.data_ptr())
+        v = self._views.get(key)
+        if v is None:
+            a, b = self.ranges[name]
+            v = (cc[a:b], G[a:b], dofmap[a:b])  # views are kept so the operator's plan cache hits
+            self._views[key] = v
+        return v
+
+    def _apply(self, name, x, cc, y, G, dofmap):
+        a, b = self.ranges[name]
+        if b <= a:
+            return
+        c_, G_, d_ = self._sub(name, cc, G, dofmap)
+        if self._apply_fn is not None:
+            self._apply_fn(x, c_, y, G_, d_)
+        else:
+            self.op(x, c_, y, G_, d_)
+
+    def apply(self, x, cell_constants, y, G, dofmap):
+        if not self.overlap:
+            self.fwd(x)
+            for name in ("boundary", "interior1", "interior2"):
+                self._apply(name, x, cell_constants, y, G, dofmap)
+            self.rev(y)
+            return
+        w = self.fwd.begin(x)
+        self._apply("interior1", x, cell_constants, y, G, dofmap)
+        self.fwd.end(x, w)
+        self._apply("boundary", x, cell_constants, y, G, dofmap)
+        w = self.rev.begin(y)
+        self._apply("interior2", x, cell_constants, y, G, dofmap)
+        self.rev.end(y, w)
+
+    def apply_local_only(self, x, cell_constants, y, G, dofmap):
+        """The three kernel launches without any exchange (bench: kernel time at N > 1)."""
+        for name in ("interior1", "boundary", "interior2"):
+            self._apply(name, x, cell_constants, y, G, dofmap)

@@ -53,7 +53,7 @@ def oracle_c():
     return OracleLib()
 
 
-def test_function(xyz):
+def ref_field(xyz):
     """The reference's test field, numba-cpu/test_operators.py:274-279."""
     return 100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])
 
@@ -70,7 +70,7 @@ def build_problem(P, ncells, dtype=np.float64, perturb=0.0, seed=0, grid=(1, 1, 
     detJ = np.zeros((mesh.ncells, n**3), dtype=dtype)
     pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), mesh.ncells, dphi_g, wts3)
     pre.compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), mesh.ncells, dphi_g, wts3)
-    x = test_function(mesh.dof_coordinates()).astype(dtype)
+    x = ref_field(mesh.dof_coordinates()).astype(dtype)
     rng = np.random.default_rng(1234)
     cc = (1.0 + 0.25 * rng.standard_normal(mesh.ncells)).astype(dtype) if random_constants else np.ones(mesh.ncells, dtype)
     return dict(mesh=mesh, pts=pts, wts=wts, D=D, G=G, detJ=detJ, x=x, cc=cc, P=P, n=n)

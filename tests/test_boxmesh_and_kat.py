@@ -1,0 +1,129 @@
+"""Synthetic mesh / partition plumbing and operator known-answer tests through the
+oracle (the invariants a dolfinx assembly would also satisfy)."""
+
+import numpy as np
+import pytest
+
+from conftest import build_problem, pkg, rel_l2
+from oracle import oracle_np
+
+
+@pytest.mark.parametrize("P,cells,grid", [(2, (4, 3, 2), (2, 1, 1)), (3, (4, 4, 3), (2, 2, 1)), (2, (2, 2, 2), (2, 2, 2)),
+                                          (1, (5, 4, 3), (2, 2, 1)), (4, (3, 2, 2), (1, 2, 1))])
+def test_partition_consistency(P, cells, grid):
+    boxmesh, utils = pkg("boxmesh"), pkg("utils")
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r) for r in range(R)]
+    nglob = int(np.prod([P * c + 1 for c in cells]))
+    owned = np.concatenate([m.global_lexicographic_ids()[: m.nlocal] for m in meshes])
+    assert owned.size == nglob and np.array_equal(np.sort(owned), np.arange(nglob))  # every dof owned exactly once
+    assert sum(m.ncells for m in meshes) == int(np.prod(cells))
+    lex_of_global = {}
+    for m in meshes:
+        im = m.index_map
+        assert im.size_global == nglob and im.local_range[1] - im.local_range[0] == m.nlocal
+        lex = m.global_lexicographic_ids()
+        for li in range(m.nlocal):
+            lex_of_global[im.local_range[0] + li] = lex[li]
+    for m in meshes:
+        im, lex = m.index_map, m.global_lexicographic_ids()
+        # ghost global index and owner agree with the owner's numbering
+        for g in range(m.nghost):
+            assert lex_of_global[int(im.ghosts[g])] == lex[m.nlocal + g]
+            o = int(im.owners[g])
+            assert meshes[o].index_map.local_range[0] <= im.ghosts[g] < meshes[o].index_map.local_range[1]
+            assert o < m.rank  # lowest rank touching a dof owns it
+        # boundary cells first, and exactly they touch ghosts
+        touches = (m.dofmap >= m.nlocal).any(axis=1)
+        assert np.all(touches[: m.num_boundary_cells]) and not np.any(touches[m.num_boundary_cells:])
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    for r, m in enumerate(meshes):
+        assert int(np.sum(od[r][1])) == m.nghost
+        # dest ranks adjacency matches the ghosting ranks found by the exchange
+        assert sorted(np.unique(m.index_map.index_to_dest_ranks().array).tolist()) == sorted(gd[r][3].tolist())
+
+
+def test_partitioned_apply_equals_serial_in_process(oracle_c):
+    """P-rank partitioned apply + reverse scatter == 1-rank apply (simulated ranks)."""
+    boxmesh, utils = pkg("boxmesh"), pkg("utils")
+    from halo_cpu import global_cell_constants
+
+    P, cells, grid = 2, (4, 4, 2), (2, 2, 1)
+    ser = build_problem(P, cells, perturb=0.16, seed=3)
+    y_ser = np.zeros(ser["mesh"].ndofs)
+    oracle_c.stiffness_apply(P, ser["D"], ser["x"], global_cell_constants(ser["mesh"]), y_ser, ser["G"], ser["mesh"].dofmap)
+    R = int(np.prod(grid))
+    parts = [build_problem(P, cells, perturb=0.16, seed=3, grid=grid, rank=r) for r in range(R)]
+    meshes = [p["mesh"] for p in parts]
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    nl = [m.nlocal for m in meshes]
+    xs = []
+    for p in parts:
+        x = p["x"].copy()
+        x[p["mesh"].nlocal:] = np.nan  # stale ghosts
+        xs.append(x)
+    oracle_np.scatter_forward_all(xs, od, gd, nl)
+    ys = []
+    for p, x in zip(parts, xs):
+        y = np.zeros(p["mesh"].ndofs)
+        oracle_c.stiffness_apply(P, p["D"], x, global_cell_constants(p["mesh"]), y, p["G"], p["mesh"].dofmap)
+        ys.append(y)
+    oracle_np.scatter_reverse_all(ys, od, gd, nl)
+    for m, y in zip(meshes, ys):
+        lex = m.global_lexicographic_ids()[: m.nlocal]
+        assert rel_l2(y[: m.nlocal], y_ser[lex]) < 1e-14
+
+
+@pytest.mark.parametrize("P", [2, 4, 5])
+def test_operator_known_answers(oracle_c, P):
+    """mass(1) sums to the volume; K const = 0; 1^T K u = 0; u^T K u = |a|^2 vol for u = a.x;
+    symmetry; positive semi-definiteness."""
+    pb = build_problem(P, (3, 2, 2), perturb=0.0, random_constants=False)
+    mesh = pb["mesh"]
+    n = P + 1
+    ones = np.ones(mesh.ndofs)
+    m = np.zeros(mesh.ndofs)
+    oracle_c.mass_apply(ones, pb["cc"], m, pb["detJ"], mesh.dofmap)
+    assert abs(m.sum() - 1.0) < 1e-13
+
+    def K(u):
+        y = np.zeros(mesh.ndofs)
+        oracle_c.stiffness_apply(P, pb["D"], u, pb["cc"], y, pb["G"], mesh.dofmap)
+        return y
+
+    assert np.max(np.abs(K(3.0 * ones))) < 1e-11
+    u = pb["x"]
+    Ku = K(u)
+    assert abs(Ku.sum()) < 1e-9 * np.abs(Ku).sum()
+    a = np.array([1.5, -2.0, 0.5])
+    lin = mesh.dof_coordinates() @ a
+    assert abs(lin @ K(lin) - a @ a * 1.0) < 1e-11
+    v = np.random.default_rng(0).standard_normal(mesh.ndofs)
+    assert abs(v @ Ku - u @ K(v)) < 1e-10 * abs(v @ Ku)
+    assert v @ K(v) > 0
+
+
+def test_energy_convergence(oracle_c):
+    """u^T K u -> int |grad u|^2 = 100^2 (4+9+16) pi^2 / 8 for the reference's test field."""
+    exact = 100.0**2 * 29 * np.pi**2 / 8
+    errs = []
+    for N in (2, 4):
+        pb = build_problem(4, N, random_constants=False)
+        y = np.zeros(pb["mesh"].ndofs)
+        oracle_c.stiffness_apply(4, pb["D"], pb["x"], pb["cc"], y, pb["G"], pb["mesh"].dofmap, threads=2)
+        errs.append(abs(pb["x"] @ y - exact) / exact)
+    assert errs[1] < 1e-3 and errs[1] < errs[0] / 20
+
+
+def test_facet_tables():
+    boxmesh = pkg("boxmesh")
+    m = boxmesh.BoxMesh(2, (2, 2, 2))
+    lfd = m.local_facet_dofs()
+    assert lfd.shape == (6, 9)
+    assert sorted(lfd[0].tolist()) == [l for l in range(27) if l % 3 == 0]  # z = 0 face: k = 0
+    assert sorted(lfd[3].tolist()) == list(range(18, 27))  # x = 1 face: i = 2
+    bd = m.boundary_facets()
+    assert bd.shape == (24, 2)
+    fd = m.facet_dofmap(m.boundary_facets([2]))
+    # x = 0 face dofs have lexicographic x-index 0 -> global ids below (2P+1)^2
+    assert fd.max() < 25
