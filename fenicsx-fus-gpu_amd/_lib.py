@@ -29,11 +29,15 @@ def _signatures():
         "fus_set_tuning": [_int, _int],
         "fus_get_tuning": [_int],
         "fus_stiffness_plan_bytes": [_int, _i64],
+        "fus_plan_entities_per_batch": [_int],
+        "fus_plan_bytes": [_int, _int, _i64],
+        "fus_plan_build": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_stiffness_plan_build": [_vp, _int, _i64, _vp, _i64, _vp],
     }
     for suf, ct in _SUFFIXES:
         sig[f"fus_stiffness_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_stiffness_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
+        sig[f"fus_mass_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _int, _i64, _vp]
         sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]
         sig[f"fus_copy_{suf}"] = [_vp, _vp, _i64, _vp]
@@ -52,6 +56,7 @@ SIGNATURES = _signatures()
 TUNE_STIFFNESS_VARIANT = 1
 TUNE_XCD_REMAP = 2
 TUNE_MASS_VARIANT = 3
+TUNE_PLAN_VARIANT = 4
 
 _lib = None
 
@@ -75,7 +80,7 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = _i64 if name == "fus_stiffness_plan_bytes" else _int
+        fn.restype = _i64 if name in ("fus_stiffness_plan_bytes", "fus_plan_bytes") else _int
     lib.fus_error_string.argtypes = [_int]
     lib.fus_error_string.restype = C.c_char_p
     _lib = lib

@@ -19,6 +19,7 @@ namespace {
 std::atomic<int> g_stiffness_variant{0};
 std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab_variants.log)
 std::atomic<int> g_mass_variant{0};
+std::atomic<int> g_plan_variant{0};
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
 
@@ -91,10 +92,16 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
+  const int pv = g_plan_variant.load(std::memory_order_relaxed);
   switch (P) {
-#define FUS_CASE(PP) \
-  case PP:           \
-    e = fus::launch_stiffness_plan<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s); \
+#define FUS_CASE(PP)                                                                                      \
+  case PP:                                                                                                \
+    switch (pv) {                                                                                         \
+      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
+      case 2: e = fus::launch_stiffness_plan<T, PP, false, false, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
+      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+    }                                                                                                     \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -126,6 +133,15 @@ int halo(const T* in, T* out, const int64_t* index, int64_t count, int64_t offse
   if (count == 0) return FUS_OK;
   if (!in || !out || !index) return FUS_ERR_INVALID_ARGUMENT;
   return hip_rc(fus::launch_halo<T, MODE>(in, out, index, count, offset, static_cast<hipStream_t>(stream)));
+}
+
+template <typename T>
+int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const void* ws, int N, int epb,
+                              int64_t nent, void* stream) {
+  if (nent < 0 || N < 2 || epb < 1 || (int64_t)N * epb > fus::kPlanMaxEntries) return FUS_ERR_INVALID_ARGUMENT;
+  if (nent == 0) return FUS_OK;
+  if (!x || !consts || !y || !detJ || !ws || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream)));
 }
 
 }  // namespace
@@ -166,6 +182,7 @@ int fus_set_tuning(int key, int value) {
     case FUS_TUNE_STIFFNESS_VARIANT: g_stiffness_variant = value; return FUS_OK;
     case FUS_TUNE_XCD_REMAP: g_xcd_remap = value ? 1 : 0; return FUS_OK;
     case FUS_TUNE_MASS_VARIANT: g_mass_variant = value; return FUS_OK;
+    case FUS_TUNE_PLAN_VARIANT: g_plan_variant = value; return FUS_OK;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -175,6 +192,7 @@ int fus_get_tuning(int key) {
     case FUS_TUNE_STIFFNESS_VARIANT: return g_stiffness_variant;
     case FUS_TUNE_XCD_REMAP: return g_xcd_remap;
     case FUS_TUNE_MASS_VARIANT: return g_mass_variant;
+    case FUS_TUNE_PLAN_VARIANT: return g_plan_variant;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -221,6 +239,41 @@ int fus_stiffness_apply_planned_f64(const double* x, const double* cc, double* y
 int fus_stiffness_apply_planned_f32(const float* x, const float* cc, float* y, const float* G, const void* ws,
                                     const float* dphi, int P, int64_t ncell, void* stream) {
   return stiffness_apply_planned<float>(x, cc, y, G, ws, dphi, P, ncell, stream);
+}
+
+int fus_plan_entities_per_batch(int N) {
+  if (N < 1 || N > fus::kPlanMaxEntries) return FUS_ERR_UNSUPPORTED_ENTITY;
+  // cells (N = n^3): the stiffness kernel's batch size, so one plan serves both operators
+  for (int P = FUS_MIN_DEGREE; P <= FUS_MAX_DEGREE; ++P)
+    if ((P + 1) * (P + 1) * (P + 1) == N) return 256 / ((P + 1) * (P + 1)) > 0 ? 256 / ((P + 1) * (P + 1)) : 1;
+  const int epb = 1280 / N;  // ~5 entries per thread of a 256-thread workgroup
+  return epb > 0 ? epb : 1;
+}
+
+int64_t fus_plan_bytes(int N, int entities_per_batch, int64_t nent) {
+  if (N < 1 || entities_per_batch < 1 || nent < 0 || (int64_t)N * entities_per_batch > fus::kPlanMaxEntries)
+    return FUS_ERR_INVALID_ARGUMENT;
+  return fus::plan_view_generic(nullptr, N, entities_per_batch, nent).bytes;
+}
+
+int fus_plan_build(const int32_t* dofmap, int N, int entities_per_batch, int64_t nent, void* workspace,
+                   int64_t workspace_bytes, void* stream) {
+  const int64_t need = fus_plan_bytes(N, entities_per_batch, nent);
+  if (need < 0) return (int)need;
+  if (!workspace || misaligned(workspace, 256) || workspace_bytes < need) return FUS_ERR_INVALID_ARGUMENT;
+  if (nent == 0) return FUS_OK;
+  if (!dofmap) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::launch_plan_build_generic(dofmap, N, entities_per_batch, nent, workspace,
+                                               static_cast<hipStream_t>(stream)));
+}
+
+int fus_mass_apply_planned_f64(const double* x, const double* c, double* y, const double* detJ, const void* ws, int N,
+                               int epb, int64_t nent, void* stream) {
+  return mass_apply_planned<double>(x, c, y, detJ, ws, N, epb, nent, stream);
+}
+int fus_mass_apply_planned_f32(const float* x, const float* c, float* y, const float* detJ, const void* ws, int N,
+                               int epb, int64_t nent, void* stream) {
+  return mass_apply_planned<float>(x, c, y, detJ, ws, N, epb, nent, stream);
 }
 
 int fus_mass_apply_f64(const double* x, const double* c, double* y, const double* detJ, const int32_t* dofmap, int N,

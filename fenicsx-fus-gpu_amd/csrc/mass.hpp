@@ -8,6 +8,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include "plan.hpp"
+
 namespace fus {
 
 template <typename T, typename I>
@@ -38,6 +40,97 @@ inline hipError_t launch_mass(const T* x, const T* consts, T* y, const T* detJ, 
     hipLaunchKernelGGL((mass_kernel<T, int64_t>), dim3((unsigned)nblocks), dim3(256), 0, stream, x, consts, y, detJ,
                        dofmap, (int64_t)N, total);
   }
+  return hipGetLastError();
+}
+
+// Planned mass apply (batch plan of csrc/plan.hpp built for the same entity dofmap, N dofs per
+// entity, epb entities per batch).  Per batch: gather x once per distinct dof into LDS, every
+// (entity, local dof) entry multiplies and pre-reduces into LDS, one global atomic per distinct
+// dof with consecutive lanes on ascending addresses.  EPT = entries per thread (upper bound).
+template <typename T, int EPT>
+__global__ void __launch_bounds__(256)
+    mass_plan_kernel(const T* __restrict__ x, const T* __restrict__ entity_constants, T* __restrict__ y,
+                     const T* __restrict__ detJ, const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
+                     const uint16_t* __restrict__ slot, int N, int epb, int64_t nent, uint32_t inv_n) {
+  extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  const int M = N * epb;
+  T* sx = reinterpret_cast<T*>(smem_raw);
+  T* sy = sx + M;
+
+  const int tid = threadIdx.x;
+  const int64_t batch = blockIdx.x;
+  const int64_t ent0 = batch * epb;
+  const int64_t left = nent - ent0;
+  const int valid = (int)((left < epb ? left : epb) * N);
+  const int nu_b = nu[batch];
+  const int64_t base = batch * (int64_t)M;
+  const int32_t* ud = udofs + base;
+
+  int32_t mydof[EPT];
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int s = tid + r * 256;
+    mydof[r] = ud[s < nu_b ? s : 0];
+  }
+  uint16_t sl[EPT];
+  T w[EPT];
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int i = tid + r * 256;
+    const int ic = i < valid ? i : 0;
+    sl[r] = slot[base + ic];
+    const uint32_t e = __umulhi((uint32_t)ic, inv_n);  // ic / N
+    w[r] = detJ[base + ic] * entity_constants[ent0 + e];
+  }
+  T xv[EPT];
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) xv[r] = x[mydof[r]];
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int s = tid + r * 256;
+    if (s < nu_b) {
+      sx[s] = xv[r];
+      sy[s] = T(0);
+    }
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int i = tid + r * 256;
+    if (i < valid) lds_atomic_add(&sy[sl[r]], sx[sl[r]] * w[r]);
+  }
+  __syncthreads();
+#pragma unroll
+  for (int r = 0; r < EPT; ++r) {
+    const int s = tid + r * 256;
+    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sy[s]);
+  }
+}
+
+template <typename T>
+inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* detJ, const void* workspace, int N,
+                                   int epb, int64_t nent, hipStream_t stream) {
+  if (nent <= 0) return hipSuccess;
+  const int M = N * epb;
+  if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
+  PlanView v = plan_view_generic(const_cast<void*>(workspace), N, epb, nent);
+  const uint32_t inv_n = (uint32_t)((0x100000000ull + (uint64_t)N - 1) / (uint64_t)N);  // ceil(2^32 / N), N >= 2
+  const size_t lds = 2 * (size_t)M * sizeof(T);
+  const dim3 grid((unsigned)v.nbatch), block(256);
+#define FUS_MASS_LAUNCH(E)                                                                                        \
+  hipLaunchKernelGGL((mass_plan_kernel<T, E>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \
+                     N, epb, nent, inv_n)
+  const int ept = (M + 255) / 256;
+  if (ept <= 1) FUS_MASS_LAUNCH(1);
+  else if (ept <= 2) FUS_MASS_LAUNCH(2);
+  else if (ept <= 3) FUS_MASS_LAUNCH(3);
+  else if (ept <= 4) FUS_MASS_LAUNCH(4);
+  else if (ept <= 5) FUS_MASS_LAUNCH(5);
+  else if (ept <= 6) FUS_MASS_LAUNCH(6);
+  else if (ept <= 8) FUS_MASS_LAUNCH(8);
+  else if (ept <= 11) FUS_MASS_LAUNCH(11);
+  else FUS_MASS_LAUNCH(16);
+#undef FUS_MASS_LAUNCH
   return hipGetLastError();
 }
 

@@ -50,11 +50,11 @@ struct PlanView {
   int64_t bytes;
 };
 
-inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
-  const int n = P + 1;
+// Generic plan geometry: ``nent`` entities of ``N`` dofs each, ``epb`` entities per batch.
+inline PlanView plan_view_generic(void* workspace, int N, int epb, int64_t nent) {
   PlanView v;
-  v.entries = (int64_t)cpb * n * n * n;
-  v.nbatch = (ncell + cpb - 1) / cpb;
+  v.entries = (int64_t)epb * N;
+  v.nbatch = (nent + epb - 1) / epb;
   char* base = static_cast<char*>(workspace);
   int64_t off = kPlanHeaderBytes;
   v.nu = reinterpret_cast<int32_t*>(base + off);
@@ -67,26 +67,28 @@ inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
   return v;
 }
 
+inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
+  const int n = P + 1;
+  return plan_view_generic(workspace, n * n * n, cpb, ncell);
+}
+
 // One workgroup per batch: LDS bitonic sort of (dof << 16 | position) keys, unique flags,
-// block scan, write slots + distinct dofs.
-template <int P, int CPB>
+// block scan, write slots + distinct dofs.  M = epb * N entries per batch, M <= M2 (power of 2).
+template <int M2>
 __global__ void __launch_bounds__(256)
-    plan_build_kernel(const int32_t* __restrict__ dofmap, int64_t ncell, int32_t* __restrict__ nu,
+    plan_build_kernel(const int32_t* __restrict__ dofmap, int64_t nent, int N, int epb, int32_t* __restrict__ nu,
                       int32_t* __restrict__ udofs, uint16_t* __restrict__ slot) {
-  constexpr int n = P + 1, Nd = n * n * n;
-  constexpr int M = CPB * Nd;
-  constexpr int M2 = next_pow2(M) < 256 ? 256 : next_pow2(M);
   constexpr int CH = M2 / 256;  // elements per thread in the scan phase
-  static_assert(M < 65536, "slot ids are 16-bit");
   __shared__ uint64_t keys[M2];
   __shared__ int cnt[256];
 
   const int tid = threadIdx.x;
+  const int M = epb * N;
   const int64_t batch = blockIdx.x;
-  const int64_t cell0 = batch * CPB;
-  const int64_t left = ncell - cell0;
-  const int valid = (int)((left < CPB ? left : CPB) * Nd);
-  const int32_t* dm = dofmap + cell0 * Nd;
+  const int64_t ent0 = batch * epb;
+  const int64_t left = nent - ent0;
+  const int valid = (int)((left < epb ? left : epb) * N);
+  const int32_t* dm = dofmap + ent0 * N;
 
   for (int i = tid; i < M2; i += 256)
     keys[i] = (i < valid) ? (((uint64_t)(uint32_t)dm[i] << 16) | (uint64_t)i) : ~0ull;
@@ -149,18 +151,36 @@ __global__ void __launch_bounds__(256)
   }
 }
 
-template <int P>
-inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* workspace, hipStream_t stream) {
-  constexpr int CPB = plan_cells_per_batch<P>();
-  if (ncell <= 0) return hipSuccess;
-  PlanView v = plan_view(workspace, P, CPB, ncell);
+constexpr int kPlanMaxEntries = 4096;  // per batch; slot ids are 16-bit, keys live in LDS
+
+inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int epb, int64_t nent, void* workspace,
+                                            hipStream_t stream) {
+  if (nent <= 0) return hipSuccess;
+  const int M = epb * N;
+  if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
+  PlanView v = plan_view_generic(workspace, N, epb, nent);
   if (v.nbatch > 0x7fffffffLL) return hipErrorInvalidValue;
-  int64_t hdr[6] = {kPlanMagic, P, CPB, ncell, v.nbatch, v.entries};
+  int64_t hdr[6] = {kPlanMagic, N, epb, nent, v.nbatch, v.entries};
   hipError_t e = hipMemcpyAsync(workspace, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) return e;
-  hipLaunchKernelGGL((plan_build_kernel<P, CPB>), dim3((unsigned)v.nbatch), dim3(256), 0, stream, dofmap, ncell, v.nu,
-                     v.udofs, v.slot);
+  const dim3 grid((unsigned)v.nbatch), block(256);
+  if (M <= 256)
+    hipLaunchKernelGGL((plan_build_kernel<256>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot);
+  else if (M <= 512)
+    hipLaunchKernelGGL((plan_build_kernel<512>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot);
+  else if (M <= 1024)
+    hipLaunchKernelGGL((plan_build_kernel<1024>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot);
+  else if (M <= 2048)
+    hipLaunchKernelGGL((plan_build_kernel<2048>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot);
+  else
+    hipLaunchKernelGGL((plan_build_kernel<4096>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot);
   return hipGetLastError();
+}
+
+template <int P>
+inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* workspace, hipStream_t stream) {
+  constexpr int n = P + 1;
+  return launch_plan_build_generic(dofmap, n * n * n, plan_cells_per_batch<P>(), ncell, workspace, stream);
 }
 
 template <typename T>
@@ -170,14 +190,14 @@ __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
 
 // Planned stiffness apply: same contraction structure as stiffness_col_kernel (stiffness.hpp),
 // gather / scatter through the batch plan.
-template <typename T, int P, int CPB>
-__global__ void __launch_bounds__((col_block_threads<P, CPB>()))
+template <typename T, int P, int CPB, bool NT, bool PADLDS, int MINW>
+__global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
                           const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
                           const T* __restrict__ dphi, int64_t ncell, int xcd_remap) {
   constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
-  constexpr int S = lds_cell_stride<T, P>();
+  constexpr int S = PADLDS ? lds_cell_stride<T, P>() : Nd;
   constexpr int BLOCK = col_block_threads<P, CPB>();
   constexpr int M = CPB * Nd;
   constexpr int SPT = (M + BLOCK - 1) / BLOCK;  // distinct-dof slots per thread (upper bound)
@@ -217,7 +237,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
     const T* Gc = G + (cell * Nd + t) * 6;
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
+    for (int ix = 0; ix < n; ++ix) load_g6<T, NT>(Gc + (int64_t)ix * n2 * 6, g[ix]);
     coeff = cell_constants[cell];
   }
   T xv[SPT];
@@ -311,15 +331,15 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
   }
 }
 
-template <typename T, int P>
+template <typename T, int P, bool NT, bool PADLDS, int MINW>
 inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
                                         const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
-  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB>), dim3((unsigned)v.nbatch), dim3(threads), 0, stream, x, cc, y,
-                     G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap);
+  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, NT, PADLDS, MINW>), dim3((unsigned)v.nbatch), dim3(threads), 0,
+                     stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap);
   return hipGetLastError();
 }
 

@@ -28,24 +28,36 @@
 
 namespace fus {
 
+typedef double fus_double2 __attribute__((ext_vector_type(2)));
+typedef float fus_float2 __attribute__((ext_vector_type(2)));
 template <typename T>
 struct vec2_of;
 template <>
 struct vec2_of<double> {
-  using type = double2;
+  using type = fus_double2;
 };
 template <>
 struct vec2_of<float> {
-  using type = float2;
+  using type = fus_float2;
 };
 
 // 6 consecutive T (one quadrature point's symmetric G) as three 2-wide vector loads.
 // Requires G to be aligned to 2*sizeof(T) (checked on the host).
-template <typename T>
+// NT: non-temporal (streaming) loads -- G is read exactly once per apply.
+template <typename T, bool NT = false>
 __device__ __forceinline__ void load_g6(const T* __restrict__ p, T (&g)[6]) {
   using V = typename vec2_of<T>::type;
   const V* v = reinterpret_cast<const V*>(p);
-  const V a = v[0], b = v[1], c = v[2];
+  V a, b, c;
+  if constexpr (NT) {
+    a = __builtin_nontemporal_load(v);
+    b = __builtin_nontemporal_load(v + 1);
+    c = __builtin_nontemporal_load(v + 2);
+  } else {
+    a = v[0];
+    b = v[1];
+    c = v[2];
+  }
   g[0] = a.x;
   g[1] = a.y;
   g[2] = b.x;

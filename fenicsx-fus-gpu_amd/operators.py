@@ -45,30 +45,44 @@ def use_plan(flag: bool):
 
 
 class _PlanCache:
-    """Plan workspaces keyed on the identity of the dofmap array (pointer, shape, version)."""
+    """Batch-plan workspaces keyed on the identity of the dofmap array (pointer, shape, version).
+    One cache for the whole module: the cell mass operator and the stiffness operator share a
+    plan when they are given the same dofmap."""
 
-    def __init__(self, P: int):
-        self.P = P
+    def __init__(self, capacity: int = 16):
         self._plans = {}
+        self.capacity = capacity
 
-    def get(self, dofmap: torch.Tensor) -> torch.Tensor:
-        key = (dofmap.data_ptr(), tuple(dofmap.shape), dofmap._version, dofmap.device.index)
-        ws = self._plans.get(key)
-        if ws is None:
-            lib = _lib.load()
-            ncell = dofmap.shape[0]
-            nbytes = lib.fus_stiffness_plan_bytes(self.P, ncell)
+    def get(self, dofmap: torch.Tensor):
+        """-> (workspace tensor, entities_per_batch)"""
+        lib = _lib.load()
+        nent, N = dofmap.shape
+        key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index)
+        hit = self._plans.get(key)
+        if hit is None:
+            epb = lib.fus_plan_entities_per_batch(N)
+            if epb < 0:
+                _lib.check(epb, "fus_plan_entities_per_batch")
+            nbytes = lib.fus_plan_bytes(N, epb, nent)
             if nbytes < 0:
-                _lib.check(int(nbytes), "fus_stiffness_plan_bytes")
+                _lib.check(int(nbytes), "fus_plan_bytes")
             ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dofmap.device)
             _lib.check(
-                lib.fus_stiffness_plan_build(dofmap.data_ptr(), self.P, ncell, ws.data_ptr(), int(nbytes), _lib.stream_ptr()),
-                "fus_stiffness_plan_build",
+                lib.fus_plan_build(dofmap.data_ptr(), N, epb, nent, ws.data_ptr(), int(nbytes), _lib.stream_ptr()),
+                "fus_plan_build",
             )
-            if len(self._plans) >= 8:  # bounded: drop the oldest plan
+            if len(self._plans) >= self.capacity:  # bounded: drop the oldest plan
                 self._plans.pop(next(iter(self._plans)))
-            self._plans[key] = ws
-        return ws
+            hit = (ws, epb)
+            self._plans[key] = hit
+        return hit
+
+    def clear(self):
+        self._plans.clear()
+
+
+_PLANS = _PlanCache()
+_MASS_PLAN_MIN_ENTRIES = 1 << 15  # below this the plan-free kernel is already launch-bound
 
 
 class _Launchable:
@@ -94,6 +108,17 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None):
         raise ValueError(f"operator was built for N={N} dofs per entity, dofmap has {n_per}")
     if entity_constants.numel() != nent:
         raise ValueError("entity_constants must have one value per entity")
+    if nent == 0:
+        return
+    if _USE_PLAN and n_per >= 2 and nent * n_per >= _MASS_PLAN_MIN_ENTRIES:
+        ws, epb = _PLANS.get(entity_dofmap)
+        fn = getattr(lib, f"fus_mass_apply_planned_{_lib.suffix(dt)}")
+        _lib.check(
+            fn(x.data_ptr(), entity_constants.data_ptr(), y.data_ptr(), entity_detJ.data_ptr(), ws.data_ptr(),
+               int(n_per), int(epb), int(nent), _lib.stream_ptr()),
+            "fus_mass_apply_planned",
+        )
+        return
     fn = getattr(lib, f"fus_mass_apply_{_lib.suffix(dt)}")
     _lib.check(
         fn(x.data_ptr(), entity_constants.data_ptr(), y.data_ptr(), entity_detJ.data_ptr(), entity_dofmap.data_ptr(),
@@ -134,7 +159,6 @@ class _StiffnessOperator(_Launchable):
         self.dtype = _lib.torch_dtype(float_type)
         self._fn = getattr(_lib.load(), f"fus_stiffness_apply_{_lib.suffix(self.dtype)}")
         self._fn_planned = getattr(_lib.load(), f"fus_stiffness_apply_planned_{_lib.suffix(self.dtype)}")
-        self._plans = _PlanCache(self.P)
         self._dphi = None
         self._dphi_src = None
         if dphi is not None:
@@ -169,7 +193,7 @@ class _StiffnessOperator(_Launchable):
         if ncell == 0:
             return
         if _USE_PLAN:
-            ws = self._plans.get(dofmap)
+            ws, _ = _PLANS.get(dofmap)
             _lib.check(
                 self._fn_planned(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(), ws.data_ptr(),
                                  dphi_t.data_ptr(), self.P, int(ncell), _lib.stream_ptr()),

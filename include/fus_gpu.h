@@ -47,6 +47,7 @@ int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_byt
 #define FUS_TUNE_STIFFNESS_VARIANT 1 /* 0 = default; see DESIGN.md for the variants */
 #define FUS_TUNE_XCD_REMAP 2         /* 1 = give each XCD a contiguous range of cell batches */
 #define FUS_TUNE_MASS_VARIANT 3
+#define FUS_TUNE_PLAN_VARIANT 4      /* planned stiffness kernel build: see csrc/fus_gpu.hip */
 int fus_set_tuning(int key, int value);
 int fus_get_tuning(int key);
 
@@ -89,6 +90,23 @@ int fus_mass_apply_f64(const double* x, const double* entity_constants, double* 
                        const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, void* stream);
 int fus_mass_apply_f32(const float* x, const float* entity_constants, float* y, const float* entity_detJ,
                        const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, void* stream);
+
+/*
+ * Generic batch plan (any entity kind: cells N = n^3, boundary facets N = n^2) and planned mass
+ * apply.  fus_plan_entities_per_batch(N) returns the preferred batch size (for cells it equals
+ * the stiffness plan's, so ONE workspace built from the cell dofmap serves both operators:
+ * fus_stiffness_plan_build(dofmap, P, ...) == fus_plan_build(dofmap, n^3, fus_plan_entities_per_batch(n^3), ...)).
+ */
+int fus_plan_entities_per_batch(int ndof_per_entity);
+int64_t fus_plan_bytes(int ndof_per_entity, int entities_per_batch, int64_t nent);
+int fus_plan_build(const int32_t* entity_dofmap, int ndof_per_entity, int entities_per_batch, int64_t nent,
+                   void* workspace, int64_t workspace_bytes, void* stream);
+int fus_mass_apply_planned_f64(const double* x, const double* entity_constants, double* y, const double* entity_detJ,
+                               const void* workspace, int ndof_per_entity, int entities_per_batch, int64_t nent,
+                               void* stream);
+int fus_mass_apply_planned_f32(const float* x, const float* entity_constants, float* y, const float* entity_detJ,
+                               const void* workspace, int ndof_per_entity, int entities_per_batch, int64_t nent,
+                               void* stream);
 
 /*
  * Streaming vector kernels of the RK4 stage.

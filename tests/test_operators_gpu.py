@@ -228,3 +228,41 @@ def test_vector_ops(gpu, oracle_c, dtype):
             _check(out.copy_to_host(), ah / bh, dtype, "divide")
             ops.square[1, 1](ad, out)
             _check(out.copy_to_host(), ah * ah, dtype, "square")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [1, 2, 4, 6, 9])
+def test_mass_planned_vs_oracle(gpu, oracle_c, plan_mode, P, dtype):
+    """Cell mass and boundary-facet mass on sets big enough to take the planned path
+    (and the same sets plan-free), ragged last batch included."""
+    dev, ops = gpu
+    ncells = (13, 7, 5) if P <= 4 else (5, 3, 3)
+    pb = build_problem(P, ncells, dtype=dtype, perturb=0.16, seed=P)
+    mesh = pb["mesh"]
+    old = ops._MASS_PLAN_MIN_ENTRIES
+    ops._MASS_PLAN_MIN_ENTRIES = 1
+    try:
+        rng = np.random.default_rng(P)
+        y0 = rng.standard_normal(mesh.ndofs).astype(dtype)
+        x, cc = dev.to_device(pb["x"]), dev.to_device(pb["cc"])
+        y_ref = y0.copy()
+        oracle_c.mass_apply(pb["x"], pb["cc"], y_ref, pb["detJ"], mesh.dofmap)
+        y = dev.to_device(y0)
+        ops.mass_operator((P + 1) ** 3, dtype)(x, cc, y, dev.to_device(pb["detJ"]), dev.to_device(mesh.dofmap))
+        _check(y.copy_to_host(), y_ref, dtype, f"cell mass P={P}")
+        # boundary facets of the whole box
+        gll, pre = pkg("gll"), pkg("precompute")
+        bd = mesh.boundary_facets()
+        fdm = mesh.facet_dofmap(bd)
+        dF = np.zeros((bd.shape[0], (P + 1) ** 2), dtype=dtype)
+        pre.compute_boundary_facets_scaled_jacobian_determinant(
+            dF, (mesh.x_dofs, mesh.x_g), bd, pre.tabulate_facet_gradients(pb["pts"], dtype),
+            gll.tensor_weights_2d(pb["wts"]).astype(dtype))
+        fc = (1.0 + 0.3 * rng.standard_normal(bd.shape[0])).astype(dtype)
+        y_ref = y0.copy()
+        oracle_c.mass_apply(pb["x"], fc, y_ref, dF, fdm)
+        y = dev.to_device(y0)
+        ops.mass_operator((P + 1) ** 2, dtype)(x, dev.to_device(fc), y, dev.to_device(dF), dev.to_device(fdm))
+        _check(y.copy_to_host(), y_ref, dtype, f"facet mass P={P}")
+    finally:
+        ops._MASS_PLAN_MIN_ENTRIES = old

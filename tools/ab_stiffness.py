@@ -46,9 +46,13 @@ def main():
     times = {c: [] for c in cfgs}
     for rnd in range(a.rounds + 1):
         for c in cfgs:
-            ops.use_plan(c[0] < 0)
-            if c[0] >= 0:
+            ops.use_plan(c[0] < 0 or c[0] >= 100)
+            if c[0] >= 100:  # 100 + k = planned kernel build k
+                lib.set_tuning(lib.TUNE_PLAN_VARIANT, c[0] - 100)
+            elif c[0] >= 0:
                 lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, c[0])
+            else:
+                lib.set_tuning(lib.TUNE_PLAN_VARIANT, 0)
             lib.set_tuning(lib.TUNE_XCD_REMAP, c[1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             op(x, cc, y, G, dm)
