@@ -19,7 +19,7 @@ namespace {
 std::atomic<int> g_stiffness_variant{0};
 std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab_variants.log)
 std::atomic<int> g_mass_variant{0};
-std::atomic<int> g_plan_variant{0};
+std::atomic<int> g_plan_variant{-1};  // -1 = auto: LDS-aliased build for P >= 6 (profiles/r01c_ab_plan_builds.log)
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
 
@@ -92,14 +92,15 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
-  const int pv = g_plan_variant.load(std::memory_order_relaxed);
+  int pv = g_plan_variant.load(std::memory_order_relaxed);
+  if (pv < 0) pv = (P >= 6) ? 1 : 0;
   switch (P) {
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
       case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, false, false, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, 3>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
+      case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
     }                                                                                                     \
     break;

@@ -190,7 +190,7 @@ __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
 
 // Planned stiffness apply: same contraction structure as stiffness_col_kernel (stiffness.hpp),
 // gather / scatter through the batch plan.
-template <typename T, int P, int CPB, bool NT, bool PADLDS, int MINW>
+template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
@@ -202,11 +202,16 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   constexpr int M = CPB * Nd;
   constexpr int SPT = (M + BLOCK - 1) / BLOCK;  // distinct-dof slots per thread (upper bound)
 
+  // LDS: three cubes per cell (u, f_y, f_z) + the batch's distinct-dof values.  Lifetimes:
+  //   x values [load, B2)   u cube [B1, B3)   f_y/f_z [B2, B4)   y partial sums [B3, end)
+  // ALIAS: x values live in the f_y region and the y sums in the u region (one more barrier).
   __shared__ T sD[n2];
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
-  __shared__ T sxy[M];  // x values of the batch's distinct dofs, later their y partial sums
+  __shared__ T sxy_own[ALIAS ? 1 : M];
+  T* const sx = ALIAS ? sfy : sxy_own;  // x values of the batch's distinct dofs
+  T* const sy = ALIAS ? su : sxy_own;   // their y partial sums
 
   const int tid = threadIdx.x;
   const unsigned batch = remap_block(blockIdx.x, gridDim.x, xcd_remap);
@@ -237,7 +242,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
     const T* Gc = G + (cell * Nd + t) * 6;
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) load_g6<T, NT>(Gc + (int64_t)ix * n2 * 6, g[ix]);
+    for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
     coeff = cell_constants[cell];
   }
   T xv[SPT];
@@ -246,7 +251,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
-    if (s < nu_b) sxy[s] = xv[r];
+    if (s < nu_b) sx[s] = xv[r];
   }
   __syncthreads();
 
@@ -255,17 +260,18 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     T* cu = su + lc * S + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) {
-      u[ix] = sxy[sl[ix]];
+      u[ix] = sx[sl[ix]];
       cu[ix * n2] = u[ix];
     }
   }
   __syncthreads();
 
-  // all reads of the x values are done: the buffer becomes the y accumulator
+  if constexpr (!ALIAS) {  // all reads of the x values are done: the buffer becomes the y accumulator
 #pragma unroll
-  for (int r = 0; r < SPT; ++r) {
-    const int s = tid + r * BLOCK;
-    if (s < nu_b) sxy[s] = T(0);
+    for (int r = 0; r < SPT; ++r) {
+      const int s = tid + r * BLOCK;
+      if (s < nu_b) sy[s] = T(0);
+    }
   }
 
   T fx[n];
@@ -298,6 +304,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     }
   }
   __syncthreads();
+  if constexpr (ALIAS) {  // the u cube is dead: zero it as the y accumulator
+#pragma unroll
+    for (int r = 0; r < SPT; ++r) {
+      const int s = tid + r * BLOCK;
+      if (s < nu_b) sy[s] = T(0);
+    }
+    __syncthreads();
+  }
 
   if (active) {
     T dyT[n], dzT[n];
@@ -318,7 +332,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
         acc += dyT[q] * cf_y[jx * n2 + q * n];
         acc += dzT[q] * cf_z[jx * n2 + q];
       }
-      lds_atomic_add(&sxy[sl[jx]], acc);
+      lds_atomic_add(&sy[sl[jx]], acc);
     }
   }
   __syncthreads();
@@ -327,18 +341,18 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
-    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sxy[s]);
+    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sy[s]);
   }
 }
 
-template <typename T, int P, bool NT, bool PADLDS, int MINW>
+template <typename T, int P, bool ALIAS, bool PADLDS, int MINW>
 inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
                                         const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
-  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, NT, PADLDS, MINW>), dim3((unsigned)v.nbatch), dim3(threads), 0,
+  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW>), dim3((unsigned)v.nbatch), dim3(threads), 0,
                      stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap);
   return hipGetLastError();
 }

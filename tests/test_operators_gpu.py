@@ -266,3 +266,25 @@ def test_mass_planned_vs_oracle(gpu, oracle_c, plan_mode, P, dtype):
         _check(y.copy_to_host(), y_ref, dtype, f"facet mass P={P}")
     finally:
         ops._MASS_PLAN_MIN_ENTRIES = old
+
+
+@pytest.mark.parametrize("pv", [0, 1, 2, 3])
+@pytest.mark.parametrize("P", [2, 4, 6])
+def test_planned_kernel_builds(gpu, oracle_c, P, pv):
+    """Every build of the planned stiffness kernel (LDS aliasing / padding / occupancy hints)."""
+    dev, ops = gpu
+    lib = pkg("_lib")
+    pb = build_problem(P, (5, 3, 4) if P < 6 else (3, 2, 3), perturb=0.16, seed=11)
+    mesh = pb["mesh"]
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    old = lib.get_tuning(lib.TUNE_PLAN_VARIANT)
+    try:
+        lib.set_tuning(lib.TUNE_PLAN_VARIANT, pv)
+        ops.use_plan(True)
+        y = dev.to_device(np.zeros(mesh.ndofs))
+        ops.stiffness_operator(P, pb["D"].flatten(), np.float64)(
+            dev.to_device(pb["x"]), dev.to_device(pb["cc"]), y, dev.to_device(pb["G"]), dev.to_device(mesh.dofmap))
+        _check(y.copy_to_host(), y_ref, np.float64, f"planned build {pv} P={P}")
+    finally:
+        lib.set_tuning(lib.TUNE_PLAN_VARIANT, old)
