@@ -11,6 +11,7 @@
 #include "halo.hpp"
 #include "mass.hpp"
 #include "plan.hpp"
+#include "rk4.hpp"
 #include "stiffness.hpp"
 #include "vecops.hpp"
 
@@ -316,6 +317,19 @@ int fus_mass_apply_f32(const float* x, const float* c, float* y, const float* de
   }
 FUS_VEC(double, f64)
 FUS_VEC(float, f32)
+
+#define FUS_RK4(T, SUF)                                                                                        \
+  int fus_rk4_stage_##SUF(T bw, T aw, int new_step, const T* minv, T* b, T* u, T* v, T* u0, T* v0, T* ku, T* un, \
+                          int64_t nlocal, int64_t ntotal, void* s) {                                           \
+    if (nlocal < 0 || ntotal < nlocal) return FUS_ERR_INVALID_ARGUMENT;                                        \
+    if (ntotal == 0) return FUS_OK;                                                                            \
+    if (!minv || !b || !u || !v || !u0 || !v0 || !ku || !un) return FUS_ERR_INVALID_ARGUMENT;                  \
+    return hip_rc(fus::launch_rk4_stage<T>(bw, aw, new_step, minv, b, u, v, u0, v0, ku, un, nlocal, ntotal,    \
+                                           static_cast<hipStream_t>(s)));                                      \
+  }
+FUS_RK4(double, f64)
+FUS_RK4(float, f32)
+#undef FUS_RK4
 #undef FUS_VEC
 
 }  // extern "C"

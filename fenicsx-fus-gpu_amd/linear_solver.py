@@ -1,0 +1,239 @@
+"""
+Linear acoustic wave solver (explicit RK4 on u' = v, M v' = -K u + boundary terms) on the
+synthetic box mesh, driven entirely by this package's operators and scatterers -- the
+"demo_linear_box" caller of the hot path (BASELINE config 3).
+
+Semantics follow the reference drivers:
+  set-up        cuda/demo_linear_box.py:245-345 (geometry factors, source facets x = 0,
+                absorbing facets x = L, material coefficients), :421-428 (lumped mass
+                m = M(1/(rho c^2)) 1, scatter_rev)
+  time step     cuda/demo_linear_box.py:115-122 (dt = CFL h / (c P^2), snapped to an integer
+                number of steps per period; final time L/c + 2/f)
+  RK4 stage     cuda/demo_linear_box.py:487-566; source window / g evaluated at the STAGE
+                time tn as fenicsx/demo_linear_box.py:187-199,270, numba-cpu/demo_linear_box.py:345-358
+                and cpp/common/Linear.hpp:179-187,317 do (the CUDA demos use t -- SURVEY 3.4 quirks;
+                ``source_time="t"`` reproduces them)
+The class shape mirrors cpp/common/Linear.hpp:52-348 (LinearSpectral3D: init / rk4 / u_sol).
+
+Two stage implementations with identical results up to round-off:
+  fused=False   the reference's exact launch sequence (5 copy, 4 axpy, 2 fill, 1 divide, 3 operator
+                applies, 3 scatters per stage), through the reference-compatible call surface;
+  fused=True    one fused vector kernel per stage (csrc/rk4.hpp), ku doubling as v_n, the source
+                term through scaled facet constants instead of a full-vector fill, 1/m precomputed,
+                halo exchange overlapped with interior cells.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import operators as ops
+from .gll import gll_points_weights, tabulate_1d, tensor_points_3d, tensor_weights_2d, tensor_weights_3d
+from .precompute import (
+    compute_boundary_facets_scaled_jacobian_determinant,
+    compute_scaled_geometrical_factor,
+    compute_scaled_jacobian_determinant,
+    tabulate_facet_gradients,
+    tabulate_hex_p1_gradients,
+)
+
+A_RUNGE = (0.0, 0.5, 0.5, 1.0)
+B_RUNGE = (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0)
+C_RUNGE = (0.0, 0.5, 0.5, 1.0)
+
+
+def time_step_parameters(mesh, P, speed_of_sound, source_frequency, domain_length, CFL=0.65):
+    """cuda/demo_linear_box.py:115-122.  ``mesh_size`` = smallest cell diameter (dolfinx
+    ``cpp.mesh.h``: largest vertex-vertex distance of a cell), min over ranks by the caller."""
+    xg = mesh.x_g.astype(np.float64)[mesh.x_dofs]  # [nc, 8, 3]
+    d = np.linalg.norm(xg[:, :, None, :] - xg[:, None, :, :], axis=-1).reshape(mesh.ncells, -1).max(axis=1)
+    return float(d.min())
+
+
+def snap_time_step(mesh_size, P, speed_of_sound, source_frequency, domain_length, CFL=0.65):
+    period = 1.0 / source_frequency
+    dt = CFL * mesh_size / (speed_of_sound * P**2)
+    step_per_period = int(period / dt) + 1
+    dt = period / step_per_period
+    final_time = domain_length / speed_of_sound + 2.0 / source_frequency
+    return dt, final_time, int((final_time - 0.0) / dt) + 1
+
+
+class LinearSpectral3D:
+    def __init__(self, mesh, float_type=np.float64, speed_of_sound=1500.0, density=1000.0,
+                 source_frequency=0.5e6, source_amplitude=60000.0, comm=None, fused=True,
+                 source_time="tn", overlap=True, halo_kernels=None):
+        self.mesh, self.P = mesh, mesh.P
+        self.dt_np = np.dtype(float_type)
+        self.tdt = _lib.torch_dtype(float_type)
+        self.c0, self.rho0 = float(speed_of_sound), float(density)
+        self.f0, self.p0 = float(source_frequency), float(source_amplitude)
+        self.w0 = 2.0 * np.pi * self.f0
+        self.fused, self.source_time = bool(fused), source_time
+        self.comm = comm
+        P, n = self.P, self.P + 1
+        dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
+        ft = self.dt_np
+
+        # ---- host precompute (reference: numba on CPU, cuda/demo_linear_box.py:245-317) -------
+        pts, wts, D = tabulate_1d(P, ft)
+        self.D = D
+        w3 = tensor_weights_3d(wts).astype(ft)
+        dphi_g = tabulate_hex_p1_gradients(tensor_points_3d(pts), ft)
+        nc = mesh.ncells
+        G = np.zeros((nc, n**3, 6), dtype=ft)
+        detJ = np.zeros((nc, n**3), dtype=ft)
+        compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), nc, dphi_g, w3)
+        compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), nc, dphi_g, w3)
+        bd1 = mesh.boundary_facets([2])  # x = 0: source
+        bd2 = mesh.boundary_facets([3])  # x = L: absorbing
+        w2 = tensor_weights_2d(wts).astype(ft)
+        dphi_f = tabulate_facet_gradients(pts, ft)
+        dF1 = np.zeros((bd1.shape[0], n * n), dtype=ft)
+        dF2 = np.zeros((bd2.shape[0], n * n), dtype=ft)
+        compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dphi_f, w2)
+        compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dphi_f, w2)
+        rho = np.full(nc, self.rho0, dtype=ft)
+        c = np.full(nc, self.c0, dtype=ft)
+        td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+        self.cell_coeff1 = td(1.0 / rho / c / c)  # :336
+        self.cell_coeff2 = td(-1.0 / rho)  # :337
+        self.facet_coeff1 = td((1.0 / rho[bd1[:, 0]]).astype(ft))  # :339-341
+        self.facet_coeff2 = td((-1.0 / rho[bd2[:, 0]] / c[bd2[:, 0]]).astype(ft))  # :343-345
+        self.G, self.detJ, self.dofmap = td(G), td(detJ), td(mesh.dofmap)
+        self.detJ_f1, self.detJ_f2 = td(dF1), td(dF2)
+        self.fdm1, self.fdm2 = td(mesh.facet_dofmap(bd1)), td(mesh.facet_dofmap(bd2))
+        self.nlocal, self.ndofs = mesh.nlocal, mesh.ndofs
+
+        # ---- operators --------------------------------------------------------------------------
+        self.stiff = ops.stiffness_operator(P, D.flatten(), ft)
+        self.mass_cell = ops.mass_operator(n**3, ft)
+        self.mass_facet = ops.mass_operator(n * n, ft)
+        self.axpy = ops.axpy(self.ndofs)
+
+        # ---- halo ---------------------------------------------------------------------------------
+        self.halo = None
+        if comm is not None and comm.size > 1:
+            from .scatterer import HaloApply, scatter_forward
+
+            self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap, kernels=halo_kernels)
+            self.fwd_v = scatter_forward(comm, self.halo.owners_data, self.halo.ghosts_data, mesh.nlocal, ft, halo_kernels)
+
+        z = lambda: torch.zeros(self.ndofs, dtype=self.tdt, device=dev)  # noqa: E731
+        self.u, self.v, self.u0, self.v0 = z(), z(), z(), z()
+        self.un, self.vn, self.ku, self.kv = z(), z(), z(), z()
+        self.u_n, self.v_n, self.g, self.b, self.m = z(), z(), z(), z(), z()
+        self.fc1_work = torch.zeros_like(self.facet_coeff1)
+
+        # ---- lumped mass: m = M(1/(rho c^2)) 1, reverse-scattered (:421-428) ---------------------
+        ops.fill(1.0, self.g)
+        self.mass_cell(self.g, self.cell_coeff1, self.m, self.detJ, self.dofmap)
+        if self.halo is not None:
+            self.halo.rev(self.m)
+        self.minv = z()
+        ops.fill(1.0, self.minv)
+        ops.pointwise_divide(self.minv, self.m, self.minv)  # owned entries are what the fused kernel reads
+        # g stays 1 for the fused path (source enters through scaled facet constants)
+
+    # ------------------------------------------------------------------------------------------
+    def init(self):
+        """u = v = 0 (cuda/demo_linear_box.py:434-435)."""
+        for t in (self.u, self.v, self.ku, self.kv):
+            ops.fill(0.0, t)
+
+    def source_value(self, t):
+        """Window x p0 w0 / c0 x cos(w0 t) (cuda/demo_linear_box.py:515-530)."""
+        T, alpha = 1.0 / self.f0, 4.0
+        window = 0.5 * (1.0 - np.cos(self.f0 * np.pi * t / alpha)) if t < T * alpha else 1.0
+        return window * self.p0 * self.w0 / self.c0 * np.cos(self.w0 * t)
+
+    # -- reference launch sequence ----------------------------------------------------------------
+    def _stage_reference(self, i, t, dt):
+        copy, fill, axpy = ops.copy, ops.fill, self.axpy
+        copy(self.u0, self.un)
+        copy(self.v0, self.vn)
+        axpy(A_RUNGE[i] * dt, self.ku, self.un)
+        axpy(A_RUNGE[i] * dt, self.kv, self.vn)
+        tn = t + C_RUNGE[i] * dt
+        copy(self.vn, self.ku)  # f0
+        fill(self.source_value(tn if self.source_time == "tn" else t), self.g)
+        copy(self.un, self.u_n)
+        copy(self.vn, self.v_n)
+        fill(0.0, self.b)
+
+        def facets():
+            self.mass_facet(self.g, self.facet_coeff1, self.b, self.detJ_f1, self.fdm1)
+            self.mass_facet(self.v_n, self.facet_coeff2, self.b, self.detJ_f2, self.fdm2)
+
+        if self.halo is None:
+            self.stiff(self.u_n, self.cell_coeff2, self.b, self.G, self.dofmap)
+            facets()
+        else:
+            self.halo.apply(self.u_n, self.cell_coeff2, self.b, self.G, self.dofmap,
+                            extra_forward=[(self.fwd_v, self.v_n)], boundary_terms=facets)
+        ops.pointwise_divide(self.b, self.m, self.kv)
+        axpy(B_RUNGE[i] * dt, self.ku, self.u)
+        axpy(B_RUNGE[i] * dt, self.kv, self.v)
+
+    # -- fused --------------------------------------------------------------------------------------
+    def _rk4_stage_kernel(self, bw, aw, new_step):
+        fn = getattr(_lib.load(), f"fus_rk4_stage_{_lib.suffix(self.tdt)}")
+        _lib.check(
+            fn(float(bw), float(aw), int(new_step), self.minv.data_ptr(), self.b.data_ptr(), self.u.data_ptr(),
+               self.v.data_ptr(), self.u0.data_ptr(), self.v0.data_ptr(), self.ku.data_ptr(), self.un.data_ptr(),
+               self.nlocal, self.ndofs, _lib.stream_ptr()),
+            "fus_rk4_stage",
+        )
+
+    def _operator_fused(self, tn_or_t):
+        gval = self.source_value(tn_or_t)
+        ops.fill(0.0, self.fc1_work)
+        if self.fc1_work.numel():
+            ops.axpy[1, 1](gval, self.facet_coeff1, self.fc1_work)  # facet constants x g (x = 1 on the facets)
+
+        def facets():
+            self.mass_facet(self.g, self.fc1_work, self.b, self.detJ_f1, self.fdm1)
+            self.mass_facet(self.ku, self.facet_coeff2, self.b, self.detJ_f2, self.fdm2)  # ku == v_n
+
+        if self.halo is None:
+            self.stiff(self.un, self.cell_coeff2, self.b, self.G, self.dofmap)
+            facets()
+        else:
+            self.halo.apply(self.un, self.cell_coeff2, self.b, self.G, self.dofmap,
+                            extra_forward=[(self.fwd_v, self.ku)], boundary_terms=facets)
+
+    def rk4(self, start_time, final_time, dt, max_steps=None):
+        """Advance from ``start_time`` to ``final_time`` (cuda/demo_linear_box.py:487-566).
+        Returns ``(t, steps)``."""
+        t, step = float(start_time), 0
+        tf = float(final_time)
+        if self.fused:
+            # prologue: u0 = u, v0 = v, un = u, ku = vn = v, b = 0  (bw = aw = 0, new step)
+            ops.fill(0.0, self.b)
+            self._rk4_stage_kernel(0.0, 0.0, 1)
+        while t < tf and (max_steps is None or step < max_steps):
+            dt = min(dt, tf - t)
+            if self.fused:
+                for i in range(4):
+                    tn = t + C_RUNGE[i] * dt
+                    self._operator_fused(tn if self.source_time == "tn" else t)
+                    last = i == 3
+                    self._rk4_stage_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 1 if last else 0)
+            else:
+                ops.copy(self.u, self.u0)
+                ops.copy(self.v, self.v0)
+                for i in range(4):
+                    self._stage_reference(i, t, dt)
+            t += dt
+            step += 1
+        return t, step
+
+    def u_sol(self):
+        """Owned part of the pressure field on the host."""
+        return self.u[: self.nlocal].detach().cpu().numpy()
+
+    def v_sol(self):
+        return self.v[: self.nlocal].detach().cpu().numpy()

@@ -220,17 +220,30 @@ class HaloApply:
         else:
             self.op(x, c_, y, G_, d_)
 
-    def apply(self, x, cell_constants, y, G, dofmap):
+    def apply(self, x, cell_constants, y, G, dofmap, extra_forward=(), boundary_terms=None):
+        """``extra_forward``: further ``(scatter_forward closure, vector)`` pairs to refresh
+        alongside x (e.g. v_n of the RK stage); ``boundary_terms()``: callable adding the
+        boundary-facet contributions to y -- it runs after every forward scatter has landed
+        and before the reverse scatter is posted (facet dofs can be ghosts)."""
         if not self.overlap:
             self.fwd(x)
+            for sc, vec in extra_forward:
+                sc(vec)
             for name in ("boundary", "interior1", "interior2"):
                 self._apply(name, x, cell_constants, y, G, dofmap)
+            if boundary_terms is not None:
+                boundary_terms()
             self.rev(y)
             return
         w = self.fwd.begin(x)
+        extra = [(sc, vec, sc.begin(vec)) for sc, vec in extra_forward]
         self._apply("interior1", x, cell_constants, y, G, dofmap)
         self.fwd.end(x, w)
+        for sc, vec, wk in extra:
+            sc.end(vec, wk)
         self._apply("boundary", x, cell_constants, y, G, dofmap)
+        if boundary_terms is not None:
+            boundary_terms()
         w = self.rev.begin(y)
         self._apply("interior2", x, cell_constants, y, G, dofmap)
         self.rev.end(y, w)

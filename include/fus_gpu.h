@@ -125,6 +125,20 @@ int fus_square_f64(const double* a, double* b, int64_t n, void* stream);        
 int fus_square_f32(const float* a, float* b, int64_t n, void* stream);
 
 /*
+ * Fused RK4 stage update: everything the reference does between scatter_rev(b) of one stage and
+ * scatter_fwd of the next (cuda/demo_linear_box.py:556-563 then :491-508,541 -- 12 launches, 216
+ * B/dof) in one pass:
+ *   kv = b * minv;  u += bw ku;  v += bw kv;  [new_step: u0 = u; v0 = v;]
+ *   un = u0 + aw ku;  ku = v0 + aw kv  (= vn, which is also f0 of the next stage);  b = 0
+ * over the owned dofs [0, nlocal); b is zeroed over [0, ntotal).  bw = b_runge[i] dt,
+ * aw = a_runge[i+1] dt (0 with new_step = 1 after the last stage).  minv = 1 / m.
+ */
+int fus_rk4_stage_f64(double bw, double aw, int new_step, const double* minv, double* b, double* u, double* v,
+                      double* u0, double* v0, double* ku, double* un, int64_t nlocal, int64_t ntotal, void* stream);
+int fus_rk4_stage_f32(float bw, float aw, int new_step, const float* minv, float* b, float* u, float* v, float* u0,
+                      float* v0, float* ku, float* un, int64_t nlocal, int64_t ntotal, void* stream);
+
+/*
  * Halo pack / unpack (all neighbours in ONE launch: ``index`` is the concatenation of the
  * per-neighbour index lists, the send/recv buffer is the concatenation of the per-neighbour
  * messages).  N = nlocal (offset of the ghost block in a dof vector).

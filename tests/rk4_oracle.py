@@ -1,0 +1,68 @@
+"""ORACLE-side RK4 driver (test infrastructure): the linear wave solver of
+numba-cpu/demo_linear_box.py:302-455 (f0 / f1 / RK4 loop, source evaluated at tn) on one
+rank, restated with the oracle's operators.  Used to check the GPU solver's pressure field."""
+
+import numpy as np
+
+from conftest import pkg
+from oracle import oracle_np
+
+A = (0.0, 0.5, 0.5, 1.0)
+B = (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0)
+C = (0.0, 0.5, 0.5, 1.0)
+
+
+def solve(mesh, nsteps, dt, c0=1500.0, rho0=1000.0, f0=0.5e6, p0=60000.0, source_time="tn", oracle_c=None):
+    gll, pre = pkg("gll"), pkg("precompute")
+    P, n = mesh.P, mesh.P + 1
+    pts, wts, D = gll.tabulate_1d(P)
+    w3 = gll.tensor_weights_3d(wts)
+    dg = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))
+    nc = mesh.ncells
+    G, detJ = np.zeros((nc, n**3, 6)), np.zeros((nc, n**3))
+    pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), nc, dg, w3)
+    pre.compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), nc, dg, w3)
+    bd1, bd2 = mesh.boundary_facets([2]), mesh.boundary_facets([3])
+    w2, dpf = gll.tensor_weights_2d(wts), pre.tabulate_facet_gradients(pts)
+    dF1, dF2 = np.zeros((bd1.shape[0], n * n)), np.zeros((bd2.shape[0], n * n))
+    pre.compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dpf, w2)
+    pre.compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dpf, w2)
+    fd1, fd2 = mesh.facet_dofmap(bd1), mesh.facet_dofmap(bd2)
+    cc1, cc2 = np.full(nc, 1 / rho0 / c0 / c0), np.full(nc, -1 / rho0)
+    fc1, fc2 = np.full(bd1.shape[0], 1 / rho0), np.full(bd2.shape[0], -1 / rho0 / c0)
+    nd = mesh.ndofs
+    w0 = 2 * np.pi * f0
+    m = np.zeros(nd)
+    oracle_np.mass_apply(np.ones(nd), cc1, m, detJ, mesh.dofmap)
+
+    def stiff(x, y):
+        if oracle_c is not None:
+            oracle_c.stiffness_apply(P, D, x, cc2, y, G, mesh.dofmap)
+        else:
+            oracle_np.stiffness_apply(P, D.flatten(), x, cc2, y, G, mesh.dofmap)
+
+    def f1(t, un, vn):
+        T, alpha = 1 / f0, 4.0
+        window = 0.5 * (1 - np.cos(f0 * np.pi * t / alpha)) if t < T * alpha else 1.0
+        g = np.full(nd, window * p0 * w0 / c0 * np.cos(w0 * t))
+        b = np.zeros(nd)
+        stiff(un, b)
+        oracle_np.mass_apply(g, fc1, b, dF1, fd1)
+        oracle_np.mass_apply(vn, fc2, b, dF2, fd2)
+        return b / m
+
+    u, v = np.zeros(nd), np.zeros(nd)
+    ku, kv = np.zeros(nd), np.zeros(nd)
+    t = 0.0
+    for _ in range(nsteps):
+        u0, v0 = u.copy(), v.copy()
+        for i in range(4):
+            un = u0 + A[i] * dt * ku
+            vn = v0 + A[i] * dt * kv
+            tn = t + C[i] * dt
+            ku = vn.copy()
+            kv = f1(tn if source_time == "tn" else t, un, vn)
+            u = u + B[i] * dt * ku
+            v = v + B[i] * dt * kv
+        t += dt
+    return u, v

@@ -81,3 +81,13 @@ def test_partitioned_apply_two_ranks_one_gpu(tmp_path, oracle_c):
     P, cells, grid = 4, (4, 4, 4), (2, 1, 1)
     res = run_ranks("gpu", tmp_path, P, cells, grid, 1)
     check(res, *serial_reference(P, cells, oracle_c))
+
+
+@pytest.mark.gpu
+def test_rccl_world1_alltoallv():
+    """RCCL transport of TorchComm with the bench's process-group options (world size 1)."""
+    env = dict(os.environ, RANK="0", WORLD_SIZE="1", LOCAL_RANK="0", MASTER_ADDR="127.0.0.1",
+               MASTER_PORT=str(_free_port()), HSA_ENABLE_IPC_MODE_LEGACY="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tests", "_nccl_worker.py")], env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "NCCL_WORLD1_OK" in r.stdout, (r.stdout + r.stderr)[-3000:]
