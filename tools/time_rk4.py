@@ -1,0 +1,48 @@
+#!/usr/bin/env python3
+"""Time one RK4 step of the linear wave solver (BASELINE config 3 shape) on one GPU:
+the reference's launch sequence vs the fused stage."""
+import argparse
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--cells", type=int, default=54)
+    ap.add_argument("--degree", type=int, default=4)
+    ap.add_argument("--steps", type=int, default=20)
+    a = ap.parse_args()
+    import torch
+
+    import fusgpu_loader
+
+    torch.cuda.set_device(0)
+    boxmesh, ls = fusgpu_loader.submodule("boxmesh"), fusgpu_loader.submodule("linear_solver")
+    L = 0.12
+    mesh = boxmesh.BoxMesh(a.degree, a.cells, length=L)
+    h = ls.time_step_parameters(mesh, a.degree, 1500.0, 0.5e6, L)
+    dt, tf, nstep = ls.snap_time_step(h, a.degree, 1500.0, 0.5e6, L)
+    print(f"P={a.degree} cells={mesh.ncells} dofs={mesh.ndofs} dt={dt:.3e} steps to final time={nstep}")
+    for fused in (False, True):
+        s = ls.LinearSpectral3D(mesh, np.float64, fused=fused)
+        s.init()
+        s.rk4(0.0, tf, dt, max_steps=3)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        s.rk4(3 * dt, tf, dt, max_steps=a.steps)
+        torch.cuda.synchronize()
+        el = (time.perf_counter() - t0) / a.steps
+        print(f"{'fused' if fused else 'reference sequence'}: {el * 1e3:.3f} ms/step  "
+              f"({mesh.ndofs / el / 1e9:.2f} GDOF-steps/s; full run of {nstep} steps = {el * nstep:.1f} s)", flush=True)
+        del s
+        torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
