@@ -1,0 +1,177 @@
+"""
+Westervelt (nonlinear) acoustic wave solver on the synthetic mesh -- the caller of BASELINE
+config 5 (cuda/demo_nonlinear_bowl.py / demo_nonlinear_box.py): per RK4 stage two stiffness
+applies (u_n with -1/rho, v_n with -delta/(rho c^2)), a solution-dependent lumped mass
+m = m0 + M(-2 beta/(rho^2 c^4)) u_n, the quadratic term M(2 beta/(rho^2 c^4)) v_n^2 and the
+source / absorbing boundary-facet terms (cuda/demo_nonlinear_bowl.py:357-374, 458-475, 540-650).
+
+The reference's transducer mesh (H131/mesh.xdmf) is not in its repository; the geometry here is
+the synthetic box, optionally warped into non-affine trilinear cells (``BoxMesh(warp=...)``), with
+the source on x = 0 and the absorbing condition on x = L as in cuda/demo_nonlinear_box.py.
+The stage follows the reference's launch sequence through the reference-compatible operators.
+"""
+
+from __future__ import annotations
+
+import numpy as np
+import torch
+
+from . import _lib
+from . import operators as ops
+from .gll import tabulate_1d, tensor_points_3d, tensor_weights_2d, tensor_weights_3d
+from .linear_solver import A_RUNGE, B_RUNGE, C_RUNGE
+from .precompute import (
+    compute_boundary_facets_scaled_jacobian_determinant,
+    compute_scaled_geometrical_factor,
+    compute_scaled_jacobian_determinant,
+    tabulate_facet_gradients,
+    tabulate_hex_p1_gradients,
+)
+
+
+def compute_diffusivity_of_sound(frequency, speed, attenuationdB):
+    """cuda/utils.py:157-162."""
+    attenuationNp = attenuationdB / 20 * np.log(10)
+    return 2 * attenuationNp * speed**3 / frequency / frequency
+
+
+class WesterveltSpectral3D:
+    def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
+                 source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
+                 attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True):
+        self.mesh, self.P = mesh, mesh.P
+        ft = np.dtype(float_type)
+        self.tdt = _lib.torch_dtype(ft)
+        self.c0, self.rho0, self.f0 = float(speed_of_sound), float(density), float(source_frequency)
+        self.p0 = float(source_amplitude) if source_amplitude is not None else self.rho0 * self.c0 * 0.38557513826589934
+        self.w0 = 2 * np.pi * self.f0
+        self.beta = float(nonlinear_coefficient)
+        self.delta = compute_diffusivity_of_sound(self.w0, self.c0, attenuation_coefficient_dB)
+        self.source_time = source_time
+        P, n = self.P, self.P + 1
+        dev = torch.device("cuda", torch.cuda.current_device())
+        pts, wts, D = tabulate_1d(P, ft)
+        w3 = tensor_weights_3d(wts).astype(ft)
+        dg = tabulate_hex_p1_gradients(tensor_points_3d(pts), ft)
+        nc = mesh.ncells
+        G, detJ = np.zeros((nc, n**3, 6), dtype=ft), np.zeros((nc, n**3), dtype=ft)
+        compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), nc, dg, w3)
+        compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), nc, dg, w3)
+        bd1, bd2 = mesh.boundary_facets([2]), mesh.boundary_facets([3])
+        w2, dpf = tensor_weights_2d(wts).astype(ft), tabulate_facet_gradients(pts, ft)
+        dF1, dF2 = np.zeros((bd1.shape[0], n * n), dtype=ft), np.zeros((bd2.shape[0], n * n), dtype=ft)
+        compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dpf, w2)
+        compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dpf, w2)
+        rho, c = np.full(nc, self.rho0), np.full(nc, self.c0)
+        beta, delta = np.full(nc, self.beta), np.full(nc, self.delta)
+        td = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=ft))).to(dev)  # noqa: E731
+        # cuda/demo_nonlinear_bowl.py:357-374
+        self.cc1 = td(1.0 / rho / c / c)
+        self.cc2 = td(-2.0 * beta / rho / rho / c**4)
+        self.cc3 = td(-1.0 / rho)
+        self.cc4 = td(-delta / rho / c / c)
+        self.cc5 = td(2.0 * beta / rho / rho / c**4)
+        c1, c2 = bd1[:, 0], bd2[:, 0]
+        self.fc1_1 = td(1.0 / rho[c1])
+        self.fc2_1 = td(delta[c1] / rho[c1] / c[c1] ** 2)
+        self.fc1_2 = td(delta[c2] / rho[c2] / c[c2] ** 3)
+        self.fc2_2 = td(-1.0 / rho[c2] / c[c2])
+        self.G, self.detJ = td(G), td(detJ)
+        self.dofmap = torch.from_numpy(mesh.dofmap).to(dev)
+        self.dF1, self.dF2 = td(dF1), td(dF2)
+        self.fdm1 = torch.from_numpy(mesh.facet_dofmap(bd1)).to(dev)
+        self.fdm2 = torch.from_numpy(mesh.facet_dofmap(bd2)).to(dev)
+        self.nlocal, self.ndofs = mesh.nlocal, mesh.ndofs
+        self.stiff = ops.stiffness_operator(P, D.flatten(), ft)
+        self.mass_cell = ops.mass_operator(n**3, ft)
+        self.mass_facet = ops.mass_operator(n * n, ft)
+        self.axpy = ops.axpy(self.ndofs)
+        self.halo = None
+        if comm is not None and comm.size > 1:
+            from .scatterer import HaloApply, scatter_forward
+
+            self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap)
+            mk = lambda: scatter_forward(comm, self.halo.owners_data, self.halo.ghosts_data, mesh.nlocal, ft)  # noqa: E731
+            self.fwd_u, self.fwd_v, self.fwd_w = self.halo.fwd, mk(), mk()
+        z = lambda: torch.zeros(self.ndofs, dtype=self.tdt, device=dev)  # noqa: E731
+        (self.u, self.v, self.u0, self.v0, self.un, self.vn, self.ku, self.kv, self.u_n, self.v_n, self.w_n,
+         self.g, self.dg, self.b, self.m, self.m0) = (z() for _ in range(16))
+        # steady part of the lumped mass (:458-475)
+        ops.fill(1.0, self.g)
+        self.mass_cell(self.g, self.cc1, self.m0, self.detJ, self.dofmap)
+        self.mass_facet(self.g, self.fc1_2, self.m0, self.dF2, self.fdm2)
+        if self.halo is not None:
+            self.halo.rev(self.m0)
+
+    def init(self):
+        for t in (self.u, self.v, self.ku, self.kv):
+            ops.fill(0.0, t)
+
+    def source_values(self, t):
+        """g and dg/dt (cuda/demo_nonlinear_bowl.py:560-595)."""
+        T, alpha = 1.0 / self.f0, 4.0
+        if t < T * alpha:
+            window = 0.5 * (1.0 - np.cos(self.f0 * np.pi * t / alpha))
+            dwindow = 0.5 * np.pi * self.f0 / alpha * np.sin(self.f0 * np.pi * t / alpha)
+        else:
+            window, dwindow = 1.0, 0.0
+        a = 2.0 * self.p0 * self.w0 / self.c0
+        g = window * a * np.cos(self.w0 * t)
+        dg = dwindow * a * np.cos(self.w0 * t) - window * a * self.w0 * np.sin(self.w0 * t)
+        return g, dg
+
+    def _stage(self, i, t, dt):
+        copy, fill, axpy = ops.copy, ops.fill, self.axpy
+        copy(self.u0, self.un)
+        copy(self.v0, self.vn)
+        axpy(A_RUNGE[i] * dt, self.ku, self.un)
+        axpy(A_RUNGE[i] * dt, self.kv, self.vn)
+        tn = t + C_RUNGE[i] * dt
+        copy(self.vn, self.ku)
+        gv, dgv = self.source_values(tn if self.source_time == "tn" else t)
+        fill(gv, self.g)
+        fill(dgv, self.dg)
+        copy(self.un, self.u_n)
+        copy(self.vn, self.v_n)
+        ops.square(self.vn, self.w_n)
+        if self.halo is not None:
+            self.fwd_u(self.u_n)
+            self.fwd_v(self.v_n)
+            self.fwd_w(self.w_n)
+        # unsteady lumped mass
+        fill(0.0, self.m)
+        self.mass_cell(self.u_n, self.cc2, self.m, self.detJ, self.dofmap)
+        if self.halo is not None:
+            self.halo.rev(self.m)
+        axpy(1.0, self.m0, self.m)
+        # right-hand side
+        fill(0.0, self.b)
+        self.stiff(self.u_n, self.cc3, self.b, self.G, self.dofmap)
+        self.stiff(self.v_n, self.cc4, self.b, self.G, self.dofmap)
+        self.mass_cell(self.w_n, self.cc5, self.b, self.detJ, self.dofmap)
+        self.mass_facet(self.g, self.fc1_1, self.b, self.dF1, self.fdm1)
+        self.mass_facet(self.dg, self.fc2_1, self.b, self.dF1, self.fdm1)
+        self.mass_facet(self.v_n, self.fc2_2, self.b, self.dF2, self.fdm2)
+        if self.halo is not None:
+            self.halo.rev(self.b)
+        ops.pointwise_divide(self.b, self.m, self.kv)
+        axpy(B_RUNGE[i] * dt, self.ku, self.u)
+        axpy(B_RUNGE[i] * dt, self.kv, self.v)
+
+    def rk4(self, start_time, final_time, dt, max_steps=None):
+        t, step, tf = float(start_time), 0, float(final_time)
+        while t < tf and (max_steps is None or step < max_steps):
+            dt = min(dt, tf - t)
+            ops.copy(self.u, self.u0)
+            ops.copy(self.v, self.v0)
+            for i in range(4):
+                self._stage(i, t, dt)
+            t += dt
+            step += 1
+        return t, step
+
+    def u_sol(self):
+        return self.u[: self.nlocal].detach().cpu().numpy()
+
+    def v_sol(self):
+        return self.v[: self.nlocal].detach().cpu().numpy()
