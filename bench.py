@@ -124,6 +124,55 @@ def load_traffic(P, ncell):
     return None
 
 
+def bench_rk4(args, rank, world, device):
+    """Auxiliary metric (not the headline): full RK4 steps of the linear wave solver
+    (BASELINE config 3: demo_linear_box, P = 4, ~10 M dofs per GPU), fused stage kernels."""
+    import torch
+    import torch.distributed as dist
+
+    import fusgpu_loader
+
+    boxmesh, ls = fusgpu_loader.submodule("boxmesh"), fusgpu_loader.submodule("linear_solver")
+    scat = fusgpu_loader.submodule("scatterer")
+    P, L = args.degree, 0.12
+    dt_np = np.float64 if args.dtype == "f64" else np.float32
+    grid = boxmesh.default_grid(world)
+    gcells = tuple(args.cells * g for g in grid)
+    mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, length=tuple(L * g for g in grid), dtype=dt_np)
+    h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dts, tf, nstep = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    comm = scat.TorchComm() if world > 1 else None
+    solver = ls.LinearSpectral3D(mesh, dt_np, comm=comm, fused=True)
+    solver.init()
+    solver.rk4(0.0, tf, dts, max_steps=max(1, args.warmup))
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    solver.rk4(args.warmup * dts, tf, dts, max_steps=args.steps)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    el = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([el], dtype=torch.float64, device=device)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        el = float(tt.item())
+    out = {
+        "metric": "rk4_step_dof_per_s", "value": mesh.ndofs_global * args.steps / el, "unit": "DOF*steps/s",
+        "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": el / args.steps * 1e3,
+        "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
+        "config": {"workload": f"linear wave RK4 step (4 stages: stiffness + 2 facet mass + fused vector update + halo), "
+                               f"P={P}, {gcells[0]}x{gcells[1]}x{gcells[2]} cells, {mesh.ndofs_global} dofs",
+                   "steps_to_final_time": nstep, "dt": dts},
+        "roofline": None, "cpu_baseline": None,
+    }
+    if rank == 0:
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -136,6 +185,8 @@ def main():
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--xcd-remap", type=int, default=None)
     ap.add_argument("--no-plan", action="store_true", help="plan-free kernel (reads dofmap directly)")
+    ap.add_argument("--mode", default="stiffness", choices=["stiffness", "rk4"],
+                    help="stiffness: the headline metric; rk4: one full RK4 time step of the linear solver per 'step'")
     args = ap.parse_args()
 
     import torch
@@ -173,6 +224,9 @@ def main():
     if args.xcd_remap is not None:
         lib.set_tuning(lib.TUNE_XCD_REMAP, args.xcd_remap)
 
+    if args.mode == "rk4":
+        return bench_rk4(args, rank, world, device)
+
     P = args.degree
     n = P + 1
     dt = np.float64 if args.dtype == "f64" else np.float32
@@ -185,21 +239,25 @@ def main():
     pts, wts, D = gll.tabulate_1d(P, dt)
     wts3 = gll.tensor_weights_3d(wts).astype(dt)
     dphi_g = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts), dt)
-    G = np.zeros((mesh.ncells, n**3, 6), dtype=dt)
-    pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), mesh.ncells, dphi_g, wts3)
     xyz = mesh.dof_coordinates()
     x = (100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])).astype(dt)
     del xyz
     cc = np.random.default_rng(1234).standard_normal(mesh.ncells).astype(dt)
-    if rank == 0:
-        log(f"setup {time.time() - t0:.1f}s: P={P} cells/GPU={mesh.ncells} local dofs={mesh.ndofs} "
-            f"global dofs={mesh.ndofs_global} grid={grid} G={G.nbytes / 1e6:.0f} MB")
 
     x_d = torch.from_numpy(x).to(device)
     y_d = torch.zeros(mesh.ndofs, dtype=x_d.dtype, device=device)
     cc_d = torch.from_numpy(cc).to(device)
-    G_d = torch.from_numpy(G).to(device)
     dm_d = torch.from_numpy(mesh.dofmap).to(device)
+    # geometry factors on the device (csrc/geometry.hpp; parity with the reference's precompute.py
+    # is tested on the golden vectors): general per-quadrature-point G, no affine shortcut
+    G_d = torch.empty((mesh.ncells, n**3, 6), dtype=x_d.dtype, device=device)
+    pre.compute_scaled_geometrical_factor_device(
+        G_d, (torch.from_numpy(mesh.x_dofs).to(device), torch.from_numpy(mesh.x_g).to(device)), mesh.ncells,
+        torch.from_numpy(dphi_g).to(device), torch.from_numpy(wts3).to(device))
+    torch.cuda.synchronize()
+    if rank == 0:
+        log(f"setup {time.time() - t0:.1f}s: P={P} cells/GPU={mesh.ncells} local dofs={mesh.ndofs} "
+            f"global dofs={mesh.ndofs_global} grid={grid} G={G_d.numel() * T / 1e6:.0f} MB")
     op = ops.stiffness_operator(P, D.flatten(), dt)
 
     halo = None
@@ -299,6 +357,7 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
+            G = G_d.cpu().numpy()  # the CPU baseline streams the same G the GPU did
             pb = dict(mesh=mesh, D=D, x=x.astype(np.float64), cc=cc.astype(np.float64), G=G.astype(np.float64))
             if dt != np.float64:
                 D = D.astype(np.float64)

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstring>
 
+#include "geometry.hpp"
 #include "halo.hpp"
 #include "mass.hpp"
 #include "plan.hpp"
@@ -317,6 +318,27 @@ int fus_mass_apply_f32(const float* x, const float* c, float* y, const float* de
   }
 FUS_VEC(double, f64)
 FUS_VEC(float, f32)
+
+#define FUS_GEOM(T, SUF)                                                                                         \
+  int fus_geometry_factors_##SUF(const T* x_g, const int32_t* x_dofs, const T* dphi, const T* weights, int nq,   \
+                                 int64_t ncell, T* G, T* detJ, void* s) {                                        \
+    if (ncell < 0 || nq < 1) return FUS_ERR_INVALID_ARGUMENT;                                                    \
+    if (ncell == 0) return FUS_OK;                                                                               \
+    if (!x_g || !x_dofs || !dphi || !weights || (!G && !detJ)) return FUS_ERR_INVALID_ARGUMENT;                  \
+    return hip_rc(fus::launch_geometry<T>(x_g, x_dofs, dphi, weights, nq, ncell, G, detJ,                        \
+                                          static_cast<hipStream_t>(s)));                                         \
+  }                                                                                                              \
+  int fus_facet_jacobian_##SUF(const T* x_g, const int32_t* x_dofs, const int32_t* boundary_data, const T* dphi_f, \
+                               const T* weights, int nqf, int64_t nfacets, T* detJ_f, void* s) {                 \
+    if (nfacets < 0 || nqf < 1) return FUS_ERR_INVALID_ARGUMENT;                                                 \
+    if (nfacets == 0) return FUS_OK;                                                                             \
+    if (!x_g || !x_dofs || !boundary_data || !dphi_f || !weights || !detJ_f) return FUS_ERR_INVALID_ARGUMENT;    \
+    return hip_rc(fus::launch_facet_geometry<T>(x_g, x_dofs, boundary_data, dphi_f, weights, nqf, nfacets,       \
+                                                detJ_f, static_cast<hipStream_t>(s)));                           \
+  }
+FUS_GEOM(double, f64)
+FUS_GEOM(float, f32)
+#undef FUS_GEOM
 
 #define FUS_RK4(T, SUF)                                                                                        \
   int fus_rk4_stage_##SUF(T bw, T aw, int new_step, const T* minv, T* b, T* u, T* v, T* u0, T* v0, T* ku, T* un, \

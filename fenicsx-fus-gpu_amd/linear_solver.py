@@ -32,12 +32,39 @@ from . import _lib
 from . import operators as ops
 from .gll import gll_points_weights, tabulate_1d, tensor_points_3d, tensor_weights_2d, tensor_weights_3d
 from .precompute import (
-    compute_boundary_facets_scaled_jacobian_determinant,
-    compute_scaled_geometrical_factor,
-    compute_scaled_jacobian_determinant,
+    compute_boundary_facets_scaled_jacobian_determinant_device,
+    compute_scaled_geometrical_factor_device,
     tabulate_facet_gradients,
     tabulate_hex_p1_gradients,
 )
+
+
+def device_geometry(mesh, P, ft, dev, facet_sets):
+    """G, detJ and the facet detJ of the given boundary_data sets, computed on the device
+    (csrc/geometry.hpp; the reference does this with numba on the host,
+    cuda/demo_linear_box.py:245-317)."""
+    import torch
+
+    from .gll import tabulate_1d, tensor_points_3d, tensor_weights_2d, tensor_weights_3d
+
+    n = P + 1
+    pts, wts, D = tabulate_1d(P, ft)
+    td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
+    tdt = torch.float64 if np.dtype(ft) == np.float64 else torch.float32
+    w3, w2 = td(tensor_weights_3d(wts).astype(ft)), td(tensor_weights_2d(wts).astype(ft))
+    dphi_g = td(tabulate_hex_p1_gradients(tensor_points_3d(pts), ft))
+    dphi_f = td(tabulate_facet_gradients(pts, ft))
+    gm = (td(mesh.x_dofs), td(mesh.x_g))
+    G = torch.empty((mesh.ncells, n**3, 6), dtype=tdt, device=dev)
+    detJ = torch.empty((mesh.ncells, n**3), dtype=tdt, device=dev)
+    compute_scaled_geometrical_factor_device(G, gm, mesh.ncells, dphi_g, w3, detJ=detJ)
+    out = []
+    for bd in facet_sets:
+        dF = torch.zeros((bd.shape[0], n * n), dtype=tdt, device=dev)
+        if bd.shape[0]:
+            compute_boundary_facets_scaled_jacobian_determinant_device(dF, gm, td(bd.astype(np.int32)), dphi_f, w2)
+        out.append(dF)
+    return D, G, detJ, out
 
 A_RUNGE = (0.0, 0.5, 0.5, 1.0)
 B_RUNGE = (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0)
@@ -78,24 +105,12 @@ class LinearSpectral3D:
         self.dev = dev
         ft = self.dt_np
 
-        # ---- host precompute (reference: numba on CPU, cuda/demo_linear_box.py:245-317) -------
-        pts, wts, D = tabulate_1d(P, ft)
-        self.D = D
-        w3 = tensor_weights_3d(wts).astype(ft)
-        dphi_g = tabulate_hex_p1_gradients(tensor_points_3d(pts), ft)
+        # ---- geometry precompute (reference: numba on the host, cuda/demo_linear_box.py:245-317) --
         nc = mesh.ncells
-        G = np.zeros((nc, n**3, 6), dtype=ft)
-        detJ = np.zeros((nc, n**3), dtype=ft)
-        compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), nc, dphi_g, w3)
-        compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), nc, dphi_g, w3)
         bd1 = mesh.boundary_facets([2])  # x = 0: source
         bd2 = mesh.boundary_facets([3])  # x = L: absorbing
-        w2 = tensor_weights_2d(wts).astype(ft)
-        dphi_f = tabulate_facet_gradients(pts, ft)
-        dF1 = np.zeros((bd1.shape[0], n * n), dtype=ft)
-        dF2 = np.zeros((bd2.shape[0], n * n), dtype=ft)
-        compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dphi_f, w2)
-        compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dphi_f, w2)
+        D, G_d, detJ_d, (dF1_d, dF2_d) = device_geometry(mesh, P, ft, dev, (bd1, bd2))
+        self.D = D
         rho = np.full(nc, self.rho0, dtype=ft)
         c = np.full(nc, self.c0, dtype=ft)
         td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
@@ -103,8 +118,8 @@ class LinearSpectral3D:
         self.cell_coeff2 = td(-1.0 / rho)  # :337
         self.facet_coeff1 = td((1.0 / rho[bd1[:, 0]]).astype(ft))  # :339-341
         self.facet_coeff2 = td((-1.0 / rho[bd2[:, 0]] / c[bd2[:, 0]]).astype(ft))  # :343-345
-        self.G, self.detJ, self.dofmap = td(G), td(detJ), td(mesh.dofmap)
-        self.detJ_f1, self.detJ_f2 = td(dF1), td(dF2)
+        self.G, self.detJ, self.dofmap = G_d, detJ_d, td(mesh.dofmap)
+        self.detJ_f1, self.detJ_f2 = dF1_d, dF2_d
         self.fdm1, self.fdm2 = td(mesh.facet_dofmap(bd1)), td(mesh.facet_dofmap(bd2))
         self.nlocal, self.ndofs = mesh.nlocal, mesh.ndofs
 

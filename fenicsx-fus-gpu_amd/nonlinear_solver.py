@@ -20,13 +20,7 @@ from . import _lib
 from . import operators as ops
 from .gll import tabulate_1d, tensor_points_3d, tensor_weights_2d, tensor_weights_3d
 from .linear_solver import A_RUNGE, B_RUNGE, C_RUNGE
-from .precompute import (
-    compute_boundary_facets_scaled_jacobian_determinant,
-    compute_scaled_geometrical_factor,
-    compute_scaled_jacobian_determinant,
-    tabulate_facet_gradients,
-    tabulate_hex_p1_gradients,
-)
+from .linear_solver import device_geometry
 
 
 def compute_diffusivity_of_sound(frequency, speed, attenuationdB):
@@ -50,18 +44,9 @@ class WesterveltSpectral3D:
         self.source_time = source_time
         P, n = self.P, self.P + 1
         dev = torch.device("cuda", torch.cuda.current_device())
-        pts, wts, D = tabulate_1d(P, ft)
-        w3 = tensor_weights_3d(wts).astype(ft)
-        dg = tabulate_hex_p1_gradients(tensor_points_3d(pts), ft)
         nc = mesh.ncells
-        G, detJ = np.zeros((nc, n**3, 6), dtype=ft), np.zeros((nc, n**3), dtype=ft)
-        compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), nc, dg, w3)
-        compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), nc, dg, w3)
         bd1, bd2 = mesh.boundary_facets([2]), mesh.boundary_facets([3])
-        w2, dpf = tensor_weights_2d(wts).astype(ft), tabulate_facet_gradients(pts, ft)
-        dF1, dF2 = np.zeros((bd1.shape[0], n * n), dtype=ft), np.zeros((bd2.shape[0], n * n), dtype=ft)
-        compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dpf, w2)
-        compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dpf, w2)
+        D, G_d, detJ_d, (dF1_d, dF2_d) = device_geometry(mesh, P, ft, dev, (bd1, bd2))
         rho, c = np.full(nc, self.rho0), np.full(nc, self.c0)
         beta, delta = np.full(nc, self.beta), np.full(nc, self.delta)
         td = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=ft))).to(dev)  # noqa: E731
@@ -76,9 +61,9 @@ class WesterveltSpectral3D:
         self.fc2_1 = td(delta[c1] / rho[c1] / c[c1] ** 2)
         self.fc1_2 = td(delta[c2] / rho[c2] / c[c2] ** 3)
         self.fc2_2 = td(-1.0 / rho[c2] / c[c2])
-        self.G, self.detJ = td(G), td(detJ)
+        self.G, self.detJ = G_d, detJ_d
         self.dofmap = torch.from_numpy(mesh.dofmap).to(dev)
-        self.dF1, self.dF2 = td(dF1), td(dF2)
+        self.dF1, self.dF2 = dF1_d, dF2_d
         self.fdm1 = torch.from_numpy(mesh.facet_dofmap(bd1)).to(dev)
         self.fdm2 = torch.from_numpy(mesh.facet_dofmap(bd2)).to(dev)
         self.nlocal, self.ndofs = mesh.nlocal, mesh.ndofs

@@ -172,3 +172,56 @@ def compute_boundary_facets_scaled_jacobian_determinant(detJ_f, mesh, boundary_d
         Jf = np.einsum("mqad,at->mqdt", J, R)
         cr = np.cross(Jf[..., 0], Jf[..., 1])
         detJ_f[sel, :] = (np.linalg.norm(cr, axis=-1) * w[None, :]).astype(detJ_f.dtype)
+
+
+# ---------------------------------------------------------------------------------------------
+# Device versions (csrc/geometry.hpp): same argument order, all arrays device arrays.
+def _dev_args(mesh, dphi, weights, out):
+    import torch
+
+    from . import _lib
+
+    x_dofs, x_g = mesh
+    dt = out.dtype
+    for name, t, d in (("x_g", x_g, dt), ("dphi", dphi, dt), ("weights", weights, dt), ("x_dofs", x_dofs, torch.int32)):
+        _lib.require_device_tensor(t, d, name)
+    _lib.require_device_tensor(out, dt, "out")
+    return _lib.load(), _lib.suffix(dt), x_dofs, x_g
+
+
+def compute_scaled_geometrical_factor_device(G, mesh, num_cell, dphi, weights, detJ=None):
+    """Device twin of ``compute_scaled_geometrical_factor`` (optionally also fills ``detJ``)."""
+    from . import _lib
+
+    lib, suf, x_dofs, x_g = _dev_args(mesh, dphi, weights, G)
+    nq = weights.numel()
+    _lib.check(
+        getattr(lib, f"fus_geometry_factors_{suf}")(
+            x_g.data_ptr(), x_dofs.data_ptr(), dphi.data_ptr(), weights.data_ptr(), nq, int(num_cell), G.data_ptr(),
+            detJ.data_ptr() if detJ is not None else None, _lib.stream_ptr()),
+        "fus_geometry_factors")
+
+
+def compute_scaled_jacobian_determinant_device(detJ, mesh, num_cell, dphi, weights):
+    from . import _lib
+
+    lib, suf, x_dofs, x_g = _dev_args(mesh, dphi, weights, detJ)
+    _lib.check(
+        getattr(lib, f"fus_geometry_factors_{suf}")(
+            x_g.data_ptr(), x_dofs.data_ptr(), dphi.data_ptr(), weights.data_ptr(), weights.numel(), int(num_cell),
+            None, detJ.data_ptr(), _lib.stream_ptr()),
+        "fus_geometry_factors")
+
+
+def compute_boundary_facets_scaled_jacobian_determinant_device(detJ_f, mesh, boundary_data, dphi_f, weights):
+    import torch
+
+    from . import _lib
+
+    lib, suf, x_dofs, x_g = _dev_args(mesh, dphi_f, weights, detJ_f)
+    _lib.require_device_tensor(boundary_data, torch.int32, "boundary_data")
+    _lib.check(
+        getattr(lib, f"fus_facet_jacobian_{suf}")(
+            x_g.data_ptr(), x_dofs.data_ptr(), boundary_data.data_ptr(), dphi_f.data_ptr(), weights.data_ptr(),
+            weights.numel(), int(boundary_data.shape[0]), detJ_f.data_ptr(), _lib.stream_ptr()),
+        "fus_facet_jacobian")

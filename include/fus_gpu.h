@@ -125,6 +125,24 @@ int fus_square_f64(const double* a, double* b, int64_t n, void* stream);        
 int fus_square_f32(const float* a, float* b, int64_t n, void* stream);
 
 /*
+ * Geometry precompute on the device, same inputs / conventions / outputs as the reference's host
+ * routines (numba-cpu/precompute.py:76-163 and :17-73):
+ *   x_g T[nvert][3], x_dofs int32[ncell][8] (P1 hex), dphi T[3][nq][8], weights T[nq]
+ *   -> G T[ncell][nq][6] and/or detJ T[ncell][nq]   (either may be NULL)
+ *   boundary_data int32[nfacets][2] = (cell, local facet), dphi_f T[6][3][nqf][8], weights T[nqf]
+ *   -> detJ_f T[nfacets][nqf]
+ */
+int fus_geometry_factors_f64(const double* x_g, const int32_t* x_dofs, const double* dphi, const double* weights,
+                             int nq, int64_t ncell, double* G, double* detJ, void* stream);
+int fus_geometry_factors_f32(const float* x_g, const int32_t* x_dofs, const float* dphi, const float* weights, int nq,
+                             int64_t ncell, float* G, float* detJ, void* stream);
+int fus_facet_jacobian_f64(const double* x_g, const int32_t* x_dofs, const int32_t* boundary_data,
+                           const double* dphi_f, const double* weights, int nqf, int64_t nfacets, double* detJ_f,
+                           void* stream);
+int fus_facet_jacobian_f32(const float* x_g, const int32_t* x_dofs, const int32_t* boundary_data, const float* dphi_f,
+                           const float* weights, int nqf, int64_t nfacets, float* detJ_f, void* stream);
+
+/*
  * Fused RK4 stage update: everything the reference does between scatter_rev(b) of one stage and
  * scatter_fwd of the next (cuda/demo_linear_box.py:556-563 then :491-508,541 -- 12 launches, 216
  * B/dof) in one pass:

@@ -288,3 +288,26 @@ def test_planned_kernel_builds(gpu, oracle_c, P, pv):
         _check(y.copy_to_host(), y_ref, np.float64, f"planned build {pv} P={P}")
     finally:
         lib.set_tuning(lib.TUNE_PLAN_VARIANT, old)
+
+
+@pytest.mark.parametrize("path", golden_files("ops_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_device_precompute_vs_reference(gpu, path):
+    """Device geometry kernels against what the reference's own precompute.py produced."""
+    dev, _ = gpu
+    pre = pkg("precompute")
+    d = np.load(path)
+    dt = d["x"].dtype
+    tol = 1e-13 if dt == np.float64 else 5e-6
+    nc = d["dofmap"].shape[0]
+    mesh = (dev.to_device(d["x_dofs"]), dev.to_device(d["x_g"]))
+    G, detJ = dev.device_array(d["ref_G"].shape, dt), dev.device_array(d["ref_detJ"].shape, dt)
+    pre.compute_scaled_geometrical_factor_device(G, mesh, nc, dev.to_device(d["dphi_geom"]), dev.to_device(d["wts3"]), detJ=detJ)
+    assert rel_l2(G.copy_to_host(), d["ref_G"]) < tol
+    assert rel_l2(detJ.copy_to_host(), d["ref_detJ"]) < tol
+    detJ2 = dev.device_array(d["ref_detJ"].shape, dt)
+    pre.compute_scaled_jacobian_determinant_device(detJ2, mesh, nc, dev.to_device(d["dphi_geom"]), dev.to_device(d["wts3"]))
+    assert rel_l2(detJ2.copy_to_host(), d["ref_detJ"]) < tol
+    dF = dev.device_array(d["ref_detJ_f"].shape, dt)
+    pre.compute_boundary_facets_scaled_jacobian_determinant_device(
+        dF, mesh, dev.to_device(d["boundary_data"].astype(np.int32)), dev.to_device(d["dphi_facet"]), dev.to_device(d["wts2"]))
+    assert rel_l2(dF.copy_to_host(), d["ref_detJ_f"]) < tol
