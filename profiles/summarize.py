@@ -20,7 +20,7 @@ src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
 counters = {}
-for sub, name in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_tcc", "tcc")):
+for sub, name in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_tcc", "tcc"), ("pmc_sq", "sq")):
     p = os.path.join(src, sub, f"{name}_counter_collection.csv")
     if not os.path.exists(p):
         continue
@@ -50,6 +50,11 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
               open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
 if "TCC_EA0_ATOMIC_sum" in counters and stats:
     res["atomic_requests_per_s"] = counters["TCC_EA0_ATOMIC_sum"]["mean_per_launch"] / (stats["avg_ns"] * 1e-9)
+if "SQ_LDS_BANK_CONFLICT" in counters and "SQ_LDS_IDX_ACTIVE" in counters:
+    res["lds_bank_conflict_fraction"] = counters["SQ_LDS_BANK_CONFLICT"]["mean_per_launch"] / max(counters["SQ_LDS_IDX_ACTIVE"]["mean_per_launch"], 1.0)
+if "SQ_WAVE_CYCLES" in counters and "SQ_WAIT_ANY" in counters:
+    wc = counters["SQ_WAVE_CYCLES"]["mean_per_launch"]
+    res["wave_cycle_shares"] = {k: counters[k]["mean_per_launch"] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in counters}
 json.dump(res, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
 json.dump(bench, open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))
