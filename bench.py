@@ -202,8 +202,13 @@ def main():
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    force_dist = os.environ.get("FUS_BENCH_FORCE_DIST", "0") == "1"  # exercise the N > 1 code path in a 1-rank world
+    use_dist = world > 1 or force_dist
+    if use_dist:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("MASTER_PORT", "29511")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         opts = None
         try:  # comm kernels must get CUs while a chip-filling operator kernel runs
             opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
@@ -261,7 +266,7 @@ def main():
     op = ops.stiffness_operator(P, D.flatten(), dt)
 
     halo = None
-    if world > 1:
+    if use_dist:
         scat = fusgpu_loader.submodule("scatterer")
         halo = scat.HaloApply(mesh, op, scat.TorchComm(), dt, overlap=os.environ.get("FUS_HALO_OVERLAP", "1") != "0")
 
@@ -276,7 +281,7 @@ def main():
     y_d.zero_()
     ev0 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
     ev1 = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps)]
-    if world > 1:
+    if use_dist:
         dist.barrier()
     torch.cuda.synchronize()
     t_start = time.perf_counter()
@@ -285,10 +290,10 @@ def main():
         step()
         ev1[i].record()
     torch.cuda.synchronize()
-    if world > 1:
+    if use_dist:
         dist.barrier()
     elapsed = time.perf_counter() - t_start
-    if world > 1:
+    if use_dist:
         tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
@@ -370,7 +375,7 @@ def main():
         else:
             out["cpu_baseline"] = None
         print(json.dumps(out), flush=True)
-    if world > 1:
+    if use_dist:
         dist.destroy_process_group()
 
 
