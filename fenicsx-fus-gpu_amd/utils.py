@@ -81,6 +81,15 @@ def compute_scatterer_data_flat(index_map, comm=None):
     uo, osz, ooff, order = _owners_side(index_map)
     ug, gsz = _ghosting_ranks(index_map)
     goff = np.concatenate(([0], np.cumsum(gsz))).astype(np.int64)
+    if comm is None:
+        # the reference hard-codes MPI.COMM_WORLD (cuda/utils.py:62,68); the counterpart here is the
+        # default torch.distributed group, if one is up
+        import torch.distributed as dist
+
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            from .scatterer import TorchComm
+
+            comm = TorchComm()
     size = 1 if comm is None else comm.size
     if size == 1:
         if uo.size or ug.size:
@@ -125,3 +134,15 @@ def compute_scatterer_data(index_map, comm=None):
     """cuda/utils.py:8-78 call surface (3-element list format)."""
     od, gd = compute_scatterer_data_flat(index_map, comm)
     return to_lists(od), to_lists(gd)
+
+
+def boundary_first_cell_order(dofmap, nlocal):
+    """Permutation that lists the cells touching a ghost dof (index >= nlocal) first, keeping the
+    relative order inside both groups, and the number of such cells.  ``HaloApply`` needs
+    ``dofmap[perm]``, ``G[perm]``, ``detJ[perm]`` and ``cell_constants[perm]`` in this order so that
+    boundary / interior cell sets are contiguous sub-ranges; ``BoxMesh`` already provides it, a
+    dolfinx-built mesh applies this once at set-up."""
+    dm = np.asarray(dofmap)
+    touches = (dm >= nlocal).any(axis=1)
+    perm = np.concatenate((np.nonzero(touches)[0], np.nonzero(~touches)[0]))
+    return perm, int(touches.sum())

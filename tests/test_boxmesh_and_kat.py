@@ -127,3 +127,17 @@ def test_facet_tables():
     fd = m.facet_dofmap(m.boundary_facets([2]))
     # x = 0 face dofs have lexicographic x-index 0 -> global ids below (2P+1)^2
     assert fd.max() < 25
+
+
+def test_boundary_first_cell_order():
+    boxmesh, utils = pkg("boxmesh"), pkg("utils")
+    m = boxmesh.BoxMesh(2, (4, 4, 2), grid=(2, 2, 1), rank=3)
+    rng = np.random.default_rng(0)
+    shuffle = rng.permutation(m.ncells)
+    dm = m.dofmap[shuffle]
+    perm, nb = utils.boundary_first_cell_order(dm, m.nlocal)
+    assert nb == m.num_boundary_cells
+    d2 = dm[perm]
+    touches = (d2 >= m.nlocal).any(axis=1)
+    assert np.all(touches[:nb]) and not np.any(touches[nb:])
+    assert sorted(perm.tolist()) == list(range(m.ncells))
