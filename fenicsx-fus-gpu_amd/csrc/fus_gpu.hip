@@ -15,6 +15,7 @@
 #include "rk4.hpp"
 #include "stiffness.hpp"
 #include "vecops.hpp"
+#include "westervelt.hpp"
 
 namespace {
 
@@ -105,6 +106,28 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
       case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
     }                                                                                                     \
+    break;
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return hip_rc(e);
+}
+
+template <typename T>
+int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5, T* b, T* m, const T* G,
+                    const T* detJ, const void* ws, const T* dphi, int P, int64_t ncell, void* stream) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
+  if (ncell == 0) return FUS_OK;
+  if (!u || !v || !c2 || !c3 || !c4 || !c5 || !b || !m || !G || !detJ || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipErrorInvalidValue;
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    e = fus::launch_westervelt_cell<T, PP>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -339,6 +362,24 @@ FUS_VEC(float, f32)
 FUS_GEOM(double, f64)
 FUS_GEOM(float, f32)
 #undef FUS_GEOM
+
+#define FUS_WEST(T, SUF)                                                                                          \
+  int fus_westervelt_cell_apply_planned_##SUF(const T* u, const T* v, const T* c2, const T* c3, const T* c4,      \
+                                              const T* c5, T* b, T* m, const T* G, const T* detJ, const void* ws, \
+                                              const T* dphi, int P, int64_t ncell, void* s) {                     \
+    return westervelt_cell<T>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, P, ncell, s);                        \
+  }                                                                                                               \
+  int fus_rk4_stage_nl_##SUF(T bw, T aw, int new_step, const T* m0, T* m, T* b, T* u, T* v, T* u0, T* v0, T* ku,  \
+                             T* un, int64_t nlocal, int64_t ntotal, void* s) {                                    \
+    if (nlocal < 0 || ntotal < nlocal) return FUS_ERR_INVALID_ARGUMENT;                                           \
+    if (ntotal == 0) return FUS_OK;                                                                               \
+    if (!m0 || !m || !b || !u || !v || !u0 || !v0 || !ku || !un) return FUS_ERR_INVALID_ARGUMENT;                 \
+    return hip_rc(fus::launch_rk4_stage_nl<T>(bw, aw, new_step, m0, m, b, u, v, u0, v0, ku, un, nlocal, ntotal,   \
+                                              static_cast<hipStream_t>(s)));                                      \
+  }
+FUS_WEST(double, f64)
+FUS_WEST(float, f32)
+#undef FUS_WEST
 
 #define FUS_RK4(T, SUF)                                                                                        \
   int fus_rk4_stage_##SUF(T bw, T aw, int new_step, const T* minv, T* b, T* u, T* v, T* u0, T* v0, T* ku, T* un, \

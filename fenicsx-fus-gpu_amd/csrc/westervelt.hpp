@@ -1,0 +1,246 @@
+// Fused Westervelt cell kernel.
+//
+// Per RK4 stage the reference launches, over the SAME cells,
+//   mass(u_n, c2) -> m          cuda/demo_nonlinear_bowl.py:612-616   (solution-dependent lumped mass)
+//   stiffness(u_n, c3) -> b     :624-626
+//   stiffness(v_n, c4) -> b     :627-629
+//   mass(w_n = v_n^2, c5) -> b  :630-632  (+ square :603)
+// i.e. G is streamed twice, detJ twice, the dofmap four times, b scattered three times.
+// K is linear and the constants are per cell, so  c3 K u + c4 K v = K (c3 u + c4 v)  cell by cell,
+// and with GLL collocation the mass terms are pointwise in the cell; one pass does all four:
+//   b[dof] += [D^T G D (c3 u + c4 v)]_cell + detJ c5 v^2 ;   m[dof] += detJ c2 u
+// G and detJ are read once, u and v are gathered once (through the batch plan), b and m are
+// pre-reduced in LDS and flushed with one atomic per distinct dof each.
+// Same column-per-thread contraction structure as stiffness_plan_kernel (plan.hpp).
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "plan.hpp"
+
+namespace fus {
+
+template <typename T, int P, int CPB>
+__global__ void __launch_bounds__((col_block_threads<P, CPB>()))
+    westervelt_cell_kernel(const T* __restrict__ u_in, const T* __restrict__ v_in, const T* __restrict__ c2,
+                           const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
+                           T* __restrict__ b, T* __restrict__ m, const T* __restrict__ G, const T* __restrict__ detJ,
+                           const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
+                           const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell) {
+  constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
+  constexpr int S = lds_cell_stride<T, P>();
+  constexpr int BLOCK = col_block_threads<P, CPB>();
+  constexpr int M = CPB * Nd;
+  constexpr int SPT = (M + BLOCK - 1) / BLOCK;
+
+  // regions: su (combined input cube, later the b accumulator), sfy (u values, later flux y),
+  // sfz (v values, later flux z), sm (m accumulator)
+  __shared__ T sD[n2];
+  __shared__ T su[CPB * S];
+  __shared__ T sfy[CPB * S];
+  __shared__ T sfz[CPB * S];
+  __shared__ T sm[M];
+  T* const sxu = sfy;
+  T* const sxv = sfz;
+  T* const sb = su;
+
+  const int tid = threadIdx.x;
+  const unsigned batch = blockIdx.x;
+  const int lc = tid / n2;
+  const int t = tid - lc * n2;
+  const int ty = t / n, tz = t - ty * n;
+  const int64_t cell = (int64_t)batch * CPB + lc;
+  const bool active = (lc < CPB) && (cell < ncell);
+  const int nu_b = nu[batch];
+  const int32_t* ud = udofs + (int64_t)batch * M;
+
+  if (tid < n2) sD[tid] = dphi[tid];
+
+  int32_t mydof[SPT];
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    mydof[r] = ud[s < nu_b ? s : 0];
+  }
+  uint16_t sl[n];
+  T g[n][6];
+  T dj[n];
+  T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
+  if (active) {
+    const uint16_t* sp = slot + cell * Nd + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+    const T* Gc = G + (cell * Nd + t) * 6;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
+    const T* dc = detJ + cell * Nd + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) dj[ix] = dc[ix * n2];
+    k2 = c2[cell];
+    k3 = c3[cell];
+    k4 = c4[cell];
+    k5 = c5[cell];
+  }
+  T xu[SPT], xv[SPT];
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    xu[r] = u_in[mydof[r]];
+    xv[r] = v_in[mydof[r]];
+  }
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    if (s < nu_b) {
+      sxu[s] = xu[r];
+      sxv[s] = xv[r];
+      sm[s] = T(0);
+    }
+  }
+  __syncthreads();  // B1
+
+  T w[n];       // combined stiffness input  c3 u + c4 v
+  T bextra[n];  // detJ c5 v^2
+  if (active) {
+    T* cu = su + lc * S + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) {
+      const T uu = sxu[sl[ix]], vv = sxv[sl[ix]];
+      w[ix] = k3 * uu + k4 * vv;
+      bextra[ix] = dj[ix] * k5 * vv * vv;
+      lds_atomic_add(&sm[sl[ix]], dj[ix] * k2 * uu);
+      cu[ix * n2] = w[ix];
+    }
+  }
+  __syncthreads();  // B2: u / v values are dead, the flux cubes may be written
+
+  T fx[n];
+  if (active) {
+    T dy[n], dz[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      dy[i] = sD[ty * n + i];
+      dz[i] = sD[tz * n + i];
+    }
+    const T* cu_y = su + lc * S + tz;
+    const T* cu_z = su + lc * S + ty * n;
+    T* cfy = sfy + lc * S + t;
+    T* cfz = sfz + lc * S + t;
+#pragma unroll
+    for (int qx = 0; qx < n; ++qx) {
+      T vx = T(0);
+#pragma unroll
+      for (int ix = 0; ix < n; ++ix) vx += dphi[qx * n + ix] * w[ix];
+      T vy = T(0), vz = T(0);
+#pragma unroll
+      for (int i = 0; i < n; ++i) {
+        vy += dy[i] * cu_y[qx * n2 + i * n];
+        vz += dz[i] * cu_z[qx * n2 + i];
+      }
+      const T* gq = g[qx];
+      fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
+      cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
+      cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
+    }
+  }
+  __syncthreads();  // B3: the input cube is dead: it becomes the b accumulator
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    if (s < nu_b) sb[s] = T(0);
+  }
+  __syncthreads();  // B3.5
+
+  if (active) {
+    T dyT[n], dzT[n];
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      dyT[q] = sD[q * n + ty];
+      dzT[q] = sD[q * n + tz];
+    }
+    const T* cf_y = sfy + lc * S + tz;
+    const T* cf_z = sfz + lc * S + ty * n;
+#pragma unroll
+    for (int jx = 0; jx < n; ++jx) {
+      T acc = bextra[jx];
+#pragma unroll
+      for (int qx = 0; qx < n; ++qx) acc += dphi[qx * n + jx] * fx[qx];
+#pragma unroll
+      for (int q = 0; q < n; ++q) {
+        acc += dyT[q] * cf_y[jx * n2 + q * n];
+        acc += dzT[q] * cf_z[jx * n2 + q];
+      }
+      lds_atomic_add(&sb[sl[jx]], acc);
+    }
+  }
+  __syncthreads();  // B4
+
+#pragma unroll
+  for (int r = 0; r < SPT; ++r) {
+    const int s = tid + r * BLOCK;
+    if (s < nu_b) {
+      unsafeAtomicAdd(b + mydof[r], sb[s]);
+      unsafeAtomicAdd(m + mydof[r], sm[s]);
+    }
+  }
+}
+
+template <typename T, int P>
+inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5,
+                                         T* b, T* m, const T* G, const T* detJ, const void* workspace, const T* dphi,
+                                         int64_t ncell, hipStream_t stream) {
+  constexpr int CPB = plan_cells_per_batch<P>();
+  if (ncell <= 0) return hipSuccess;
+  PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
+  constexpr int threads = col_block_threads<P, CPB>();
+  hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u, v, c2,
+                     c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell);
+  return hipGetLastError();
+}
+
+// Fused RK4 stage vector kernel of the Westervelt solver: as rk4_stage_kernel (rk4.hpp) but the
+// lumped mass changes every stage, so kv = b / m and m is reset to its steady part m0.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    rk4_stage_nl_kernel(T bw, T aw, int new_step, const T* __restrict__ m0, T* __restrict__ m, T* __restrict__ b,
+                        T* __restrict__ u, T* __restrict__ v, T* __restrict__ u0, T* __restrict__ v0,
+                        T* __restrict__ ku, T* __restrict__ un, int64_t nlocal, int64_t ntotal) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntotal; i += stride) {
+    if (i < nlocal) {
+      const T kv = b[i] / m[i];
+      const T kui = ku[i];
+      const T ui = u[i] + bw * kui;
+      const T vi = v[i] + bw * kv;
+      u[i] = ui;
+      v[i] = vi;
+      T u0i, v0i;
+      if (new_step) {
+        u0i = ui;
+        v0i = vi;
+        u0[i] = ui;
+        v0[i] = vi;
+      } else {
+        u0i = u0[i];
+        v0i = v0[i];
+      }
+      un[i] = u0i + aw * kui;
+      ku[i] = v0i + aw * kv;
+    }
+    m[i] = m0[i];  // ghost entries too: they receive this rank's partial sums next stage
+    b[i] = T(0);
+  }
+}
+
+template <typename T>
+inline hipError_t launch_rk4_stage_nl(T bw, T aw, int new_step, const T* m0, T* m, T* b, T* u, T* v, T* u0, T* v0,
+                                      T* ku, T* un, int64_t nlocal, int64_t ntotal, hipStream_t stream) {
+  if (ntotal <= 0) return hipSuccess;
+  int64_t nblocks = (ntotal + 255) / 256;
+  if (nblocks > 4096) nblocks = 4096;
+  hipLaunchKernelGGL((rk4_stage_nl_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, new_step, m0, m,
+                     b, u, v, u0, v0, ku, un, nlocal, ntotal);
+  return hipGetLastError();
+}
+
+}  // namespace fus

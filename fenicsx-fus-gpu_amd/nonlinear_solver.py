@@ -32,7 +32,7 @@ def compute_diffusivity_of_sound(frequency, speed, attenuationdB):
 class WesterveltSpectral3D:
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
                  source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
-                 attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True):
+                 attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False):
         self.mesh, self.P = mesh, mesh.P
         ft = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(ft)
@@ -42,6 +42,7 @@ class WesterveltSpectral3D:
         self.beta = float(nonlinear_coefficient)
         self.delta = compute_diffusivity_of_sound(self.w0, self.c0, attenuation_coefficient_dB)
         self.source_time = source_time
+        self.fused = bool(fused)
         P, n = self.P, self.P + 1
         dev = torch.device("cuda", torch.cuda.current_device())
         nc = mesh.ncells
@@ -78,6 +79,9 @@ class WesterveltSpectral3D:
             self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap)
             mk = lambda: scatter_forward(comm, self.halo.owners_data, self.halo.ghosts_data, mesh.nlocal, ft)  # noqa: E731
             self.fwd_u, self.fwd_v, self.fwd_w = self.halo.fwd, mk(), mk()
+            from .scatterer import scatter_reverse
+
+            self.rev_m = scatter_reverse(comm, self.halo.owners_data, self.halo.ghosts_data, mesh.nlocal, ft)
         z = lambda: torch.zeros(self.ndofs, dtype=self.tdt, device=dev)  # noqa: E731
         (self.u, self.v, self.u0, self.v0, self.un, self.vn, self.ku, self.kv, self.u_n, self.v_n, self.w_n,
          self.g, self.dg, self.b, self.m, self.m0) = (z() for _ in range(16))
@@ -88,9 +92,44 @@ class WesterveltSpectral3D:
         if self.halo is not None:
             self.halo.rev(self.m0)
 
+        self.cell_fused = ops.westervelt_cell_operator(P, D.flatten(), ft)
+        self.fc_src = torch.zeros_like(self.fc1_1)  # per-stage source-facet constants (fused mode)
+
     def init(self):
         for t in (self.u, self.v, self.ku, self.kv):
             ops.fill(0.0, t)
+
+    # -- fused stage: one cell pass + one vector pass ------------------------------------------------
+    def _stage_vector_kernel(self, bw, aw, new_step):
+        fn = getattr(_lib.load(), f"fus_rk4_stage_nl_{_lib.suffix(self.tdt)}")
+        _lib.check(
+            fn(float(bw), float(aw), int(new_step), self.m0.data_ptr(), self.m.data_ptr(), self.b.data_ptr(),
+               self.u.data_ptr(), self.v.data_ptr(), self.u0.data_ptr(), self.v0.data_ptr(), self.ku.data_ptr(),
+               self.un.data_ptr(), self.nlocal, self.ndofs, _lib.stream_ptr()),
+            "fus_rk4_stage_nl",
+        )
+
+    def _operator_fused(self, ts):
+        gv, dgv = self.source_values(ts)
+        ops.fill(0.0, self.fc_src)
+        if self.fc_src.numel():
+            ops.axpy[1, 1](gv, self.fc1_1, self.fc_src)   # M_f1(fc1_1) g + M_f1(fc2_1) dg
+            ops.axpy[1, 1](dgv, self.fc2_1, self.fc_src)  #   = M_f1(fc1_1 g + fc2_1 dg) 1
+
+        def cells(c2, c3, c4, c5, G_, dJ_, dm_):
+            self.cell_fused(self.un, self.ku, c2, c3, c4, c5, self.b, self.m, G_, dJ_, dm_)  # ku == v_n
+
+        def facets():
+            self.mass_facet(self.g, self.fc_src, self.b, self.dF1, self.fdm1)  # g == 1
+            self.mass_facet(self.ku, self.fc2_2, self.b, self.dF2, self.fdm2)
+
+        percell = (self.cc2, self.cc3, self.cc4, self.cc5, self.G, self.detJ, self.dofmap)
+        if self.halo is None:
+            cells(*percell)
+            facets()
+        else:
+            self.halo.run(cells, percell, [(self.fwd_u, self.un), (self.fwd_v, self.ku)],
+                          [(self.halo.rev, self.b), (self.rev_m, self.m)], facets)
 
     def source_values(self, t):
         """g and dg/dt (cuda/demo_nonlinear_bowl.py:560-595)."""
@@ -145,12 +184,24 @@ class WesterveltSpectral3D:
 
     def rk4(self, start_time, final_time, dt, max_steps=None):
         t, step, tf = float(start_time), 0, float(final_time)
+        if self.fused:
+            ops.fill(1.0, self.g)  # source enters through scaled facet constants
+            ops.fill(0.0, self.b)
+            ops.copy(self.m0, self.m)
+            self._stage_vector_kernel(0.0, 0.0, 1)  # u0 = u, v0 = v, un = u, ku = v, b = 0, m = m0
         while t < tf and (max_steps is None or step < max_steps):
             dt = min(dt, tf - t)
-            ops.copy(self.u, self.u0)
-            ops.copy(self.v, self.v0)
-            for i in range(4):
-                self._stage(i, t, dt)
+            if self.fused:
+                for i in range(4):
+                    tn = t + C_RUNGE[i] * dt
+                    self._operator_fused(tn if self.source_time == "tn" else t)
+                    last = i == 3
+                    self._stage_vector_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 1 if last else 0)
+            else:
+                ops.copy(self.u, self.u0)
+                ops.copy(self.v, self.v0)
+                for i in range(4):
+                    self._stage(i, t, dt)
             t += dt
             step += 1
         return t, step

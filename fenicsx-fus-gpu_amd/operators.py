@@ -231,6 +231,44 @@ def stiffness_operator(P, *args):
     raise TypeError("stiffness_operator(P, dphi, float_type) or stiffness_operator(P, float_type)")
 
 
+class _WesterveltCellOperator:
+    """Fused Westervelt cell pass (csrc/westervelt.hpp): ``b += K(c3) u + K(c4) v + M(c5) v^2`` and
+    ``m += M(c2) u`` in one sweep over the cells -- the four cell launches of
+    cuda/demo_nonlinear_bowl.py:612-632 (+ square :603).  No reference counterpart as a single call."""
+
+    def __init__(self, P, dphi, float_type):
+        self._st = _StiffnessOperator(P, float_type, dphi)  # reuses table conversion + checks
+        self.P, self.n, self.dtype = self._st.P, self._st.n, self._st.dtype
+        self._fn = getattr(_lib.load(), f"fus_westervelt_cell_apply_planned_{_lib.suffix(self.dtype)}")
+
+    def __call__(self, u, v, c2, c3, c4, c5, b, m, G, detJ, dofmap):
+        dt = self.dtype
+        for name, t in (("u", u), ("v", v), ("c2", c2), ("c3", c3), ("c4", c4), ("c5", c5), ("b", b), ("m", m),
+                        ("G", G), ("detJ", detJ)):
+            _req(t, dt, name)
+        _req(dofmap, torch.int32, "dofmap")
+        nd = self.n**3
+        ncell = dofmap.shape[0]
+        if dofmap.dim() != 2 or dofmap.shape[1] != nd or G.numel() != ncell * nd * 6 or detJ.numel() != ncell * nd:
+            raise ValueError(f"dofmap [ncell, {nd}], G [ncell, {nd}, 6], detJ [ncell, {nd}] expected")
+        for name, t in (("c2", c2), ("c3", c3), ("c4", c4), ("c5", c5)):
+            if t.numel() != ncell:
+                raise ValueError(f"{name} must have one value per cell")
+        if ncell == 0:
+            return
+        ws, _ = _PLANS.get(dofmap)
+        _lib.check(
+            self._fn(u.data_ptr(), v.data_ptr(), c2.data_ptr(), c3.data_ptr(), c4.data_ptr(), c5.data_ptr(),
+                     b.data_ptr(), m.data_ptr(), G.data_ptr(), detJ.data_ptr(), ws.data_ptr(),
+                     self._st._dphi.data_ptr(), self.P, int(ncell), _lib.stream_ptr()),
+            "fus_westervelt_cell_apply_planned",
+        )
+
+
+def westervelt_cell_operator(P, dphi, float_type):
+    return _WesterveltCellOperator(P, dphi, float_type)
+
+
 # -------------------------------------------------------------------- vector ops
 def _vec(name, *tensors):
     dt = tensors[0].dtype if isinstance(tensors[0], torch.Tensor) else None

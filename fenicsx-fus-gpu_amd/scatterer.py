@@ -198,57 +198,63 @@ class HaloApply:
         nb, nc = mesh.num_boundary_cells, mesh.ncells
         mid = nb + (nc - nb) // 2
         self.ranges = {"boundary": (0, nb), "interior1": (nb, mid), "interior2": (mid, nc)}
-        self._views = {}
+        self._views_cache = {}
         self._apply_fn = apply_fn  # tests: CPU stand-in for the operator
 
-    def _sub(self, name, cc, G, dofmap):
-        key = (name, cc.data_ptr(), G.data_ptr(), dofmap.data_ptr())
-        v = self._views.get(key)
+    def _views(self, name, percell):
+        key = (name,) + tuple(t.data_ptr() for t in percell)
+        v = self._views_cache.get(key)
         if v is None:
             a, b = self.ranges[name]
-            v = (cc[a:b], G[a:b], dofmap[a:b])  # views are kept so the operator's plan cache hits
-            self._views[key] = v
+            v = tuple(t[a:b] for t in percell)  # views are kept so the operators' plan cache hits
+            self._views_cache[key] = v
         return v
 
-    def _apply(self, name, x, cc, y, G, dofmap):
-        a, b = self.ranges[name]
-        if b <= a:
-            return
-        c_, G_, d_ = self._sub(name, cc, G, dofmap)
-        if self._apply_fn is not None:
-            self._apply_fn(x, c_, y, G_, d_)
-        else:
-            self.op(x, c_, y, G_, d_)
+    def run(self, cell_fn, percell, forward, reverse, boundary_terms=None):
+        """Generic overlapped stage.  ``cell_fn(*views)`` applies the cell operator(s) to one
+        contiguous sub-range of cells, given views of the per-cell tensors ``percell`` (constants,
+        G, detJ, dofmap, ...).  ``forward`` / ``reverse``: lists of ``(scatter closure, vector)``.
+        ``boundary_terms()`` adds boundary-facet contributions; it runs after every forward scatter
+        has landed and before the reverse scatters are posted (facet dofs can be ghosts)."""
+        def part(name):
+            a, b = self.ranges[name]
+            if b > a:
+                cell_fn(*self._views(name, percell))
 
-    def apply(self, x, cell_constants, y, G, dofmap, extra_forward=(), boundary_terms=None):
-        """``extra_forward``: further ``(scatter_forward closure, vector)`` pairs to refresh
-        alongside x (e.g. v_n of the RK stage); ``boundary_terms()``: callable adding the
-        boundary-facet contributions to y -- it runs after every forward scatter has landed
-        and before the reverse scatter is posted (facet dofs can be ghosts)."""
         if not self.overlap:
-            self.fwd(x)
-            for sc, vec in extra_forward:
+            for sc, vec in forward:
                 sc(vec)
             for name in ("boundary", "interior1", "interior2"):
-                self._apply(name, x, cell_constants, y, G, dofmap)
+                part(name)
             if boundary_terms is not None:
                 boundary_terms()
-            self.rev(y)
+            for sc, vec in reverse:
+                sc(vec)
             return
-        w = self.fwd.begin(x)
-        extra = [(sc, vec, sc.begin(vec)) for sc, vec in extra_forward]
-        self._apply("interior1", x, cell_constants, y, G, dofmap)
-        self.fwd.end(x, w)
-        for sc, vec, wk in extra:
+        fw = [(sc, vec, sc.begin(vec)) for sc, vec in forward]
+        part("interior1")
+        for sc, vec, wk in fw:
             sc.end(vec, wk)
-        self._apply("boundary", x, cell_constants, y, G, dofmap)
+        part("boundary")
         if boundary_terms is not None:
             boundary_terms()
-        w = self.rev.begin(y)
-        self._apply("interior2", x, cell_constants, y, G, dofmap)
-        self.rev.end(y, w)
+        rv = [(sc, vec, sc.begin(vec)) for sc, vec in reverse]
+        part("interior2")
+        for sc, vec, wk in rv:
+            sc.end(vec, wk)
+
+    def apply(self, x, cell_constants, y, G, dofmap, extra_forward=(), boundary_terms=None):
+        """y += K x on the partitioned mesh (``extra_forward``: further ``(scatter_forward closure,
+        vector)`` pairs to refresh alongside x, e.g. v_n of the RK stage)."""
+        fn = self._apply_fn if self._apply_fn is not None else self.op
+        self.run(lambda c_, G_, d_: fn(x, c_, y, G_, d_), (cell_constants, G, dofmap),
+                 [(self.fwd, x)] + list(extra_forward), [(self.rev, y)], boundary_terms)
 
     def apply_local_only(self, x, cell_constants, y, G, dofmap):
         """The three kernel launches without any exchange (bench: kernel time at N > 1)."""
+        fn = self._apply_fn if self._apply_fn is not None else self.op
         for name in ("interior1", "boundary", "interior2"):
-            self._apply(name, x, cell_constants, y, G, dofmap)
+            a, b = self.ranges[name]
+            if b > a:
+                c_, G_, d_ = self._views(name, (cell_constants, G, dofmap))
+                fn(x, c_, y, G_, d_)

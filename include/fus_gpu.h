@@ -157,6 +157,27 @@ int fus_rk4_stage_f32(float bw, float aw, int new_step, const float* minv, float
                       float* v0, float* ku, float* un, int64_t nlocal, int64_t ntotal, void* stream);
 
 /*
+ * Fused Westervelt cell pass (needs the cell batch plan): what the reference does with four
+ * launches over the same cells per RK4 stage (cuda/demo_nonlinear_bowl.py:612-632 + square :603)
+ *   b += K(c3) u + K(c4) v + M(c5) v^2 ;   m += M(c2) u
+ * reading G and detJ once and gathering u, v once.  c2..c5: per-cell constants T[ncell].
+ * fus_rk4_stage_nl_*: fus_rk4_stage_* for a stage-dependent lumped mass: kv = b / m, then m = m0.
+ */
+int fus_westervelt_cell_apply_planned_f64(const double* u, const double* v, const double* c2, const double* c3,
+                                          const double* c4, const double* c5, double* b, double* m, const double* G,
+                                          const double* detJ, const void* workspace, const double* dphi, int P,
+                                          int64_t ncell, void* stream);
+int fus_westervelt_cell_apply_planned_f32(const float* u, const float* v, const float* c2, const float* c3,
+                                          const float* c4, const float* c5, float* b, float* m, const float* G,
+                                          const float* detJ, const void* workspace, const float* dphi, int P,
+                                          int64_t ncell, void* stream);
+int fus_rk4_stage_nl_f64(double bw, double aw, int new_step, const double* m0, double* m, double* b, double* u,
+                         double* v, double* u0, double* v0, double* ku, double* un, int64_t nlocal, int64_t ntotal,
+                         void* stream);
+int fus_rk4_stage_nl_f32(float bw, float aw, int new_step, const float* m0, float* m, float* b, float* u, float* v,
+                         float* u0, float* v0, float* ku, float* un, int64_t nlocal, int64_t ntotal, void* stream);
+
+/*
  * Halo pack / unpack (all neighbours in ONE launch: ``index`` is the concatenation of the
  * per-neighbour index lists, the send/recv buffer is the concatenation of the per-neighbour
  * messages).  N = nlocal (offset of the ghost block in a dof vector).
