@@ -311,3 +311,49 @@ def test_device_precompute_vs_reference(gpu, path):
     pre.compute_boundary_facets_scaled_jacobian_determinant_device(
         dF, mesh, dev.to_device(d["boundary_data"].astype(np.int32)), dev.to_device(d["dphi_facet"]), dev.to_device(d["wts2"]))
     assert rel_l2(dF.copy_to_host(), d["ref_detJ_f"]) < tol
+
+
+def test_full_size_config3(gpu, oracle_c):
+    """BASELINE config 3 at full size (P = 4, 54^3 perturbed cells, 10 218 313 dofs): the planned
+    and the plan-free kernel against the oracle (all host cores), plus size-independent
+    properties -- K 1 = 0, symmetry, linearity."""
+    import torch
+
+    dev, ops = gpu
+    boxmesh, gll, pre = pkg("boxmesh"), pkg("gll"), pkg("precompute")
+    P, N = 4, 54
+    mesh = boxmesh.BoxMesh(P, N, perturb=0.16, seed=0)
+    assert mesh.ndofs == 10218313 and mesh.ncells == 157464
+    pts, wts, D = gll.tabulate_1d(P)
+    gm = (dev.to_device(mesh.x_dofs), dev.to_device(mesh.x_g))
+    G = dev.device_array((mesh.ncells, 125, 6), np.float64)
+    pre.compute_scaled_geometrical_factor_device(
+        G, gm, mesh.ncells, dev.to_device(pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))),
+        dev.to_device(gll.tensor_weights_3d(wts)))
+    rng = np.random.default_rng(0)
+    x = rng.standard_normal(mesh.ndofs)
+    v = rng.standard_normal(mesh.ndofs)
+    cc = 1.0 + 0.25 * rng.standard_normal(mesh.ncells)
+    dm, cc_d = dev.to_device(mesh.dofmap), dev.to_device(cc)
+    op = ops.stiffness_operator(P, D.flatten(), np.float64)
+
+    def K(vec, plan=True):
+        ops.use_plan(plan)
+        try:
+            y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+            op(dev.to_device(vec), cc_d, y, G, dm)
+            return y.cpu().numpy()
+        finally:
+            ops.use_plan(True)
+
+    Kx = K(x)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, D, x, cc, y_ref, G.copy_to_host(), mesh.dofmap, threads=max(1, min(32, oracle_c.max_threads())))
+    _check(Kx, y_ref, np.float64, "planned kernel, full config 3")
+    _check(K(x, plan=False), y_ref, np.float64, "plan-free kernel, full config 3")
+    scale = np.max(np.abs(Kx))
+    assert np.max(np.abs(K(np.full(mesh.ndofs, 2.5)))) < 1e-9 * scale  # K const = 0
+    Kv = K(v)
+    a, b = float(v @ Kx), float(x @ Kv)
+    assert abs(a - b) < 1e-11 * max(abs(a), abs(b))  # symmetry
+    _check(K(2.0 * x - 3.0 * v), 2.0 * Kx - 3.0 * Kv, np.float64, "linearity")

@@ -17,6 +17,7 @@ def main():
     ap.add_argument("--cells", type=int, default=54)
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--westervelt", action="store_true")
     a = ap.parse_args()
     import torch
 
@@ -29,8 +30,9 @@ def main():
     h = ls.time_step_parameters(mesh, a.degree, 1500.0, 0.5e6, L)
     dt, tf, nstep = ls.snap_time_step(h, a.degree, 1500.0, 0.5e6, L)
     print(f"P={a.degree} cells={mesh.ncells} dofs={mesh.ndofs} dt={dt:.3e} steps to final time={nstep}")
+    nls = fusgpu_loader.submodule("nonlinear_solver")
     for fused in (False, True):
-        s = ls.LinearSpectral3D(mesh, np.float64, fused=fused)
+        s = nls.WesterveltSpectral3D(mesh, np.float64, fused=fused) if a.westervelt else ls.LinearSpectral3D(mesh, np.float64, fused=fused)
         s.init()
         s.rk4(0.0, tf, dt, max_steps=3)
         torch.cuda.synchronize()
