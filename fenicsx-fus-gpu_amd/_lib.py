@@ -62,6 +62,7 @@ TUNE_STIFFNESS_VARIANT = 1
 TUNE_XCD_REMAP = 2
 TUNE_MASS_VARIANT = 3
 TUNE_PLAN_VARIANT = 4
+TUNE_PLAN_RUNS = 5
 
 _lib = None
 

@@ -22,6 +22,15 @@ namespace {
 std::atomic<int> g_stiffness_variant{0};
 std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab_variants.log)
 std::atomic<int> g_mass_variant{0};
+std::atomic<int> g_plan_runs{1};  // 0 never, 1 auto, 2 always
+
+// Run-length coded dof lists pay off where the index stream is a large share of the bytes
+// (P <= 3: +6 % at P = 2) and cost an extra barrier + LDS search elsewhere (P = 4 neutral,
+// P = 6 -12 %): profiles/r01d_ab_plan_runs.log.
+inline int plan_allow_runs(int ndof_per_entity) {
+  const int mode = g_plan_runs.load(std::memory_order_relaxed);
+  return mode == 2 ? 1 : (mode == 1 ? (ndof_per_entity <= 64) : 0);
+}
 std::atomic<int> g_plan_variant{-1};  // -1 = auto: LDS-aliased build for P >= 6 (profiles/r01c_ab_plan_builds.log)
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
@@ -209,6 +218,7 @@ int fus_set_tuning(int key, int value) {
     case FUS_TUNE_XCD_REMAP: g_xcd_remap = value ? 1 : 0; return FUS_OK;
     case FUS_TUNE_MASS_VARIANT: g_mass_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_VARIANT: g_plan_variant = value; return FUS_OK;
+    case FUS_TUNE_PLAN_RUNS: g_plan_runs = value; return FUS_OK;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -219,6 +229,7 @@ int fus_get_tuning(int key) {
     case FUS_TUNE_XCD_REMAP: return g_xcd_remap;
     case FUS_TUNE_MASS_VARIANT: return g_mass_variant;
     case FUS_TUNE_PLAN_VARIANT: return g_plan_variant;
+    case FUS_TUNE_PLAN_RUNS: return g_plan_runs;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -249,7 +260,7 @@ int fus_stiffness_plan_build(const int32_t* dofmap, int P, int64_t ncell, void* 
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_plan_build<PP>(dofmap, ncell, workspace, s); \
+    e = fus::launch_plan_build<PP>(dofmap, ncell, workspace, s, plan_allow_runs((PP + 1) * (PP + 1) * (PP + 1))); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -290,7 +301,7 @@ int fus_plan_build(const int32_t* dofmap, int N, int entities_per_batch, int64_t
   if (nent == 0) return FUS_OK;
   if (!dofmap) return FUS_ERR_INVALID_ARGUMENT;
   return hip_rc(fus::launch_plan_build_generic(dofmap, N, entities_per_batch, nent, workspace,
-                                               static_cast<hipStream_t>(stream)));
+                                               static_cast<hipStream_t>(stream), plan_allow_runs(N)));
 }
 
 int fus_mass_apply_planned_f64(const double* x, const double* c, double* y, const double* detJ, const void* ws, int N,

@@ -62,16 +62,14 @@ __global__ void __launch_bounds__(256)
   const int64_t ent0 = batch * epb;
   const int64_t left = nent - ent0;
   const int valid = (int)((left < epb ? left : epb) * N);
-  const int nu_b = nu[batch];
+  __shared__ int s_runs[2 * kPlanMaxRuns];
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
   const int64_t base = batch * (int64_t)M;
   const int32_t* ud = udofs + base;
 
   int32_t mydof[EPT];
-#pragma unroll
-  for (int r = 0; r < EPT; ++r) {
-    const int s = tid + r * 256;
-    mydof[r] = ud[s < nu_b ? s : 0];
-  }
+  const int rt = batch_dofs_issue<EPT, 256>(ud, nu_b, nr_b, tid, mydof);
   uint16_t sl[EPT];
   T w[EPT];
 #pragma unroll
@@ -82,6 +80,7 @@ __global__ void __launch_bounds__(256)
     const uint32_t e = __umulhi((uint32_t)ic, inv_n);  // ic / N
     w[r] = detJ[base + ic] * entity_constants[ent0 + e];
   }
+  batch_dofs_resolve<EPT, 256>(rt, nu_b, nr_b, tid, s_runs, mydof);
   T xv[EPT];
 #pragma unroll
   for (int r = 0; r < EPT; ++r) xv[r] = x[mydof[r]];

@@ -52,17 +52,15 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
   const int ty = t / n, tz = t - ty * n;
   const int64_t cell = (int64_t)batch * CPB + lc;
   const bool active = (lc < CPB) && (cell < ncell);
-  const int nu_b = nu[batch];
+  __shared__ int s_runs[2 * kPlanMaxRuns];
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
   const int32_t* ud = udofs + (int64_t)batch * M;
 
   if (tid < n2) sD[tid] = dphi[tid];
 
   int32_t mydof[SPT];
-#pragma unroll
-  for (int r = 0; r < SPT; ++r) {
-    const int s = tid + r * BLOCK;
-    mydof[r] = ud[s < nu_b ? s : 0];
-  }
+  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, nu_b, nr_b, tid, mydof);
   uint16_t sl[n];
   T g[n][6];
   T dj[n];
@@ -82,6 +80,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
     k4 = c4[cell];
     k5 = c5[cell];
   }
+  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
   T xu[SPT], xv[SPT];
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {

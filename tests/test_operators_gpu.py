@@ -268,9 +268,10 @@ def test_mass_planned_vs_oracle(gpu, oracle_c, plan_mode, P, dtype):
         ops._MASS_PLAN_MIN_ENTRIES = old
 
 
+@pytest.mark.parametrize("runs", [0, 2], ids=["rawplan", "runplan"])
 @pytest.mark.parametrize("pv", [0, 1, 2, 3])
 @pytest.mark.parametrize("P", [2, 4, 6])
-def test_planned_kernel_builds(gpu, oracle_c, P, pv):
+def test_planned_kernel_builds(gpu, oracle_c, P, pv, runs):
     """Every build of the planned stiffness kernel (LDS aliasing / padding / occupancy hints)."""
     dev, ops = gpu
     lib = pkg("_lib")
@@ -281,13 +282,28 @@ def test_planned_kernel_builds(gpu, oracle_c, P, pv):
     old = lib.get_tuning(lib.TUNE_PLAN_VARIANT)
     try:
         lib.set_tuning(lib.TUNE_PLAN_VARIANT, pv)
+        lib.set_tuning(lib.TUNE_PLAN_RUNS, runs)
+        ops._PLANS.clear()
         ops.use_plan(True)
         y = dev.to_device(np.zeros(mesh.ndofs))
         ops.stiffness_operator(P, pb["D"].flatten(), np.float64)(
             dev.to_device(pb["x"]), dev.to_device(pb["cc"]), y, dev.to_device(pb["G"]), dev.to_device(mesh.dofmap))
         _check(y.copy_to_host(), y_ref, np.float64, f"planned build {pv} P={P}")
+        # the planned mass kernel reads the same plan
+        y_ref = np.zeros(mesh.ndofs)
+        oracle_c.mass_apply(pb["x"], pb["cc"], y_ref, pb["detJ"], mesh.dofmap)
+        y = dev.to_device(np.zeros(mesh.ndofs))
+        old_min, ops._MASS_PLAN_MIN_ENTRIES = ops._MASS_PLAN_MIN_ENTRIES, 1
+        try:
+            ops.mass_operator((P + 1) ** 3, np.float64)(dev.to_device(pb["x"]), dev.to_device(pb["cc"]), y,
+                                                        dev.to_device(pb["detJ"]), dev.to_device(mesh.dofmap))
+        finally:
+            ops._MASS_PLAN_MIN_ENTRIES = old_min
+        _check(y.copy_to_host(), y_ref, np.float64, f"planned mass, runs={runs} P={P}")
     finally:
         lib.set_tuning(lib.TUNE_PLAN_VARIANT, old)
+        lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
+        ops._PLANS.clear()
 
 
 @pytest.mark.parametrize("path", golden_files("ops_"), ids=lambda p: p.split("/")[-1][:-4])

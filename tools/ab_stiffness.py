@@ -42,7 +42,17 @@ def main():
     dm = torch.from_numpy(mesh.dofmap).to(dev)
     y = torch.zeros(mesh.ndofs, dtype=x.dtype, device=dev)
     op = ops.stiffness_operator(a.degree, pb["D"].flatten(), dt)
-    cfgs = [tuple(-1 if v == "p" else int(v) for v in c.split(":")) for c in a.configs]
+    # "p" = planned (run-length plan), "r" = planned with a raw (uncompressed) plan
+    cfgs = [tuple({"p": -1, "r": -2}.get(v, None) if v in ("p", "r") else int(v) for v in c.split(":")) for c in a.configs]
+    dm_raw = dm.clone()  # a second dofmap array => its own cached plan, built with runs disabled
+    lib.set_tuning(lib.TUNE_PLAN_RUNS, 0)
+    ops.use_plan(True)
+    op(x, cc, y, G, dm_raw)
+    torch.cuda.synchronize()
+    lib.set_tuning(lib.TUNE_PLAN_RUNS, 2)  # "p" = run-length plan
+    op(x, cc, y, G, dm)
+    torch.cuda.synchronize()
+    lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
     times = {c: [] for c in cfgs}
     for rnd in range(a.rounds + 1):
         for c in cfgs:
@@ -55,10 +65,11 @@ def main():
                 lib.set_tuning(lib.TUNE_PLAN_VARIANT, 0)
             lib.set_tuning(lib.TUNE_XCD_REMAP, c[1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            op(x, cc, y, G, dm)
+            d_ = dm_raw if c[0] == -2 else dm
+            op(x, cc, y, G, d_)
             e0.record()
             for _ in range(a.reps):
-                op(x, cc, y, G, dm)
+                op(x, cc, y, G, d_)
             e1.record()
             torch.cuda.synchronize()
             if rnd > 0:
