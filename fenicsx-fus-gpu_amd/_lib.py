@@ -14,7 +14,8 @@ import numpy as np
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "csrc", "libfusgpu.so")
+# FUS_LIB_PATH: load another build of the same ABI (A/B runs of two builds on one device)
+LIB_PATH = os.environ.get("FUS_LIB_PATH") or os.path.join(_HERE, "csrc", "libfusgpu.so")
 
 _i64, _int, _vp = C.c_int64, C.c_int, C.c_void_p
 

@@ -113,6 +113,7 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
       case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
       case 2: e = fus::launch_stiffness_plan<T, PP, true, true, 3>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
       case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
+      case 4: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
     }                                                                                                     \
     break;

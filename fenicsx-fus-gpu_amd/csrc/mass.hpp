@@ -69,7 +69,7 @@ __global__ void __launch_bounds__(256)
   const int32_t* ud = udofs + base;
 
   int32_t mydof[EPT];
-  const int rt = batch_dofs_issue<EPT, 256>(ud, nu_b, nr_b, tid, mydof);
+  const int rt = batch_dofs_issue<EPT, 256>(ud, M, nr_b, tid, mydof);
   uint16_t sl[EPT];
   T w[EPT];
 #pragma unroll

@@ -169,6 +169,12 @@ __global__ void __launch_bounds__(256)
       sl[key & 0xffffu] = (uint16_t)(s - 1);
     }
   }
+  // raw lists: pad [nu, M) with the batch's first dof, so the apply kernels can issue their
+  // per-slot loads without first waiting for nu (entries beyond nu are loaded but never used)
+  if (!use_runs && valid > 0) {
+    const int32_t d0 = (int32_t)(uint32_t)(keys[0] >> 16);
+    for (int i = nu_b + tid; i < M; i += 256) ud[i] = d0;
+  }
 }
 
 constexpr int kPlanMaxEntries = 4096;  // per batch; slot ids are 16-bit, keys live in LDS
@@ -213,15 +219,15 @@ inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* 
 // Phase 1 (issue the global loads; call BEFORE the other HBM loads of the batch so that the x
 // gather, which depends on them, can be issued while those are still in flight):
 template <int SPT, int BLOCK>
-__device__ __forceinline__ int batch_dofs_issue(const int32_t* __restrict__ ud, int nu_b, int nr_b, int tid,
+__device__ __forceinline__ int batch_dofs_issue(const int32_t* __restrict__ ud, int M, int nr_b, int tid,
                                                 int32_t (&mydof)[SPT]) {
   static_assert(BLOCK >= 2 * kPlanMaxRuns, "one run-table word per thread");
   int rt = 0;
-  if (nr_b == 0) {  // raw list (branch-free loads: out-of-range slots re-read slot 0)
+  if (nr_b == 0) {  // raw list; the builder padded [nu, M) with a valid dof
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const int s = tid + r * BLOCK;
-      mydof[r] = ud[s < nu_b ? s : 0];
+      mydof[r] = ud[s < M ? s : 0];
     }
   } else {
     rt = ud[tid < 2 * nr_b ? tid : 0];
@@ -258,7 +264,7 @@ __device__ __forceinline__ void lds_atomic_add(T* p, T v) {
 
 // Planned stiffness apply: same contraction structure as stiffness_col_kernel (stiffness.hpp),
 // gather / scatter through the batch plan.
-template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW>
+template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, int GMODE = 0>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
@@ -297,7 +303,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 
   // ---- issue every HBM load of the batch up front ---------------------------------------------
   int32_t mydof[SPT];
-  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, nu_b, nr_b, tid, mydof);
+  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
   uint16_t sl[n];
   T g[n][6];
   T coeff = T(0);
@@ -305,9 +311,19 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const uint16_t* sp = slot + cell * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
-    const T* Gc = G + (cell * Nd + t) * 6;
+    if constexpr (GMODE == 1) {
+      // EXPERIMENT ONLY (tools/ab_stiffness.py): G pre-transposed to [cell][6][n^3], every load a
+      // fully coalesced 8-byte-per-lane access -- prices the AoS access shape, not a product path
+      const T* Gs = G + cell * Nd * 6 + t;
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
+      for (int ix = 0; ix < n; ++ix)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[ix][k] = Gs[(int64_t)k * Nd + ix * n2];
+    } else {
+      const T* Gc = G + (cell * Nd + t) * 6;
+#pragma unroll
+      for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
+    }
     coeff = cell_constants[cell];
   }
   batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
@@ -411,14 +427,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   }
 }
 
-template <typename T, int P, bool ALIAS, bool PADLDS, int MINW>
+template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, int GMODE = 0>
 inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
                                         const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
-  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW>), dim3((unsigned)v.nbatch), dim3(threads), 0,
+  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GMODE>), dim3((unsigned)v.nbatch), dim3(threads), 0,
                      stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap);
   return hipGetLastError();
 }

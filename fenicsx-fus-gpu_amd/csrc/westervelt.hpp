@@ -60,7 +60,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
   if (tid < n2) sD[tid] = dphi[tid];
 
   int32_t mydof[SPT];
-  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, nu_b, nr_b, tid, mydof);
+  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
   uint16_t sl[n];
   T g[n][6];
   T dj[n];
