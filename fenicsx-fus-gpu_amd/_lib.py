@@ -64,6 +64,7 @@ TUNE_XCD_REMAP = 2
 TUNE_MASS_VARIANT = 3
 TUNE_PLAN_VARIANT = 4
 TUNE_PLAN_RUNS = 5
+TUNE_PLAN_THREADS = 6
 
 _lib = None
 

@@ -12,6 +12,9 @@
 #include "halo.hpp"
 #include "mass.hpp"
 #include "plan.hpp"
+#ifdef FUS_EXPERIMENTS
+#include "experimental/plan_persistent.hpp"
+#endif
 #include "rk4.hpp"
 #include "stiffness.hpp"
 #include "vecops.hpp"
@@ -23,12 +26,14 @@ std::atomic<int> g_stiffness_variant{0};
 std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab_variants.log)
 std::atomic<int> g_mass_variant{0};
 std::atomic<int> g_plan_runs{1};  // 0 never, 1 auto, 2 always
+std::atomic<int> g_plan_threads{256};  // workgroup size the cell batches are cut for (256 or 128)
 
 // Run-length coded dof lists pay off where the index stream is a large share of the bytes
 // (P <= 3: +6 % at P = 2) and cost an extra barrier + LDS search elsewhere (P = 4 neutral,
 // P = 6 -12 %): profiles/r01d_ab_plan_runs.log.
 inline int plan_allow_runs(int ndof_per_entity) {
   const int mode = g_plan_runs.load(std::memory_order_relaxed);
+  if (g_plan_threads.load(std::memory_order_relaxed) < 256) return 0;  // 128-thread builds read raw plans only
   return mode == 2 ? 1 : (mode == 1 ? (ndof_per_entity <= 64) : 0);
 }
 std::atomic<int> g_plan_variant{-1};  // -1 = auto: LDS-aliased build for P >= 6 (profiles/r01c_ab_plan_builds.log)
@@ -93,6 +98,29 @@ int64_t plan_bytes(int P, int64_t ncell) {
   return FUS_ERR_UNSUPPORTED_DEGREE;
 }
 
+// Experimental builds of the planned kernel (layout / ablation / persistent studies recorded in
+// profiles/r01d_*.log); compiled only with -DFUS_EXPERIMENTS (make EXPERIMENTS=1), selected with
+// FUS_TUNE_PLAN_VARIANT by tools/ab_stiffness.py.
+#ifdef FUS_EXPERIMENTS
+#define FUS_EXPERIMENT_CASES(PP) \
+      case 4: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 5: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 2>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 6: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 7: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 8>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 8: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 6>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 9: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 14>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 12: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 16>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 13: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 16>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 20: e = fus::launch_stiffness_plan_persistent<T, PP, false, 3>(x, cc, y, G, ws, dphi, ncell, 3, s); break; \
+      case 21: e = fus::launch_stiffness_plan_persistent<T, PP, true, 4>(x, cc, y, G, ws, dphi, ncell, 4, s); break;  \
+      case 22: e = fus::launch_stiffness_plan_persistent<T, PP, true, 3>(x, cc, y, G, ws, dphi, ncell, 3, s); break;  \
+      case 23: e = fus::launch_stiffness_plan_persistent<T, PP, false, 1>(x, cc, y, G, ws, dphi, ncell, 2, s); break; \
+      case 10: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 0, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 11: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 0, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break;
+#else
+#define FUS_EXPERIMENT_CASES(PP)
+#endif
+
 template <typename T>
 int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int P,
                             int64_t ncell, void* stream) {
@@ -113,7 +141,7 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
       case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
       case 2: e = fus::launch_stiffness_plan<T, PP, true, true, 3>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
       case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
-      case 4: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+FUS_EXPERIMENT_CASES(PP)                                                                             \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
     }                                                                                                     \
     break;
@@ -220,6 +248,7 @@ int fus_set_tuning(int key, int value) {
     case FUS_TUNE_MASS_VARIANT: g_mass_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_VARIANT: g_plan_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_RUNS: g_plan_runs = value; return FUS_OK;
+    case FUS_TUNE_PLAN_THREADS: g_plan_threads = (value == 128) ? 128 : 256; return FUS_OK;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -231,6 +260,7 @@ int fus_get_tuning(int key) {
     case FUS_TUNE_MASS_VARIANT: return g_mass_variant;
     case FUS_TUNE_PLAN_VARIANT: return g_plan_variant;
     case FUS_TUNE_PLAN_RUNS: return g_plan_runs;
+    case FUS_TUNE_PLAN_THREADS: return g_plan_threads;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -283,7 +313,10 @@ int fus_plan_entities_per_batch(int N) {
   if (N < 1 || N > fus::kPlanMaxEntries) return FUS_ERR_UNSUPPORTED_ENTITY;
   // cells (N = n^3): the stiffness kernel's batch size, so one plan serves both operators
   for (int P = FUS_MIN_DEGREE; P <= FUS_MAX_DEGREE; ++P)
-    if ((P + 1) * (P + 1) * (P + 1) == N) return 256 / ((P + 1) * (P + 1)) > 0 ? 256 / ((P + 1) * (P + 1)) : 1;
+    if ((P + 1) * (P + 1) * (P + 1) == N) {
+      const int tgt = g_plan_threads.load(std::memory_order_relaxed);
+      return tgt / ((P + 1) * (P + 1)) > 0 ? tgt / ((P + 1) * (P + 1)) : 1;
+    }
   const int epb = 1280 / N;  // ~5 entries per thread of a 256-thread workgroup
   return epb > 0 ? epb : 1;
 }

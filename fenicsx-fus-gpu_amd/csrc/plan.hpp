@@ -26,6 +26,8 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+#include <type_traits>
+
 #include "stiffness.hpp"
 
 namespace fus {
@@ -221,7 +223,6 @@ inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* 
 template <int SPT, int BLOCK>
 __device__ __forceinline__ int batch_dofs_issue(const int32_t* __restrict__ ud, int M, int nr_b, int tid,
                                                 int32_t (&mydof)[SPT]) {
-  static_assert(BLOCK >= 2 * kPlanMaxRuns, "one run-table word per thread");
   int rt = 0;
   if (nr_b == 0) {  // raw list; the builder padded [nu, M) with a valid dof
 #pragma unroll
@@ -229,7 +230,7 @@ __device__ __forceinline__ int batch_dofs_issue(const int32_t* __restrict__ ud, 
       const int s = tid + r * BLOCK;
       mydof[r] = ud[s < M ? s : 0];
     }
-  } else {
+  } else if constexpr (BLOCK >= 2 * kPlanMaxRuns) {  // one run-table word per thread
     rt = ud[tid < 2 * nr_b ? tid : 0];
   }
   return rt;
@@ -239,6 +240,7 @@ template <int SPT, int BLOCK>
 __device__ __forceinline__ void batch_dofs_resolve(int rt, int nu_b, int nr_b, int tid, int* __restrict__ s_runs,
                                                    int32_t (&mydof)[SPT]) {
   if (nr_b == 0) return;  // block-uniform
+  if constexpr (BLOCK < 2 * kPlanMaxRuns) return;  // such builds only accept raw plans (host-checked)
   if (tid < 2 * kPlanMaxRuns) s_runs[tid] = rt;
   __syncthreads();
 #pragma unroll
@@ -311,7 +313,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const uint16_t* sp = slot + cell * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
-    if constexpr (GMODE == 1) {
+    if constexpr (GMODE & 8) {  // ABLATION (timing only): no G loads
+#pragma unroll
+      for (int ix = 0; ix < n; ++ix)
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[ix][k] = T(k + 1);
+    } else if constexpr (GMODE & 1) {
       // EXPERIMENT ONLY (tools/ab_stiffness.py): G pre-transposed to [cell][6][n^3], every load a
       // fully coalesced 8-byte-per-lane access -- prices the AoS access shape, not a product path
       const T* Gs = G + cell * Nd * 6 + t;
@@ -329,7 +336,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
   T xv[SPT];
 #pragma unroll
-  for (int r = 0; r < SPT; ++r) xv[r] = x[mydof[r]];
+  for (int r = 0; r < SPT; ++r) {
+    if constexpr (GMODE & 4)
+      xv[r] = T(mydof[r]);  // ABLATION (timing only): no x gather
+    else
+      xv[r] = x[mydof[r]];
+  }
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
@@ -364,8 +376,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       dy[i] = sD[ty * n + i];
       dz[i] = sD[tz * n + i];
     }
-    const T* cu_y = su + lc * S + tz;
-    const T* cu_z = su + lc * S + ty * n;
+    // GMODE & 16: volatile LDS reads keep hipcc from fusing pairs into ds_read2_b64, which moves
+    // 16 B/lane in 8 LDS cycles where two ds_read_b64 take 4 (MI355X_MICROARCH.md, LDS table)
+    using LT = typename std::conditional<(GMODE & 16) != 0, const volatile __attribute__((address_space(3))) T,
+                                         const T>::type;
+    LT* cu_y = (LT*)(su + lc * S + tz);
+    LT* cu_z = (LT*)(su + lc * S + ty * n);
     T* cfy = sfy + lc * S + t;
     T* cfz = sfz + lc * S + t;
 #pragma unroll
@@ -402,8 +418,10 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       dyT[q] = sD[q * n + ty];
       dzT[q] = sD[q * n + tz];
     }
-    const T* cf_y = sfy + lc * S + tz;
-    const T* cf_z = sfz + lc * S + ty * n;
+    using LT2 = typename std::conditional<(GMODE & 16) != 0, const volatile __attribute__((address_space(3))) T,
+                                          const T>::type;
+    LT2* cf_y = (LT2*)(sfy + lc * S + tz);
+    LT2* cf_z = (LT2*)(sfz + lc * S + ty * n);
 #pragma unroll
     for (int jx = 0; jx < n; ++jx) {
       T acc = T(0);
@@ -423,14 +441,18 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
-    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sy[s]);
+    if constexpr (GMODE & 2) {  // ABLATION (timing only): no global atomics; keep the value alive
+      if (s < nu_b && sy[s] == T(-1.2345e300)) y[mydof[r]] = sy[s];
+    } else {
+      if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sy[s]);
+    }
   }
 }
 
-template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, int GMODE = 0>
+template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, int GMODE = 0, int TARGET = 256>
 inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
                                         const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream) {
-  constexpr int CPB = plan_cells_per_batch<P>();
+  constexpr int CPB = default_cells_per_block<P>(TARGET);
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();

@@ -54,6 +54,13 @@ def main():
     op(x, cc, y, G, dm)
     torch.cuda.synchronize()
     lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
+    dm_128 = dm.clone()  # a third dofmap array: plan cut for 128-thread workgroups (builds 110 / 111)
+    lib.set_tuning(lib.TUNE_PLAN_THREADS, 128)
+    lib.set_tuning(lib.TUNE_PLAN_VARIANT, 10)
+    op(x, cc, y, G, dm_128)
+    torch.cuda.synchronize()
+    lib.set_tuning(lib.TUNE_PLAN_THREADS, 256)
+    lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
     times = {c: [] for c in cfgs}
     for rnd in range(a.rounds + 1):
         for c in cfgs:
@@ -66,7 +73,7 @@ def main():
                 lib.set_tuning(lib.TUNE_PLAN_VARIANT, 0)
             lib.set_tuning(lib.TUNE_XCD_REMAP, c[1])
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            d_ = dm_raw if c[0] == -2 else dm
+            d_ = dm_raw if (c[0] == -2 or c[0] >= 120) else (dm_128 if c[0] in (110, 111) else dm)  # persistent builds (120+) read raw plans
             G_ = G_soa if c[0] == 104 else G
             op(x, cc, y, G_, d_)
             e0.record()
