@@ -36,7 +36,7 @@ inline int plan_allow_runs(int ndof_per_entity) {
   if (g_plan_threads.load(std::memory_order_relaxed) < 256) return 0;  // 128-thread builds read raw plans only
   return mode == 2 ? 1 : (mode == 1 ? (ndof_per_entity <= 64) : 0);
 }
-std::atomic<int> g_plan_variant{-1};  // -1 = auto: LDS-aliased build for P >= 6 (profiles/r01c_ab_plan_builds.log)
+std::atomic<int> g_plan_variant{-1};  // -1 = auto
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
 
@@ -133,7 +133,7 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
   int pv = g_plan_variant.load(std::memory_order_relaxed);
-  if (pv < 0) pv = (P >= 6) ? 1 : 0;
+  if (pv < 0) pv = (P >= 4) ? 1 : 0;  // LDS-aliased build from P = 4 up (profiles/r01d_ab_alias_by_degree.log)
   switch (P) {
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
