@@ -248,7 +248,13 @@ int fus_set_tuning(int key, int value) {
     case FUS_TUNE_MASS_VARIANT: g_mass_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_VARIANT: g_plan_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_RUNS: g_plan_runs = value; return FUS_OK;
-    case FUS_TUNE_PLAN_THREADS: g_plan_threads = (value == 128) ? 128 : 256; return FUS_OK;
+    case FUS_TUNE_PLAN_THREADS:
+#ifdef FUS_EXPERIMENTS
+      g_plan_threads = (value == 128) ? 128 : 256;
+      return FUS_OK;
+#else
+      return value == 256 ? FUS_OK : FUS_ERR_INVALID_ARGUMENT;  // only the experimental builds 10/11 read 128-thread plans
+#endif
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }

@@ -73,9 +73,11 @@ class _PlanCache:
             )
             if len(self._plans) >= self.capacity:  # bounded: drop the oldest plan
                 self._plans.pop(next(iter(self._plans)))
-            hit = (ws, epb)
+            # the entry holds the dofmap tensor itself: while a plan is cached its memory cannot be
+            # freed and handed to another array with the same address / shape / version
+            hit = (ws, epb, dofmap)
             self._plans[key] = hit
-        return hit
+        return hit[0], hit[1]
 
     def clear(self):
         self._plans.clear()

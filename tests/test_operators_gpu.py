@@ -373,3 +373,28 @@ def test_full_size_config3(gpu, oracle_c):
     a, b = float(v @ Kx), float(x @ Kv)
     assert abs(a - b) < 1e-11 * max(abs(a), abs(b))  # symmetry
     _check(K(2.0 * x - 3.0 * v), 2.0 * Kx - 3.0 * Kv, np.float64, "linearity")
+
+
+def test_plan_cache_follows_dofmap_changes(gpu, oracle_c):
+    """The cached batch plan is keyed on the dofmap array's identity AND version: an in-place
+    change of the dofmap must be seen by the next apply."""
+    dev, ops = gpu
+    P = 2
+    pb = build_problem(P, (3, 3, 3), perturb=0.1)
+    mesh = pb["mesh"]
+    op = ops.stiffness_operator(P, pb["D"].flatten(), np.float64)
+    x, cc, G = dev.to_device(pb["x"]), dev.to_device(pb["cc"]), dev.to_device(pb["G"])
+    dm = dev.to_device(mesh.dofmap)
+    y = dev.to_device(np.zeros(mesh.ndofs))
+    op(x, cc, y, G, dm)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    _check(y.copy_to_host(), y_ref, np.float64, "first dofmap")
+    perm = np.random.default_rng(0).permutation(mesh.ndofs).astype(np.int32)
+    dm2 = perm[mesh.dofmap]  # renumbered dofs, same array object on the device
+    dm.copy_(dev.to_device(dm2))
+    y = dev.to_device(np.zeros(mesh.ndofs))
+    op(x, cc, y, G, dm)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], np.ascontiguousarray(dm2))
+    _check(y.copy_to_host(), y_ref, np.float64, "dofmap changed in place")
