@@ -276,6 +276,11 @@ def main():
         else:
             halo.apply(x_d, cc_d, y_d, G_d, dm_d)
 
+    # set-up outside every step: batch plans, communicator bring-up
+    if halo is None:
+        op.prepare(dm_d)
+    else:
+        halo.prepare(x_d, cc_d, G_d, dm_d)
     for _ in range(args.warmup):
         step()
     y_d.zero_()

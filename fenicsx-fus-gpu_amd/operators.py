@@ -208,6 +208,13 @@ class _StiffnessOperator(_Launchable):
                 "fus_stiffness_apply",
             )
 
+    def prepare(self, dofmap):
+        """Set-up, not an apply: build (and cache) the batch plan for ``dofmap`` now instead of
+        lazily inside the first apply."""
+        _req(dofmap, torch.int32, "dofmap")
+        if _USE_PLAN and dofmap.shape[0] > 0:
+            _PLANS.get(dofmap)
+
     # numba-cpu flavour: op(x, cell_constants, y, G, dofmap)
     def __call__(self, x, cell_constants, y, G, dofmap):
         if self._dphi is None:

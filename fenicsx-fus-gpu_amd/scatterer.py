@@ -250,6 +250,18 @@ class HaloApply:
         self.run(lambda c_, G_, d_: fn(x, c_, y, G_, d_), (cell_constants, G, dofmap),
                  [(self.fwd, x)] + list(extra_forward), [(self.rev, y)], boundary_terms)
 
+    def prepare(self, x, cell_constants, G, dofmap):
+        """Set-up, not an apply: build the batch plans of the three cell sub-ranges and bring the
+        communicator up (RCCL creates its channels on first use) with two no-effect exchanges --
+        a forward scatter of x (ghosts receive their owners' values) and a reverse scatter of a
+        zero vector."""
+        for name in ("interior1", "boundary", "interior2"):
+            a, b = self.ranges[name]
+            if b > a and self.op is not None and hasattr(self.op, "prepare"):
+                self.op.prepare(self._views(name, (cell_constants, G, dofmap))[2])
+        self.fwd(x)
+        self.rev(x.new_zeros(x.shape))
+
     def apply_local_only(self, x, cell_constants, y, G, dofmap):
         """The three kernel launches without any exchange (bench: kernel time at N > 1)."""
         fn = self._apply_fn if self._apply_fn is not None else self.op
