@@ -115,6 +115,9 @@ int64_t plan_bytes(int P, int64_t ncell) {
       case 21: e = fus::launch_stiffness_plan_persistent<T, PP, true, 4>(x, cc, y, G, ws, dphi, ncell, 4, s); break;  \
       case 22: e = fus::launch_stiffness_plan_persistent<T, PP, true, 3>(x, cc, y, G, ws, dphi, ncell, 3, s); break;  \
       case 23: e = fus::launch_stiffness_plan_persistent<T, PP, false, 1>(x, cc, y, G, ws, dphi, ncell, 2, s); break; \
+      case 14: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 15: e = fus::launch_stiffness_plan<T, PP, true, false, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 16: e = fus::launch_stiffness_plan<T, PP, true, false, 5, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 10: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 0, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 11: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 0, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break;
 #else

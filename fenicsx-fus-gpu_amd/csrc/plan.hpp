@@ -326,7 +326,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       for (int ix = 0; ix < n; ++ix)
 #pragma unroll
         for (int k = 0; k < 6; ++k) g[ix][k] = Gs[(int64_t)k * Nd + ix * n2];
-    } else {
+    } else if constexpr ((GMODE & 32) == 0) {
       const T* Gc = G + (cell * Nd + t) * 6;
 #pragma unroll
       for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
@@ -395,6 +395,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
         vy += dy[i] * cu_y[qx * n2 + i * n];
         vz += dz[i] * cu_z[qx * n2 + i];
       }
+      if constexpr ((GMODE & 32) != 0)  // stream this slab of G now (fewer live registers)
+        load_g6<T>(G + (cell * Nd + t) * 6 + (int64_t)qx * n2 * 6, g[qx]);
       const T* gq = g[qx];
       fx[qx] = coeff * (gq[0] * vx + gq[1] * vy + gq[2] * vz);
       cfy[qx * n2] = coeff * (gq[1] * vx + gq[3] * vy + gq[4] * vz);
