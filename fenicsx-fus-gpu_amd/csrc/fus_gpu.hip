@@ -115,6 +115,9 @@ int64_t plan_bytes(int P, int64_t ncell) {
       case 21: e = fus::launch_stiffness_plan_persistent<T, PP, true, 4>(x, cc, y, G, ws, dphi, ncell, 4, s); break;  \
       case 22: e = fus::launch_stiffness_plan_persistent<T, PP, true, 3>(x, cc, y, G, ws, dphi, ncell, 3, s); break;  \
       case 23: e = fus::launch_stiffness_plan_persistent<T, PP, false, 1>(x, cc, y, G, ws, dphi, ncell, 2, s); break; \
+      case 17: e = fus::launch_stiffness_plan<T, PP, true, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 18: e = fus::launch_stiffness_plan<T, PP, true, true, 6>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 19: e = fus::launch_stiffness_plan<T, PP, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 14: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 15: e = fus::launch_stiffness_plan<T, PP, true, false, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 16: e = fus::launch_stiffness_plan<T, PP, true, false, 5, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
@@ -136,7 +139,12 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
   int pv = g_plan_variant.load(std::memory_order_relaxed);
-  if (pv < 0) pv = (P >= 4) ? 1 : 0;  // LDS-aliased build from P = 4 up (profiles/r01d_ab_alias_by_degree.log)
+  if (pv < 0) {  // auto (profiles/r01d_ab_alias_by_degree.log, r01d_ablation_and_experiments.log)
+    if (sizeof(T) == 4 && P <= 4)
+      pv = 30;  // fp32: registers allow 5 waves/SIMD (+9 %)
+    else
+      pv = (P >= 4) ? 1 : 0;  // LDS-aliased build from P = 4 up
+  }
   switch (P) {
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
@@ -144,6 +152,7 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
       case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
       case 2: e = fus::launch_stiffness_plan<T, PP, true, true, 3>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
       case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
+      case 30: e = fus::launch_stiffness_plan<T, PP, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
 FUS_EXPERIMENT_CASES(PP)                                                                             \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
     }                                                                                                     \
