@@ -360,6 +360,8 @@ def main():
             "traffic": load_traffic(P, mesh.ncells),
             "kernel": "fus::stiffness_plan_kernel" if ops._USE_PLAN else "fus::stiffness_col_kernel",
             "kernel_ms": kern_ms,
+            "step_ms_min": float(ev_ms.min()),
+            "step_ms_std": float(ev_ms.std()),
             "algorithmic_bytes_per_cell": bpc,
             "cells_per_launch": mesh.ncells,
             "pct_of_hbm_roofline_dofs": 100.0 * achieved / HBM_PEAK_GBS,
