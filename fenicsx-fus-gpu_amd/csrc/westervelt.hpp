@@ -226,7 +226,10 @@ __global__ void __launch_bounds__(256)
       un[i] = u0i + aw * kui;
       ku[i] = v0i + aw * kv;
     }
-    m[i] = m0[i];  // ghost entries too: they receive this rank's partial sums next stage
+    // owned: restart from the steady part (already reverse-scattered); ghosts: restart from zero --
+    // they collect this rank's partial sums of the next stage, which the reverse scatter ADDS to the
+    // owner (the reference adds m0 after scatter_rev(m), cuda/demo_nonlinear_bowl.py:611-619)
+    m[i] = (i < nlocal) ? m0[i] : T(0);
     b[i] = T(0);
   }
 }

@@ -41,17 +41,23 @@ class StagedComm:
         return self.inner.alltoallv_int64(*a)
 
 
-def run_solver(outdir, P, cells, grid, overlap):
-    """mode "gpu-solver": the fused linear RK4 solver on a partitioned mesh, all ranks on cuda:0."""
+def run_solver(outdir, P, cells, grid, overlap, nonlinear=False):
+    """mode "gpu-solver" / "gpu-solver-nl": the fused linear / Westervelt RK4 solver on a
+    partitioned mesh, all ranks on cuda:0."""
     rank = dist.get_rank()
     boxmesh, ls, scat = (fusgpu_loader.submodule(m) for m in ("boxmesh", "linear_solver", "scatterer"))
+    nls = fusgpu_loader.submodule("nonlinear_solver")
     torch.cuda.set_device(0)
     L = 0.012
     mesh = boxmesh.BoxMesh(P, cells, grid=grid, rank=rank, length=L)
     serial = boxmesh.BoxMesh(P, cells, length=L)
     h = ls.time_step_parameters(serial, P, 1500.0, 0.5e6, L)
     dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
-    solver = ls.LinearSpectral3D(mesh, np.float64, comm=StagedComm(scat.TorchComm()), fused=True, overlap=bool(overlap))
+    if nonlinear:
+        solver = nls.WesterveltSpectral3D(mesh, np.float64, speed_of_sound=1500.0, source_frequency=0.5e6,
+                                          comm=StagedComm(scat.TorchComm()), fused=True, overlap=bool(overlap))
+    else:
+        solver = ls.LinearSpectral3D(mesh, np.float64, comm=StagedComm(scat.TorchComm()), fused=True, overlap=bool(overlap))
     solver.init()
     solver.rk4(0.0, tf, dt, max_steps=8)
     torch.cuda.synchronize()
@@ -67,8 +73,8 @@ def main():
     dist.init_process_group("gloo")
     rank, world = dist.get_rank(), dist.get_world_size()
     assert world == gx * gy * gz
-    if mode == "gpu-solver":
-        return run_solver(outdir, P, (nx, ny, nz), (gx, gy, gz), overlap)
+    if mode in ("gpu-solver", "gpu-solver-nl"):
+        return run_solver(outdir, P, (nx, ny, nz), (gx, gy, gz), overlap, nonlinear=mode.endswith("nl"))
     boxmesh, gll, pre = (fusgpu_loader.submodule(m) for m in ("boxmesh", "gll", "precompute"))
     scat = fusgpu_loader.submodule("scatterer")
     mesh = boxmesh.BoxMesh(P, (nx, ny, nz), grid=(gx, gy, gz), rank=rank, perturb=0.16, seed=3)

@@ -112,3 +112,19 @@ def test_partitioned_rk4_solver_on_one_gpu(tmp_path, oracle_c, grid):
         seen[d["lex_owned"]] += 1
         assert rel_l2(d["u_owned"], u_ref[d["lex_owned"]]) < 1e-11
     assert np.all(seen == 1)
+
+
+@pytest.mark.gpu
+def test_partitioned_westervelt_solver_on_one_gpu(tmp_path, oracle_c):
+    """Fused Westervelt stage on 2 ranks: three quantities cross the partition per stage (u_n and
+    v_n forward, b and the solution-dependent lumped mass m reverse)."""
+    import rk4_oracle
+
+    P, cells, L = 3, (4, 3, 3), 0.012
+    res = run_ranks("gpu-solver-nl", tmp_path, P, cells, (2, 1, 1), 1)
+    boxmesh = pkg("boxmesh")
+    serial = boxmesh.BoxMesh(P, cells, length=L)
+    u_ref, _ = rk4_oracle.solve_westervelt(serial, 8, float(res[0]["dt"]), c0=1500.0, f0=0.5e6, oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 0
+    for d in res:
+        assert rel_l2(d["u_owned"], u_ref[d["lex_owned"]]) < 1e-11
