@@ -3,7 +3,13 @@
 N variants x M rounds on the BASELINE config-3 workload; prints median / min per variant.
 
     python tools/ab_stiffness.py [--cells 54] [--degree 4] [--rounds 7] [--reps 10] v:r [v:r ...]
-where each ``v:r`` is (stiffness variant):(xcd remap); variant ``p`` = planned kernel."""
+where each ``v:r`` is (kernel):(xcd remap).  Kernels: ``0``/``1`` = plan-free column kernel with
+~256 / ~128-thread workgroups; ``p`` = planned kernel on a run-length coded plan, ``r`` = planned
+kernel on a raw plan; ``100 + k`` = build k of the planned kernel (FUS_TUNE_PLAN_VARIANT, see
+csrc/fus_gpu.hip: 0 default, 1 LDS-aliased, 2/3 occupancy hints, 30 fp32 5-waves build; k >= 4
+are the experimental builds -- SoA G, ablations, volatile LDS reads, G streaming, 128-thread
+batches, persistent kernel -- and need ``make -C fenicsx-fus-gpu_amd/csrc EXPERIMENTS=1``).
+Results of the studies run with this tool: profiles/r01*_ab_*.log, r01d_ablation_and_experiments.log."""
 import argparse
 import os
 import sys
