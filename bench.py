@@ -164,7 +164,9 @@ def bench_rk4(args, rank, world, device):
         "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": args.dtype, "data": "synthetic",
         "config": {"workload": f"linear wave RK4 step (4 stages: stiffness + 2 facet mass + fused vector update + halo), "
                                f"P={P}, {gcells[0]}x{gcells[1]}x{gcells[2]} cells, {mesh.ndofs_global} dofs",
-                   "steps_to_final_time": nstep, "dt": dts},
+                   "steps_to_final_time": nstep, "dt": dts,
+                   "geometry": "affine box: constant-G fast path (opt-in, checked at set-up)" if solver.affine
+                   else "general per-quadrature-point G"},
         "roofline": None, "cpu_baseline": None,
     }
     if rank == 0:

@@ -38,6 +38,7 @@ def _signatures():
     for suf, ct in _SUFFIXES:
         sig[f"fus_stiffness_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_stiffness_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
+        sig[f"fus_stiffness_apply_planned_affine_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_mass_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _int, _i64, _vp]
         sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]

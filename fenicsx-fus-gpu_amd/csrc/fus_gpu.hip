@@ -165,6 +165,28 @@ FUS_EXPERIMENT_CASES(PP)                                                        
 }
 
 template <typename T>
+int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, const T* wratio, const void* ws,
+                                   const T* dphi, int P, int64_t ncell, void* stream) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
+  if (ncell == 0) return FUS_OK;
+  if (!x || !cc || !y || !G || !wratio || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipErrorInvalidValue;
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    e = fus::launch_stiffness_plan<T, PP, true, true, 1, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); \
+    break;
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return hip_rc(e);
+}
+
+template <typename T>
 int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5, T* b, T* m, const T* G,
                     const T* detJ, const void* ws, const T* dphi, int P, int64_t ncell, void* stream) {
   if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
@@ -425,6 +447,15 @@ FUS_VEC(float, f32)
 FUS_GEOM(double, f64)
 FUS_GEOM(float, f32)
 #undef FUS_GEOM
+
+#define FUS_AFFINE(T, SUF)                                                                                       \
+  int fus_stiffness_apply_planned_affine_##SUF(const T* x, const T* cc, T* y, const T* G, const T* wratio,       \
+                                               const void* ws, const T* dphi, int P, int64_t ncell, void* s) {   \
+    return stiffness_apply_planned_affine<T>(x, cc, y, G, wratio, ws, dphi, P, ncell, s);                        \
+  }
+FUS_AFFINE(double, f64)
+FUS_AFFINE(float, f32)
+#undef FUS_AFFINE
 
 #define FUS_WEST(T, SUF)                                                                                          \
   int fus_westervelt_cell_apply_planned_##SUF(const T* u, const T* v, const T* c2, const T* c3, const T* c4,      \

@@ -271,7 +271,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
                           const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
-                          const T* __restrict__ dphi, int64_t ncell, int xcd_remap) {
+                          const T* __restrict__ dphi, int64_t ncell, int xcd_remap,
+                          const T* __restrict__ wratio = nullptr) {
   constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
   constexpr int S = PADLDS ? lds_cell_stride<T, P>() : Nd;
   constexpr int BLOCK = col_block_threads<P, CPB>();
@@ -313,7 +314,19 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const uint16_t* sp = slot + cell * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
-    if constexpr (GMODE & 8) {  // ABLATION (timing only): no G loads
+    if constexpr (GMODE & 64) {
+      // affine cells (opt-in): the geometric factor of an affine cell is one
+      // symmetric 3x3 matrix times the quadrature weight, G[c][q] = G[c][0] * (w_q / w_0), so only
+      // the first record of the cell (48 B instead of 48 n^3 B) is read
+      T g0[6];
+      load_g6<T>(G + cell * Nd * 6, g0);
+#pragma unroll
+      for (int ix = 0; ix < n; ++ix) {
+        const T wr = wratio[ix * n2 + t];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) g[ix][k] = g0[k] * wr;
+      }
+    } else if constexpr (GMODE & 8) {  // ABLATION (timing only): no G loads
 #pragma unroll
       for (int ix = 0; ix < n; ++ix)
 #pragma unroll
@@ -453,13 +466,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 
 template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, int GMODE = 0, int TARGET = 256>
 inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
-                                        const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream) {
+                                        const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream,
+                                        const T* wratio = nullptr) {
   constexpr int CPB = default_cells_per_block<P>(TARGET);
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GMODE>), dim3((unsigned)v.nbatch), dim3(threads), 0,
-                     stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap);
+                     stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap, wratio);
   return hipGetLastError();
 }
 

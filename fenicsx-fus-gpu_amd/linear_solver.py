@@ -91,7 +91,7 @@ def snap_time_step(mesh_size, P, speed_of_sound, source_frequency, domain_length
 class LinearSpectral3D:
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1500.0, density=1000.0,
                  source_frequency=0.5e6, source_amplitude=60000.0, comm=None, fused=True,
-                 source_time="tn", overlap=True, halo_kernels=None):
+                 source_time="tn", overlap=True, halo_kernels=None, affine="auto"):
         self.mesh, self.P = mesh, mesh.P
         self.dt_np = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(float_type)
@@ -124,7 +124,12 @@ class LinearSpectral3D:
         self.nlocal, self.ndofs = mesh.nlocal, mesh.ndofs
 
         # ---- operators --------------------------------------------------------------------------
-        self.stiff = ops.stiffness_operator(P, D.flatten(), ft)
+        # affine cells (every box mesh of the reference's demos): opt into the constant-G fast path
+        # after checking the geometry factors really are affine ("auto"), or on request / never
+        w3 = tensor_weights_3d(gll_points_weights(P)[1])
+        self.affine = bool(affine) if affine != "auto" else ops.is_affine_geometry(
+            self.G, w3, rtol=1e-11 if ft == np.float64 else 1e-5)
+        self.stiff = ops.stiffness_operator(P, D.flatten(), ft, affine_weights=w3 if self.affine else None)
         self.mass_cell = ops.mass_operator(n**3, ft)
         self.mass_facet = ops.mass_operator(n * n, ft)
         self.axpy = ops.axpy(self.ndofs)

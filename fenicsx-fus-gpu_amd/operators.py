@@ -153,7 +153,7 @@ mass_operator = _MassOperator()
 class _StiffnessOperator(_Launchable):
     """Returned by ``stiffness_operator``; callable both ways."""
 
-    def __init__(self, P: int, float_type, dphi=None):
+    def __init__(self, P: int, float_type, dphi=None, affine_weights=None):
         self.P = int(P)
         if not (1 <= self.P <= 10):
             raise ValueError(f"polynomial degree {P} outside the supported range 1..10")
@@ -165,6 +165,15 @@ class _StiffnessOperator(_Launchable):
         self._dphi_src = None
         if dphi is not None:
             self._dphi = self._table(dphi)
+        # opt-in affine-cell fast path: tensor quadrature weights [n^3] of the rule G was built with
+        self._wratio = None
+        if affine_weights is not None:
+            w = np.asarray(affine_weights, dtype=np.float64).reshape(-1)
+            if w.size != self.n**3:
+                raise ValueError(f"affine_weights must hold the {self.n ** 3} tensor quadrature weights")
+            dev = torch.device("cuda", torch.cuda.current_device())
+            self._wratio = torch.from_numpy(w / w[0]).to(device=dev, dtype=self.dtype).contiguous()
+            self._fn_affine = getattr(_lib.load(), f"fus_stiffness_apply_planned_affine_{_lib.suffix(self.dtype)}")
 
     def _table(self, dphi):
         """Accept the flat ``[q*n+i]`` (numba-cpu) or 2-D ``[q, i]`` (cuda) table, host or device."""
@@ -194,7 +203,15 @@ class _StiffnessOperator(_Launchable):
             raise ValueError("cell_constants must have one value per cell")
         if ncell == 0:
             return
-        if _USE_PLAN:
+        if self._wratio is not None:
+            ws, _ = _PLANS.get(dofmap)
+            _lib.check(
+                self._fn_affine(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(),
+                                self._wratio.data_ptr(), ws.data_ptr(), dphi_t.data_ptr(), self.P, int(ncell),
+                                _lib.stream_ptr()),
+                "fus_stiffness_apply_planned_affine",
+            )
+        elif _USE_PLAN:
             ws, _ = _PLANS.get(dofmap)
             _lib.check(
                 self._fn_planned(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(), ws.data_ptr(),
@@ -229,14 +246,18 @@ class _StiffnessOperator(_Launchable):
         self._apply(x, entity_constants, y, G_entity, entity_dofmap, self._dphi_cuda)
 
 
-def stiffness_operator(P, *args):
+def stiffness_operator(P, *args, affine_weights=None):
     """``stiffness_operator(P, dphi, float_type)`` (numba-cpu/operators.py:71) or
-    ``stiffness_operator(P, float_type)`` (cuda/operators.py:73)."""
+    ``stiffness_operator(P, float_type)`` (cuda/operators.py:73).
+
+    ``affine_weights`` (keyword, no reference counterpart): opt into the affine-cell fast path by
+    passing the tensor quadrature weights ``[n^3]``; the operator then reads only ``G[c, 0, :]`` of
+    each cell.  Only valid when every cell is affine (``is_affine_geometry`` checks)."""
     if len(args) == 2:
         dphi, float_type = args
-        return _StiffnessOperator(P, float_type, dphi)
+        return _StiffnessOperator(P, float_type, dphi, affine_weights)
     if len(args) == 1:
-        return _StiffnessOperator(P, args[0])
+        return _StiffnessOperator(P, args[0], None, affine_weights)
     raise TypeError("stiffness_operator(P, dphi, float_type) or stiffness_operator(P, float_type)")
 
 
@@ -276,6 +297,16 @@ class _WesterveltCellOperator:
 
 def westervelt_cell_operator(P, dphi, float_type):
     return _WesterveltCellOperator(P, dphi, float_type)
+
+
+def is_affine_geometry(G, weights, rtol=1e-12):
+    """True if ``G[c, q, :] == G[c, 0, :] * w_q / w_0`` for every cell (set-up check for the
+    affine fast path; one pass over G with torch, not part of the apply)."""
+    w = torch.as_tensor(np.asarray(weights, dtype=np.float64).reshape(-1), device=G.device).to(G.dtype)
+    Gv = G.reshape(G.shape[0], -1, 6)
+    ref = Gv[:, :1, :] * (w / w[0]).reshape(1, -1, 1)
+    scale = Gv.abs().amax()
+    return bool(((Gv - ref).abs().amax() <= rtol * scale).item())
 
 
 # -------------------------------------------------------------------- vector ops

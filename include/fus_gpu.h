@@ -94,6 +94,21 @@ int fus_mass_apply_f32(const float* x, const float* entity_constants, float* y, 
                        const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, void* stream);
 
 /*
+ * Opt-in fast path for AFFINE cells (reported separately from the headline, whose
+ * bytes contract is the general per-quadrature-point G): on an affine cell
+ * G[c][q] = G[c][0] * (w_q / w_0), so the apply reads only the first 6-value record of each cell of
+ * the SAME ``G`` array the reference builds, plus ``wratio`` = T[n^3] = w_q / w_0 (tensor GLL weights).
+ * The caller asserts affinity (every box mesh of the reference's demos is affine);
+ * results equal the general path up to round-off.
+ */
+int fus_stiffness_apply_planned_affine_f64(const double* x, const double* cell_constants, double* y, const double* G,
+                                           const double* wratio, const void* workspace, const double* dphi, int P,
+                                           int64_t ncell, void* stream);
+int fus_stiffness_apply_planned_affine_f32(const float* x, const float* cell_constants, float* y, const float* G,
+                                           const float* wratio, const void* workspace, const float* dphi, int P,
+                                           int64_t ncell, void* stream);
+
+/*
  * Generic batch plan (any entity kind: cells N = n^3, boundary facets N = n^2) and planned mass
  * apply.  fus_plan_entities_per_batch(N) returns the preferred batch size (for cells it equals
  * the stiffness plan's, so ONE workspace built from the cell dofmap serves both operators:

@@ -398,3 +398,25 @@ def test_plan_cache_follows_dofmap_changes(gpu, oracle_c):
     y_ref = np.zeros(mesh.ndofs)
     oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], np.ascontiguousarray(dm2))
     _check(y.copy_to_host(), y_ref, np.float64, "dofmap changed in place")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [2, 4, 6])
+def test_affine_fast_path(gpu, oracle_c, P, dtype):
+    """Opt-in affine-cell path (reads G[c, 0, :] only) == general path on an affine box with
+    anisotropic cells; the affinity check rejects a perturbed mesh."""
+    dev, ops = gpu
+    gll = pkg("gll")
+    pb = build_problem(P, (4, 3, 5), dtype=dtype)  # h = (1/4, 1/3, 1/5): affine, anisotropic
+    mesh = pb["mesh"]
+    w3 = gll.tensor_weights_3d(pb["wts"])
+    G = dev.to_device(pb["G"])
+    assert ops.is_affine_geometry(G, w3, rtol=1e-12 if dtype == np.float64 else 1e-5)
+    y_ref = np.zeros(mesh.ndofs, dtype=dtype)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    y = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    op = ops.stiffness_operator(P, pb["D"].flatten(), dtype, affine_weights=w3)
+    op(dev.to_device(pb["x"]), dev.to_device(pb["cc"]), y, G, dev.to_device(mesh.dofmap))
+    _check(y.copy_to_host(), y_ref, dtype, f"affine fast path P={P}")
+    pert = build_problem(P, (3, 2, 2), dtype=dtype, perturb=0.16)
+    assert not ops.is_affine_geometry(dev.to_device(pert["G"]), w3, rtol=1e-12 if dtype == np.float64 else 1e-5)

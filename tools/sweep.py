@@ -64,6 +64,11 @@ def main():
                 gbs = mesh.ncells * bench.stiffness_bytes_per_cell(P, T) / (t * 1e-3) / 1e9
                 res.append(f"K[{'plan' if plan else 'atomic'}] {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s {100 * gbs / 8000:5.1f}%")
             ops.use_plan(True)
+            if a.affine:
+                gll = fusgpu_loader.submodule("gll")
+                opa = ops.stiffness_operator(P, pb["D"].flatten(), dt, affine_weights=gll.tensor_weights_3d(pb["wts"]))
+                t = timeit(lambda: opa(x, cc, y, G, dm))
+                res.append(f"K[affine fast path] {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s")
             t = timeit(lambda: mop(x, cc, y, detJ, dm))
             gbs = mesh.ncells * mass_bytes_per_cell(P, T) / (t * 1e-3) / 1e9
             res.append(f"M {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s {100 * gbs / 8000:5.1f}%")

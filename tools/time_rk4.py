@@ -18,6 +18,7 @@ def main():
     ap.add_argument("--degree", type=int, default=4)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--westervelt", action="store_true")
+    ap.add_argument("--no-affine", action="store_true", help="general per-quadrature-point G even on the affine box")
     a = ap.parse_args()
     import torch
 
@@ -32,7 +33,7 @@ def main():
     print(f"P={a.degree} cells={mesh.ncells} dofs={mesh.ndofs} dt={dt:.3e} steps to final time={nstep}")
     nls = fusgpu_loader.submodule("nonlinear_solver")
     for fused in (False, True):
-        s = nls.WesterveltSpectral3D(mesh, np.float64, fused=fused) if a.westervelt else ls.LinearSpectral3D(mesh, np.float64, fused=fused)
+        s = nls.WesterveltSpectral3D(mesh, np.float64, fused=fused) if a.westervelt else ls.LinearSpectral3D(mesh, np.float64, fused=fused, affine=False if a.no_affine else "auto")
         s.init()
         s.rk4(0.0, tf, dt, max_steps=3)
         torch.cuda.synchronize()
