@@ -200,6 +200,19 @@ class HaloApply:
         self.ranges = {"boundary": (0, nb), "interior1": (nb, mid), "interior2": (mid, nc)}
         self._views_cache = {}
         self._apply_fn = apply_fn  # tests: CPU stand-in for the operator
+        import os
+
+        # FUS_HALO_SIDE_STREAM=1: run pack -> exchange -> unpack on a high-priority side stream.
+        # Off by default: in a 1-rank world it costs +11 us wall and +57 us host issue time per
+        # apply (event traffic) for ~20 us of pack/unpack launches it could take off the main
+        # stream on a real partition (profiles/r01f_host_overhead.log); to be re-measured on 8 GPUs.
+        self.side_stream = os.environ.get("FUS_HALO_SIDE_STREAM", "0") == "1"
+        self._hs = None
+
+    def _halo_stream(self):
+        if self._hs is None:
+            self._hs = torch.cuda.Stream(priority=-1)  # high priority: small kernels between big ones
+        return self._hs
 
     def _views(self, name, percell):
         key = (name,) + tuple(t.data_ptr() for t in percell)
@@ -231,17 +244,54 @@ class HaloApply:
             for sc, vec in reverse:
                 sc(vec)
             return
-        fw = [(sc, vec, sc.begin(vec)) for sc, vec in forward]
+        on_gpu = self.side_stream and len(forward) > 0 and forward[0][1].is_cuda
+        if not on_gpu:
+            fw = [(sc, vec, sc.begin(vec)) for sc, vec in forward]
+            part("interior1")
+            for sc, vec, wk in fw:
+                sc.end(vec, wk)
+            part("boundary")
+            if boundary_terms is not None:
+                boundary_terms()
+            rv = [(sc, vec, sc.begin(vec)) for sc, vec in reverse]
+            part("interior2")
+            for sc, vec, wk in rv:
+                sc.end(vec, wk)
+            return
+        # GPU: the whole exchange chain (pack -> all-to-all-v -> unpack) runs on a high-priority
+        # side stream, so not even the pack / unpack launches sit between the operator kernels of
+        # the main stream; the two streams meet only where data demands it:
+        #   side waits for main   : vectors ready to pack (start; after the boundary cells)
+        #   main waits for side   : ghosts refreshed (before the boundary cells); sums landed (end)
+        # Hazards: interior cells never touch ghost entries (unpack_fwd writes, pack_rev reads them);
+        # unpack_rev and the interior kernel both ADD into owned entries of y with atomics.
+        main = torch.cuda.current_stream()
+        hs = self._halo_stream()
+        ev = torch.cuda.Event()
+        ev.record(main)
+        hs.wait_event(ev)
+        with torch.cuda.stream(hs):
+            fw = [(sc, vec, sc.begin(vec)) for sc, vec in forward]
+            for sc, vec, wk in fw:
+                sc.end(vec, wk)
+            ev_fwd = torch.cuda.Event()
+            ev_fwd.record(hs)
         part("interior1")
-        for sc, vec, wk in fw:
-            sc.end(vec, wk)
+        main.wait_event(ev_fwd)
         part("boundary")
         if boundary_terms is not None:
             boundary_terms()
-        rv = [(sc, vec, sc.begin(vec)) for sc, vec in reverse]
+        ev_b = torch.cuda.Event()
+        ev_b.record(main)
+        hs.wait_event(ev_b)
+        with torch.cuda.stream(hs):
+            rv = [(sc, vec, sc.begin(vec)) for sc, vec in reverse]
+            for sc, vec, wk in rv:
+                sc.end(vec, wk)
+            ev_rev = torch.cuda.Event()
+            ev_rev.record(hs)
         part("interior2")
-        for sc, vec, wk in rv:
-            sc.end(vec, wk)
+        main.wait_event(ev_rev)
 
     def apply(self, x, cell_constants, y, G, dofmap, extra_forward=(), boundary_terms=None):
         """y += K x on the partitioned mesh (``extra_forward``: further ``(scatter_forward closure,

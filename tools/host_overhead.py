@@ -1,0 +1,56 @@
+#!/usr/bin/env python3
+"""Host-side issue time per apply (Python + ctypes + torch launch path), measured by issuing K steps
+without synchronising: if it exceeds the GPU time per step the path is host-bound."""
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+import fusgpu_loader  # noqa: E402
+from conftest import build_problem  # noqa: E402
+
+os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+os.environ.setdefault("MASTER_PORT", "29577")
+torch.cuda.set_device(0)
+dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda", 0))
+ops, scat = fusgpu_loader.submodule("operators"), fusgpu_loader.submodule("scatterer")
+pb = build_problem(4, 54, perturb=0.16)
+mesh = pb["mesh"]
+dev = torch.device("cuda", 0)
+x, cc, G = (torch.from_numpy(pb[k]).to(dev) for k in ("x", "cc", "G"))
+dm = torch.from_numpy(mesh.dofmap).to(dev)
+y = torch.zeros(mesh.ndofs, dtype=torch.float64, device=dev)
+op = ops.stiffness_operator(4, pb["D"].flatten(), np.float64)
+halo = scat.HaloApply(mesh, op, scat.TorchComm(), np.float64)
+halo.prepare(x, cc, G, dm)
+op.prepare(dm)
+send = torch.zeros(47089 * 3, dtype=torch.float64, device=dev)
+recv = torch.zeros_like(send)
+
+
+def issue(fn, K=200):
+    fn()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(K):
+        fn()
+    t1 = time.perf_counter()
+    torch.cuda.synchronize()
+    t2 = time.perf_counter()
+    return (t1 - t0) / K * 1e6, (t2 - t0) / K * 1e6
+
+
+for name, fn in (("single launch op(...)", lambda: op(x, cc, y, G, dm)),
+                 ("HaloApply.apply (1 rank: 3 launches, no exchange)", lambda: halo.apply(x, cc, y, G, dm)),
+                 ("all_to_all_single to self, async + wait (377 kB x3)", lambda: dist.all_to_all_single(recv, send, [send.numel()], [send.numel()], async_op=True).wait()),
+                 ("fill kernel via ctypes", lambda: ops.fill(0.0, recv))):
+    h, tot = issue(fn)
+    print(f"{name:58s} host issue {h:7.1f} us/step   wall {tot:7.1f} us/step")
+dist.destroy_process_group()
