@@ -85,3 +85,16 @@ def test_product_does_not_import_oracle():
         if fn.endswith(".py"):
             src = open(os.path.join(pkgdir, fn)).read()
             assert not re.search(r"^\s*(from|import)\s+oracle\b", src, flags=re.M), fn
+
+
+@pytest.mark.gpu
+def test_c_abi_demo_plain_cpp_host():
+    """examples/c_abi_demo.cpp: a C++ host with no Python/torch drives the library through the C ABI
+    alone and checks operator identities (K 1 = 0, symmetry, exact energy, planned == plan-free)."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "examples", "c_abi_demo")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0 and "C_ABI_DEMO_OK" in r.stdout, r.stdout + r.stderr
