@@ -42,6 +42,7 @@ def _signatures():
         sig[f"fus_mass_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _int, _i64, _vp]
         sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]
+        sig[f"fus_scale_{suf}"] = [ct, _vp, _vp, _i64, _vp]
         sig[f"fus_copy_{suf}"] = [_vp, _vp, _i64, _vp]
         sig[f"fus_fill_{suf}"] = [ct, _vp, _i64, _vp]
         sig[f"fus_pointwise_divide_{suf}"] = [_vp, _vp, _vp, _i64, _vp]

@@ -400,6 +400,9 @@ int fus_mass_apply_f32(const float* x, const float* c, float* y, const float* de
   int fus_axpy_##SUF(T alpha, const T* x, T* y, int64_t n, void* s) {                                         \
     return ew<T, fus::OpAxpy<T>, true, true>(x, y, y, n, fus::OpAxpy<T>{alpha}, s);                           \
   }                                                                                                           \
+  int fus_scale_##SUF(T alpha, const T* a, T* b, int64_t n, void* s) {                                        \
+    return ew<T, fus::OpScale<T>, true, false>(a, nullptr, b, n, fus::OpScale<T>{alpha}, s);                  \
+  }                                                                                                           \
   int fus_copy_##SUF(const T* a, T* b, int64_t n, void* s) {                                                  \
     return ew<T, fus::OpCopy<T>, true, false>(a, nullptr, b, n, fus::OpCopy<T>{}, s);                         \
   }                                                                                                           \

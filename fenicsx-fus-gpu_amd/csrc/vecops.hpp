@@ -27,6 +27,11 @@ struct OpAxpy {  // y = alpha x + y
   __device__ __forceinline__ T operator()(T a, T b) const { return alpha * a + b; }
 };
 template <typename T>
+struct OpScale {  // out = alpha a
+  T alpha;
+  __device__ __forceinline__ T operator()(T a, T) const { return alpha * a; }
+};
+template <typename T>
 struct OpCopy {  // out = a
   __device__ __forceinline__ T operator()(T a, T) const { return a; }
 };

@@ -210,9 +210,8 @@ class LinearSpectral3D:
 
     def _operator_fused(self, tn_or_t):
         gval = self.source_value(tn_or_t)
-        ops.fill(0.0, self.fc1_work)
         if self.fc1_work.numel():
-            ops.axpy[1, 1](gval, self.facet_coeff1, self.fc1_work)  # facet constants x g (x = 1 on the facets)
+            ops.scale(gval, self.facet_coeff1, self.fc1_work)  # facet constants x g (x = 1 on the facets)
 
         def facets():
             self.mass_facet(self.g, self.fc1_work, self.b, self.detJ_f1, self.fdm1)

@@ -111,9 +111,8 @@ class WesterveltSpectral3D:
 
     def _operator_fused(self, ts):
         gv, dgv = self.source_values(ts)
-        ops.fill(0.0, self.fc_src)
         if self.fc_src.numel():
-            ops.axpy[1, 1](gv, self.fc1_1, self.fc_src)   # M_f1(fc1_1) g + M_f1(fc2_1) dg
+            ops.scale(gv, self.fc1_1, self.fc_src)        # M_f1(fc1_1) g + M_f1(fc2_1) dg
             ops.axpy[1, 1](dgv, self.fc2_1, self.fc_src)  #   = M_f1(fc1_1 g + fc2_1 dg) 1
 
         def cells(c2, c3, c4, c5, G_, dJ_, dm_):

@@ -383,7 +383,21 @@ class _Square(_Launchable):
     __call__ = launch
 
 
+class _Scale(_Launchable):
+    """b = alpha a  (no reference kernel; the drivers here use it for per-stage facet constants)."""
+
+    @staticmethod
+    def launch(alpha, a, b):
+        fn, n = _vec("scale", a, b)
+        if b.numel() < n:
+            raise ValueError("scale: output shorter than input")
+        _lib.check(fn(float(alpha), a.data_ptr(), b.data_ptr(), n, _lib.stream_ptr()), "fus_scale")
+
+    __call__ = launch
+
+
 axpy = _Axpy()
+scale = _Scale()
 copy = _Copy()
 fill = _Fill()
 pointwise_divide = _PointwiseDivide()

@@ -138,6 +138,8 @@ int fus_fill_f64(double alpha, double* x, int64_t n, void* stream);             
 int fus_fill_f32(float alpha, float* x, int64_t n, void* stream);
 int fus_pointwise_divide_f64(const double* a, const double* b, double* c, int64_t n, void* stream); /* c = a / b */
 int fus_pointwise_divide_f32(const float* a, const float* b, float* c, int64_t n, void* stream);
+int fus_scale_f64(double alpha, const double* a, double* b, int64_t n, void* stream);          /* b = alpha a (no reference kernel: fill + axpy there) */
+int fus_scale_f32(float alpha, const float* a, float* b, int64_t n, void* stream);
 int fus_square_f64(const double* a, double* b, int64_t n, void* stream);                       /* b = a^2 */
 int fus_square_f32(const float* a, float* b, int64_t n, void* stream);
 

@@ -228,6 +228,8 @@ def test_vector_ops(gpu, oracle_c, dtype):
             _check(out.copy_to_host(), ah / bh, dtype, "divide")
             ops.square[1, 1](ad, out)
             _check(out.copy_to_host(), ah * ah, dtype, "square")
+            ops.scale(-2.5, ad, out)
+            _check(out.copy_to_host(), dtype(-2.5) * ah, dtype, "scale")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
