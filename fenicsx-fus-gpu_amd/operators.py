@@ -112,7 +112,7 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None):
         raise ValueError("entity_constants must have one value per entity")
     if nent == 0:
         return
-    if _USE_PLAN and n_per >= 2 and nent * n_per >= _MASS_PLAN_MIN_ENTRIES:
+    if _USE_PLAN and 2 <= n_per <= 4096 and nent * n_per >= _MASS_PLAN_MIN_ENTRIES:  # plan batches hold <= 4096 entries
         ws, epb = _PLANS.get(entity_dofmap)
         fn = getattr(lib, f"fus_mass_apply_planned_{_lib.suffix(dt)}")
         _lib.check(
