@@ -298,8 +298,6 @@ class BoxMesh:
     def dof_coordinates(self) -> np.ndarray:
         """Physical coordinates ``[ndofs, 3]`` of the local dofs (image of the
         reference GLL nodes under the trilinear geometry map)."""
-        from .precompute import tabulate_hex_p1_gradients  # noqa: F401  (same basis ordering)
-
         pts, _ = gll_points_weights(self.P)
         n = self.n
         X, Y, Z = np.meshgrid(pts, pts, pts, indexing="ij")

@@ -18,7 +18,6 @@ import torch
 
 from . import _lib
 from . import operators as ops
-from .gll import tabulate_1d, tensor_points_3d, tensor_weights_2d, tensor_weights_3d
 from .linear_solver import A_RUNGE, B_RUNGE, C_RUNGE
 from .linear_solver import device_geometry
 
