@@ -170,6 +170,15 @@ class BoxMesh:
         lid[...] = owned_idx
         gpos = np.nonzero(ghost_mask.reshape(-1))[0]  # lexicographic order in the full local grid
         nghost = gpos.size
+        if nghost:
+            # ghosts are numbered owner by owner (ascending rank), lexicographically inside an owner:
+            # the ghost block of a vector is then exactly the concatenation of the per-owner
+            # messages, so the halo exchange can receive into / send from it without an
+            # unpack / pack pass (scatterer._Scatter detects the identity index list)
+            gi_, gj_, gk_ = np.unravel_index(gpos, fdim)
+            orc = [rc[a] - ((np.array((gi_, gj_, gk_)[a]) == 0) & has_lower[a]).astype(np.int64) for a in range(3)]
+            gowner = (orc[0] * self.grid[1] + orc[1]) * self.grid[2] + orc[2]
+            gpos = gpos[np.argsort(gowner, kind="stable")]
         lid.reshape(-1)[gpos] = nlocal + np.arange(nghost, dtype=np.int32)
         self._lid = lid
         self.nlocal, self.nghost = nlocal, int(nghost)

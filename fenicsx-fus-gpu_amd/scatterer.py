@@ -136,17 +136,28 @@ class _Scatter:
         # send/recv buffers are owned by the closure and allocated once (cuda/scatterer.py:133-138)
         self.send = self.k.buffer(sum(self.send_counts))
         self.recv = self.k.buffer(sum(self.recv_counts))
+        # ghosts numbered owner by owner (BoxMesh does; a dolfinx mesh may not): the ghost block of
+        # the vector IS the message buffer of the owners' side -- receive into it (forward) / send
+        # from it (reverse) directly, no unpack_fwd / pack_rev launch
+        self.nghost = int(len(o_idx))
+        self.direct = self.nghost > 0 and bool(np.array_equal(np.asarray(o_idx), np.arange(self.nghost)))
         self.active = (sum(self.send_counts) + sum(self.recv_counts)) > 0 or comm.size > 1
 
     def begin(self, buffer):
         """Pack and post the exchange; returns a handle for ``end``."""
+        send, recv = self.send, self.recv
         if self.reverse:
-            self.k.pack_rev(buffer, self.send, self.o_idx, self.N)
+            if self.direct:
+                send = buffer[self.N : self.N + self.nghost]
+            else:
+                self.k.pack_rev(buffer, self.send, self.o_idx, self.N)
         else:
             self.k.pack_fwd(buffer, self.send, self.g_idx)
+            if self.direct:
+                recv = buffer[self.N : self.N + self.nghost]
         if self.comm.size == 1:
             return None
-        return self.comm.alltoallv(self.send, self.send_counts, self.recv, self.recv_counts, async_op=True)
+        return self.comm.alltoallv(send, self.send_counts, recv, self.recv_counts, async_op=True)
 
     def end(self, buffer, work):
         """Complete the exchange (stream-ordered for RCCL) and unpack."""
@@ -154,7 +165,7 @@ class _Scatter:
             work.wait()
         if self.reverse:
             self.k.unpack_rev(self.recv, buffer, self.g_idx)
-        else:
+        elif not self.direct:
             self.k.unpack_fwd(self.recv, buffer, self.o_idx, self.N)
 
     def __call__(self, buffer):

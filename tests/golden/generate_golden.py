@@ -104,6 +104,8 @@ def main():
         # numba-cpu/test_operators.py:274-279
         return 100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])
 
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter
+
     # ---- operator + precompute fixtures --------------------------------------
     cases = []
     for P in (2, 3, 4, 6):
@@ -113,7 +115,7 @@ def main():
                     if P == 6 and shape == (3, 2, 2):
                         continue  # keep the fixture set small
                     cases.append((P, shape, perturb, dt))
-    for P, shape, perturb, dt in cases:
+    for P, shape, perturb, dt in (cases if only in ("all", "ops") else []):
         n = P + 1
         mesh = boxmesh.BoxMesh(P, shape, perturb=perturb, seed=7, dtype=dt)
         pts, wts, D = gll.tabulate_1d(P, dt)
@@ -192,7 +194,8 @@ def main():
         print("wrote", tag, f"ncell={nc} ndofs={mesh.ndofs}")
 
     # ---- scatterer fixtures: reference closures on simulated ranks ------------
-    for P, shape, grid in ((2, (4, 2, 2), (2, 1, 1)), (3, (2, 4, 2), (1, 2, 1)), (2, (4, 4, 2), (2, 2, 1)), (2, (2, 2, 2), (2, 2, 2))):
+    scatter_cases = ((2, (4, 2, 2), (2, 1, 1)), (3, (2, 4, 2), (1, 2, 1)), (2, (4, 4, 2), (2, 2, 1)), (2, (2, 2, 2), (2, 2, 2)))
+    for P, shape, grid in (scatter_cases if only in ("all", "scatter") else []):
         R = int(np.prod(grid))
         meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r) for r in range(R)]
         od_all, gd_all = utils.compute_scatterer_data_all([m.index_map for m in meshes])
