@@ -79,3 +79,112 @@ def test_westervelt_bowl_pressure_field(oracle_c, P, cells, fused):
     assert np.max(np.abs(u_ref)) > 0
     assert rel_l2(s.u_sol(), u_ref) < 1e-11
     assert rel_l2(s.v_sol(), v_ref) < 1e-11
+
+
+def test_cuda_flavour_driver_calls_verbatim(oracle_c):
+    """The reference's CUDA driver, call for call (cuda/demo_linear_box.py:364-575): ``cuda.to_device``,
+    ``kernel[grid, block](...)`` launches with its launch configurations, 2-D ``dphi``, the
+    3-element scatter data (single rank: empty), ``copy_to_host`` -- on the package's device shim and
+    operators, against the oracle-side solver (source evaluated at ``t`` like the CUDA demos)."""
+    boxmesh, gll, pre = pkg("boxmesh"), pkg("gll"), pkg("precompute")
+    cuda = pkg("device")
+    ops, sc, utils = pkg("operators"), pkg("scatterer"), pkg("utils")
+    mass_operator, stiffness_operator = ops.mass_operator, ops.stiffness_operator
+    axpy, copy, fill, pointwise_divide = ops.axpy, ops.copy, ops.fill, ops.pointwise_divide
+    cuda.select_device(0)
+    float_type = np.float64
+    basis_degree, L = 3, 0.012
+    nd = basis_degree + 1
+    mesh = boxmesh.BoxMesh(basis_degree, (4, 3, 3), length=L)
+    speed_of_sound, density, source_frequency, source_amplitude = 1500.0, 1000.0, 0.5e6, 60000.0
+    angular_frequency = 2 * np.pi * source_frequency
+    dofmap, num_cells = mesh.dofmap, mesh.ncells
+    nlocal, ndofs = mesh.nlocal, mesh.ndofs
+    owners_data, ghosts_data = utils.compute_scatterer_data(mesh.index_map)
+
+    class _SelfComm:  # one rank: nothing to exchange
+        rank, size = 0, 1
+
+    scatter_rev = sc.scatter_reverse(_SelfComm(), owners_data, ghosts_data, nlocal, float_type)
+    scatter_fwd = sc.scatter_forward(_SelfComm(), owners_data, ghosts_data, nlocal, float_type)
+    pts, wts, dphi_1D = gll.tabulate_1d(basis_degree)
+    w3, w2 = gll.tensor_weights_3d(wts), gll.tensor_weights_2d(wts)
+    dphi = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))
+    nq = w3.size
+    detJ = np.zeros((num_cells, nq))
+    G = np.zeros((num_cells, nq, 6))
+    pre.compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), num_cells, dphi, w3)
+    pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), num_cells, dphi, w3)
+    bd1, bd2 = mesh.boundary_facets([2]), mesh.boundary_facets([3])
+    dphi_f = pre.tabulate_facet_gradients(pts)
+    detJ_f1, detJ_f2 = np.zeros((bd1.shape[0], nd * nd)), np.zeros((bd2.shape[0], nd * nd))
+    pre.compute_boundary_facets_scaled_jacobian_determinant(detJ_f1, (mesh.x_dofs, mesh.x_g), bd1, dphi_f, w2)
+    pre.compute_boundary_facets_scaled_jacobian_determinant(detJ_f2, (mesh.x_dofs, mesh.x_g), bd2, dphi_f, w2)
+    bfacet_dofmap1, bfacet_dofmap2 = mesh.facet_dofmap(bd1), mesh.facet_dofmap(bd2)
+    cell_coeff1 = np.full(num_cells, 1.0 / density / speed_of_sound**2)
+    cell_coeff2 = np.full(num_cells, -1.0 / density)
+    facet_coeff1 = np.full(bd1.shape[0], 1.0 / density)
+    facet_coeff2 = np.full(bd2.shape[0], -1.0 / density / speed_of_sound)
+
+    # ---- host to device (:364-385) ----
+    cell_coeff1_d, cell_coeff2_d = cuda.to_device(cell_coeff1), cuda.to_device(cell_coeff2)
+    dofmap_d, detJ_d, G_d, dphi_1D_d = cuda.to_device(dofmap), cuda.to_device(detJ), cuda.to_device(G), cuda.to_device(dphi_1D)
+    facet_coeff1_d, facet_coeff2_d = cuda.to_device(facet_coeff1), cuda.to_device(facet_coeff2)
+    bfacet_dofmap1_d, bfacet_dofmap2_d = cuda.to_device(bfacet_dofmap1), cuda.to_device(bfacet_dofmap2)
+    detJ_f1_d, detJ_f2_d = cuda.to_device(detJ_f1), cuda.to_device(detJ_f2)
+    zeros = np.zeros(ndofs)
+    u_t_d, g_d, u_n_d, v_n_d, m_d, b_d = (cuda.to_device(zeros) for _ in range(6))
+    # ---- launch configurations exactly as the demo computes them (:389-410); ignored by the library ----
+    threadsperblock_m = 128
+    num_blocks_m = (dofmap.size + (threadsperblock_m - 1)) // threadsperblock_m
+    num_blocks_f1 = (bfacet_dofmap1.size + (threadsperblock_m - 1)) // threadsperblock_m
+    num_blocks_f2 = (bfacet_dofmap2.size + (threadsperblock_m - 1)) // threadsperblock_m
+    threadsperblock_s, num_blocks_s = (nd, nd, nd), num_cells
+    threadsperblock_dofs = 1024
+    num_blocks_dofs = (ndofs + (threadsperblock_dofs - 1)) // threadsperblock_dofs
+    stiff_operator_cell = stiffness_operator(basis_degree, float_type)
+    # ---- LHS (:421-428) ----
+    fill[num_blocks_dofs, threadsperblock_dofs](1.0, u_t_d)
+    fill[num_blocks_dofs, threadsperblock_dofs](0.0, m_d)
+    mass_operator[num_blocks_m, threadsperblock_m](u_t_d, cell_coeff1_d, m_d, detJ_d, dofmap_d)
+    cuda.synchronize()
+    scatter_rev(m_d)
+    # ---- RK4 (:437-566) ----
+    a_runge, b_runge, c_runge = [0.0, 0.5, 0.5, 1.0], [1 / 6, 1 / 3, 1 / 3, 1 / 6], [0.0, 0.5, 0.5, 1.0]
+    u_d, v_d, un_d, vn_d, u0_d, v0_d, ku_d, kv_d = (cuda.to_device(zeros) for _ in range(8))
+    h = pkg("linear_solver").time_step_parameters(mesh, basis_degree, speed_of_sound, source_frequency, L)
+    dt, _, _ = pkg("linear_solver").snap_time_step(h, basis_degree, speed_of_sound, source_frequency, L)
+    t, nsteps = 0.0, 6
+    for _ in range(nsteps):
+        copy[num_blocks_dofs, threadsperblock_dofs](u_d, u0_d)
+        copy[num_blocks_dofs, threadsperblock_dofs](v_d, v0_d)
+        for i in range(4):
+            copy[num_blocks_dofs, threadsperblock_dofs](u0_d, un_d)
+            copy[num_blocks_dofs, threadsperblock_dofs](v0_d, vn_d)
+            axpy[num_blocks_dofs, threadsperblock_dofs](a_runge[i] * dt, ku_d, un_d)
+            axpy[num_blocks_dofs, threadsperblock_dofs](a_runge[i] * dt, kv_d, vn_d)
+            copy[num_blocks_dofs, threadsperblock_dofs](vn_d, ku_d)
+            T, alpha = 1 / source_frequency, 4.0
+            window = 0.5 * (1.0 - np.cos(source_frequency * np.pi * t / alpha)) if t < T * alpha else 1.0
+            g_vals = window * source_amplitude * angular_frequency / speed_of_sound * np.cos(angular_frequency * t)
+            fill[num_blocks_dofs, threadsperblock_dofs](g_vals, g_d)
+            copy[num_blocks_dofs, threadsperblock_dofs](un_d, u_n_d)
+            copy[num_blocks_dofs, threadsperblock_dofs](vn_d, v_n_d)
+            cuda.synchronize()
+            scatter_fwd(u_n_d)
+            scatter_fwd(v_n_d)
+            fill[num_blocks_dofs, threadsperblock_dofs](0.0, b_d)
+            stiff_operator_cell[num_blocks_s, threadsperblock_s](u_n_d, cell_coeff2_d, b_d, G_d, dofmap_d, dphi_1D_d)
+            mass_operator[num_blocks_f1, threadsperblock_m](g_d, facet_coeff1_d, b_d, detJ_f1_d, bfacet_dofmap1_d)
+            mass_operator[num_blocks_f2, threadsperblock_m](v_n_d, facet_coeff2_d, b_d, detJ_f2_d, bfacet_dofmap2_d)
+            cuda.synchronize()
+            scatter_rev(b_d)
+            pointwise_divide[num_blocks_dofs, threadsperblock_dofs](b_d, m_d, kv_d)
+            axpy[num_blocks_dofs, threadsperblock_dofs](b_runge[i] * dt, ku_d, u_d)
+            axpy[num_blocks_dofs, threadsperblock_dofs](b_runge[i] * dt, kv_d, v_d)
+        t += dt
+    cuda.synchronize()
+    u_host = u_d.copy_to_host()
+    u_ref, _ = rk4_oracle.solve(mesh, nsteps, dt, source_time="t", oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 0
+    assert rel_l2(u_host, u_ref) < 1e-11
