@@ -174,10 +174,17 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
+  int av = g_plan_variant.load(std::memory_order_relaxed);
+  if (av < 40 || av > 42) av = (P <= 4) ? 40 : 41;  // auto: unpadded 5-waves build up to P = 4 (+8 %, profiles/r01f_affine_fast_path.log)
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan<T, PP, true, true, 1, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); \
+    switch (av) {                                                                                        \
+      case 40: e = fus::launch_stiffness_plan<T, PP, true, false, 5, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break; \
+      case 41: e = fus::launch_stiffness_plan<T, PP, true, true, 5, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break;  \
+      case 42: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break; \
+      default: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break;  \
+    }                                                                                                    \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)

@@ -308,7 +308,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   int32_t mydof[SPT];
   const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
   uint16_t sl[n];
-  T g[n][6];
+  T g[(GMODE & 64) ? 1 : n][6];
+  T wr_aff[(GMODE & 64) ? n : 1];
   T coeff = T(0);
   if (active) {
     const uint16_t* sp = slot + cell * Nd + t;
@@ -318,14 +319,11 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       // affine cells (opt-in): the geometric factor of an affine cell is one
       // symmetric 3x3 matrix times the quadrature weight, G[c][q] = G[c][0] * (w_q / w_0), so only
       // the first record of the cell (48 B instead of 48 n^3 B) is read
-      T g0[6];
-      load_g6<T>(G + cell * Nd * 6, g0);
+      // g[0] holds the cell's record, g[1][0..n-1 mod 6]... (see phase 1): only 6 + n values are
+      // kept live, the per-slab factors are formed where they are used
+      load_g6<T>(G + cell * Nd * 6, g[0]);
 #pragma unroll
-      for (int ix = 0; ix < n; ++ix) {
-        const T wr = wratio[ix * n2 + t];
-#pragma unroll
-        for (int k = 0; k < 6; ++k) g[ix][k] = g0[k] * wr;
-      }
+      for (int ix = 0; ix < n; ++ix) wr_aff[ix] = wratio[ix * n2 + t];
     } else if constexpr (GMODE & 8) {  // ABLATION (timing only): no G loads
 #pragma unroll
       for (int ix = 0; ix < n; ++ix)
@@ -408,9 +406,17 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
         vy += dy[i] * cu_y[qx * n2 + i * n];
         vz += dz[i] * cu_z[qx * n2 + i];
       }
-      if constexpr ((GMODE & 32) != 0)  // stream this slab of G now (fewer live registers)
-        load_g6<T>(G + (cell * Nd + t) * 6 + (int64_t)qx * n2 * 6, g[qx]);
-      const T* gq = g[qx];
+      T gq[6];
+      if constexpr ((GMODE & 64) != 0) {
+        const T cw = wr_aff[qx];
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gq[k] = g[0][k] * cw;
+      } else {
+        if constexpr ((GMODE & 32) != 0)  // stream this slab of G now (fewer live registers)
+          load_g6<T>(G + (cell * Nd + t) * 6 + (int64_t)qx * n2 * 6, g[qx]);
+#pragma unroll
+        for (int k = 0; k < 6; ++k) gq[k] = g[(GMODE & 64) ? 0 : qx][k];
+      }
       fx[qx] = coeff * (gq[0] * vx + gq[1] * vy + gq[2] * vz);
       cfy[qx * n2] = coeff * (gq[1] * vx + gq[3] * vy + gq[4] * vz);
       cfz[qx * n2] = coeff * (gq[2] * vx + gq[4] * vy + gq[5] * vz);

@@ -67,8 +67,12 @@ def main():
             if a.affine:
                 gll = fusgpu_loader.submodule("gll")
                 opa = ops.stiffness_operator(P, pb["D"].flatten(), dt, affine_weights=gll.tensor_weights_3d(pb["wts"]))
-                t = timeit(lambda: opa(x, cc, y, G, dm))
-                res.append(f"K[affine fast path] {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s")
+                lib = fusgpu_loader.submodule("_lib")
+                for av in (-1, 40, 42, -1, 40, 42):  # builds of the affine kernel, interleaved twice
+                    lib.set_tuning(lib.TUNE_PLAN_VARIANT, av)
+                    t = timeit(lambda: opa(x, cc, y, G, dm))
+                    res.append(f"K[affine build {av}] {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s")
+                lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
             t = timeit(lambda: mop(x, cc, y, detJ, dm))
             gbs = mesh.ncells * mass_bytes_per_cell(P, T) / (t * 1e-3) / 1e9
             res.append(f"M {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s {100 * gbs / 8000:5.1f}%")
