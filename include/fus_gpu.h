@@ -4,8 +4,10 @@
  *
  * The reference has no FFI of its own: its "boundary" is the numba JIT call of Python closures.
  * Every entry point below names the reference interface it replaces (file:line, relative to the
- * reference checkout).  All pointers are DEVICE pointers (plain HIP allocations); all buffers are
- * caller-owned; nothing is allocated, freed or synchronised per call; every launch is asynchronous
+ * reference checkout).  All pointers are DEVICE pointers to ordinary (coarse-grained) device
+ * allocations -- hipMalloc / torch tensors; the scatter-adds use the hardware floating-point atomics
+ * (global_atomic_add_f64/f32), which are not defined on fine-grained or host-mapped memory.  All
+ * buffers are caller-owned; nothing is allocated, freed or synchronised per call; every launch is asynchronous
  * on ``stream`` (a hipStream_t passed as void*, NULL = the default stream).
  *
  * Return value: FUS_OK (0) or a negative error code; fus_error_string() describes it.
