@@ -12,7 +12,19 @@ B = (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0)
 C = (0.0, 0.5, 0.5, 1.0)
 
 
+def step_sizes(t0, tf, dt):
+    """The reference's time loop (``while t < tf: dt = min(dt, tf - t); ...; t += dt``,
+    cuda/demo_linear_box.py:487-488,566): the last step may be shorter."""
+    out, t = [], float(t0)
+    while t < tf:
+        dt = min(dt, tf - t)
+        out.append(dt)
+        t += dt
+    return out
+
+
 def solve(mesh, nsteps, dt, c0=1500.0, rho0=1000.0, f0=0.5e6, p0=60000.0, source_time="tn", oracle_c=None):
+    """``dt`` may be a sequence of per-step sizes (then ``nsteps`` is ignored)."""
     gll, pre = pkg("gll"), pkg("precompute")
     P, n = mesh.P, mesh.P + 1
     pts, wts, D = gll.tabulate_1d(P)
@@ -54,7 +66,8 @@ def solve(mesh, nsteps, dt, c0=1500.0, rho0=1000.0, f0=0.5e6, p0=60000.0, source
     u, v = np.zeros(nd), np.zeros(nd)
     ku, kv = np.zeros(nd), np.zeros(nd)
     t = 0.0
-    for _ in range(nsteps):
+    dts = list(dt) if hasattr(dt, "__len__") else [dt] * nsteps
+    for dt in dts:
         u0, v0 = u.copy(), v.copy()
         for i in range(4):
             un = u0 + A[i] * dt * ku

@@ -188,3 +188,25 @@ def test_cuda_flavour_driver_calls_verbatim(oracle_c):
     u_ref, _ = rk4_oracle.solve(mesh, nsteps, dt, source_time="t", oracle_c=oracle_c)
     assert np.max(np.abs(u_ref)) > 0
     assert rel_l2(u_host, u_ref) < 1e-11
+
+
+def test_linear_box_complete_run(oracle_c):
+    """A complete demo_linear_box run (start to final time, 400+ RK4 steps, source ramp included) on a
+    small box: fused GPU solver vs the oracle-side solver, pressure field at the final time."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls = pkg("boxmesh"), pkg("linear_solver")
+    P, N, L = 3, 5, 0.012
+    mesh = boxmesh.BoxMesh(P, N, length=L)
+    h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dt, tf, nstep = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    solver = ls.LinearSpectral3D(mesh, np.float64, fused=True)
+    solver.init()
+    t, steps = solver.rk4(0.0, tf, dt)
+    dts = rk4_oracle.step_sizes(0.0, tf, dt)  # same loop as the reference: the last step may be shorter
+    assert steps == len(dts) and abs(t - tf) < 1e-12 and steps >= nstep - 1
+    u_ref, v_ref = rk4_oracle.solve(mesh, steps, dts, oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 1e3  # the wave has crossed the box
+    assert rel_l2(solver.u_sol(), u_ref) < 1e-10
+    assert rel_l2(solver.v_sol(), v_ref) < 1e-10
