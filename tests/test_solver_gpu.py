@@ -191,7 +191,7 @@ def test_cuda_flavour_driver_calls_verbatim(oracle_c):
 
 
 def test_linear_box_complete_run(oracle_c):
-    """A complete demo_linear_box run (start to final time, 400+ RK4 steps, source ramp included) on a
+    """A complete demo_linear_box run (start to final time, ~66 RK4 steps, source ramp and the shorter last step included) on a
     small box: fused GPU solver vs the oracle-side solver, pressure field at the final time."""
     import torch
 
