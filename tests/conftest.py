@@ -25,6 +25,10 @@ def pytest_configure(config):
 
         subprocess.run(["make", "-C", os.path.dirname(lib), "libfusgpu.so"], check=False, capture_output=True)
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_build/libfus_oracle.so"], check=False, capture_output=True)
+    if os.path.isdir("/root/reference") and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_sumfact.so")):
+        import subprocess
+
+        subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=False, capture_output=True)
 
 
 def pkg(name):
