@@ -118,6 +118,7 @@ int64_t plan_bytes(int P, int64_t ncell) {
       case 17: e = fus::launch_stiffness_plan<T, PP, true, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 18: e = fus::launch_stiffness_plan<T, PP, true, true, 6>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 19: e = fus::launch_stiffness_plan<T, PP, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 24: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 14: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 15: e = fus::launch_stiffness_plan<T, PP, true, false, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 16: e = fus::launch_stiffness_plan<T, PP, true, false, 5, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \

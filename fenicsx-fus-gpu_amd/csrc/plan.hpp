@@ -369,7 +369,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       cu[ix * n2] = u[ix];
     }
   }
-  __syncthreads();
+  if constexpr ((GMODE & 128) == 0) __syncthreads();  // (GMODE & 128: barrier ablation, timing only)
 
   if constexpr (!ALIAS) {  // all reads of the x values are done: the buffer becomes the y accumulator
 #pragma unroll
@@ -422,7 +422,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       cfz[qx * n2] = coeff * (gq[2] * vx + gq[4] * vy + gq[5] * vz);
     }
   }
-  __syncthreads();
+  if constexpr ((GMODE & 128) == 0) __syncthreads();
   if constexpr (ALIAS) {  // the u cube is dead: zero it as the y accumulator
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
