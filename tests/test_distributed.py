@@ -68,7 +68,8 @@ def check(res, x_ser, y_ser):
 
 
 @pytest.mark.parametrize("overlap", [1, 0], ids=["overlap", "sequential"])
-@pytest.mark.parametrize("P,cells,grid", [(2, (4, 3, 2), (2, 1, 1)), (3, (4, 4, 2), (2, 2, 1))], ids=["2ranks", "4ranks"])
+@pytest.mark.parametrize("P,cells,grid", [(2, (4, 3, 2), (2, 1, 1)), (3, (4, 4, 2), (2, 2, 1)), (2, (4, 4, 4), (2, 2, 2))],
+                         ids=["2ranks", "4ranks", "8ranks"])
 def test_partitioned_apply_gloo_cpu(tmp_path, oracle_c, P, cells, grid, overlap):
     res = run_ranks("cpu", tmp_path, P, cells, grid, overlap)
     check(res, *serial_reference(P, cells, oracle_c))
