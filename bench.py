@@ -220,6 +220,8 @@ def main():
     if world != args.gpus:
         if world == 1 and args.gpus > 1:
             raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
+    ndev = max(torch.cuda.device_count(), 1)
+    local_rank = local_rank % ndev  # a launcher that masks devices per rank leaves one visible device
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     force_dist = os.environ.get("FUS_BENCH_FORCE_DIST", "0") == "1"  # exercise the N > 1 code path in a 1-rank world

@@ -39,7 +39,7 @@ def main():
 
     boxmesh, ls, scat = (fusgpu_loader.submodule(m) for m in ("boxmesh", "linear_solver", "scatterer"))
     rank, world = int(os.environ.get("RANK", "0")), int(os.environ.get("WORLD_SIZE", "1"))
-    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+    torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % max(torch.cuda.device_count(), 1))
     comm = None
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
