@@ -342,6 +342,33 @@ def main():
     else:
         kern_ms = float(ev_ms.mean())  # N = 1: the step IS the stiffness kernel launch
 
+    # measured streaming ceiling of THIS device (outside the timed region): copy of 1 GiB -> 1 GiB
+    # with the library's copy kernel (working set far beyond the 256 MiB Infinity Cache)
+    copy_gbs = read_gbs = None
+    try:
+        nel = (1 << 30) // 8
+        src = torch.empty(nel, dtype=torch.float64, device=device).fill_(1.0)
+        dst = torch.empty_like(src)
+        ops.copy(src, dst)
+        c0, c1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        c0.record()
+        for _ in range(5):
+            ops.copy(src, dst)
+        c1.record()
+        torch.cuda.synchronize()
+        copy_gbs = 2 * nel * 8 * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        # read-only stream (the stiffness kernel is ~90 % reads): torch's reduction over 1 GiB
+        src.sum()
+        c0.record()
+        for _ in range(5):
+            src.sum()
+        c1.record()
+        torch.cuda.synchronize()
+        read_gbs = nel * 8 * 5 / (c0.elapsed_time(c1) * 1e-3) / 1e9
+        del src, dst
+    except Exception as e:  # never let the side measurement break the bench line
+        log(f"copy ceiling measurement failed: {e!r}")
+
     ndofs_global = mesh.ndofs_global
     value = ndofs_global / (elapsed / args.steps)
     bpc = stiffness_bytes_per_cell(P, T)
@@ -387,6 +414,8 @@ def main():
             "algorithmic_bytes_per_cell": bpc,
             "cells_per_launch": mesh.ncells,
             "pct_of_hbm_roofline_dofs": 100.0 * achieved / HBM_PEAK_GBS,
+            "measured_copy_gbs": copy_gbs,   # 1 GiB -> 1 GiB with fus_copy (read + write bytes)
+            "measured_read_gbs": read_gbs,   # 1 GiB read-only reduction (torch.sum)
         },
     }
     if rank == 0:
