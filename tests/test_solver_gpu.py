@@ -210,3 +210,23 @@ def test_linear_box_complete_run(oracle_c):
     assert np.max(np.abs(u_ref)) > 1e3  # the wave has crossed the box
     assert rel_l2(solver.u_sol(), u_ref) < 1e-10
     assert rel_l2(solver.v_sol(), v_ref) < 1e-10
+
+
+def test_driver_scripts_run(tmp_path):
+    """The demo_linear_box / time_operators counterparts stay runnable end to end."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    pkgdir = os.path.join(ROOT, "fenicsx-fus-gpu_amd")
+    out = os.path.join(tmp_path, "plane.npz")
+    r = subprocess.run([sys.executable, os.path.join(pkgdir, "demo_linear_box.py"), "--cells", "6", "--degree", "3",
+                        "--max-steps", "5", "--out", out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "Solve time per step" in r.stdout, r.stdout + r.stderr
+    d = np.load(out)
+    assert d["u"].size == (3 * 6 + 1) ** 2 and int(d["steps"]) == 5
+    r = subprocess.run([sys.executable, os.path.join(pkgdir, "time_operators.py"), "--degree", "2", "--cells", "6",
+                        "--nreps", "3"], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and r.stdout.count("Elapsed time") == 3, r.stdout + r.stderr
