@@ -39,6 +39,7 @@ def _signatures():
         sig[f"fus_stiffness_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_stiffness_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_stiffness_apply_planned_affine_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
+        sig[f"fus_stiffness_apply_planned_geom_{suf}"] = [_vp] * 9 + [_int, _i64, _vp]
         sig[f"fus_mass_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _int, _i64, _vp]
         sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]
@@ -66,7 +67,6 @@ TUNE_XCD_REMAP = 2
 TUNE_MASS_VARIANT = 3
 TUNE_PLAN_VARIANT = 4
 TUNE_PLAN_RUNS = 5
-TUNE_PLAN_THREADS = 6
 
 _lib = None
 

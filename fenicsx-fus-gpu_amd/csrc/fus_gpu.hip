@@ -12,11 +12,11 @@
 #include "halo.hpp"
 #include "mass.hpp"
 #include "plan.hpp"
-#ifdef FUS_EXPERIMENTS
-#include "experimental/plan_persistent.hpp"
-#endif
 #include "rk4.hpp"
 #include "stiffness.hpp"
+#include "stiffness_affine.hpp"
+#include "stiffness_geom.hpp"
+#include "stiffness_plan.hpp"
 #include "vecops.hpp"
 #include "westervelt.hpp"
 
@@ -26,14 +26,12 @@ std::atomic<int> g_stiffness_variant{0};
 std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab_variants.log)
 std::atomic<int> g_mass_variant{0};
 std::atomic<int> g_plan_runs{1};  // 0 never, 1 auto, 2 always
-std::atomic<int> g_plan_threads{256};  // workgroup size the cell batches are cut for (256 or 128)
 
 // Run-length coded dof lists pay off where the index stream is a large share of the bytes
 // (P <= 3: +6 % at P = 2) and cost an extra barrier + LDS search elsewhere (P = 4 neutral,
 // P = 6 -12 %): profiles/r01d_ab_plan_runs.log.
 inline int plan_allow_runs(int ndof_per_entity) {
   const int mode = g_plan_runs.load(std::memory_order_relaxed);
-  if (g_plan_threads.load(std::memory_order_relaxed) < 256) return 0;  // 128-thread builds read raw plans only
   return mode == 2 ? 1 : (mode == 1 ? (ndof_per_entity <= 64) : 0);
 }
 std::atomic<int> g_plan_variant{-1};  // -1 = auto
@@ -98,35 +96,15 @@ int64_t plan_bytes(int P, int64_t ncell) {
   return FUS_ERR_UNSUPPORTED_DEGREE;
 }
 
-// Experimental builds of the planned kernel (layout / ablation / persistent studies recorded in
-// profiles/r01d_*.log); compiled only with -DFUS_EXPERIMENTS (make EXPERIMENTS=1), selected with
-// FUS_TUNE_PLAN_VARIANT by tools/ab_stiffness.py.
-#ifdef FUS_EXPERIMENTS
-#define FUS_EXPERIMENT_CASES(PP) \
-      case 4: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 5: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 2>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 6: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 7: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 8>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 8: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 6>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 9: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 14>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 12: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 16>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 13: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 16>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 20: e = fus::launch_stiffness_plan_persistent<T, PP, false, 3>(x, cc, y, G, ws, dphi, ncell, 3, s); break; \
-      case 21: e = fus::launch_stiffness_plan_persistent<T, PP, true, 4>(x, cc, y, G, ws, dphi, ncell, 4, s); break;  \
-      case 22: e = fus::launch_stiffness_plan_persistent<T, PP, true, 3>(x, cc, y, G, ws, dphi, ncell, 3, s); break;  \
-      case 23: e = fus::launch_stiffness_plan_persistent<T, PP, false, 1>(x, cc, y, G, ws, dphi, ncell, 2, s); break; \
-      case 17: e = fus::launch_stiffness_plan<T, PP, true, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 18: e = fus::launch_stiffness_plan<T, PP, true, true, 6>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 19: e = fus::launch_stiffness_plan<T, PP, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 24: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 14: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 15: e = fus::launch_stiffness_plan<T, PP, true, false, 1, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 16: e = fus::launch_stiffness_plan<T, PP, true, false, 5, 32>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 10: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 0, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 11: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 0, 128>(x, cc, y, G, ws, dphi, ncell, remap, s); break;
-#else
-#define FUS_EXPERIMENT_CASES(PP)
-#endif
+// fp32 build with 5 waves per SIMD (only instantiated for float)
+template <typename T, int P>
+hipError_t launch_plan_f32_5w(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int64_t ncell,
+                              int remap, hipStream_t s) {
+  if constexpr (sizeof(T) == 4 && P <= 4)
+    return fus::launch_stiffness_plan<T, P, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s);
+  else
+    return fus::launch_stiffness_plan<T, P, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s);
+}
 
 template <typename T>
 int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int P,
@@ -139,22 +117,25 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
+  // Builds (profiles/r01d_ab_alias_by_degree.log, r02*_ab_*.log; pinned by tests/test_resource_usage.py):
+  //   0  three LDS cubes + own x/y buffer           (P <= 3)
+  //   1  LDS-aliased, whole G slab issued up front  (P = 4, 5: 4 workgroups per CU at P = 4)
+  //   2  LDS-aliased, ring of G slabs               (P >= 6: registers are the binding limit there)
+  //   30 fp32, registers allow 5 waves per SIMD     (fp32, P <= 4)
   int pv = g_plan_variant.load(std::memory_order_relaxed);
-  if (pv < 0) {  // auto (profiles/r01d_ab_alias_by_degree.log, r01d_ablation_and_experiments.log)
+  if (pv < 0) {
     if (sizeof(T) == 4 && P <= 4)
-      pv = 30;  // fp32: registers allow 5 waves/SIMD (+9 %)
+      pv = 30;
     else
-      pv = (P >= 4) ? 1 : 0;  // LDS-aliased build from P = 4 up
+      pv = (P >= 6) ? 2 : ((P >= 4) ? 1 : 0);
   }
   switch (P) {
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
       case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, 3>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
-      case 3: e = fus::launch_stiffness_plan<T, PP, true, false, 4>(x, cc, y, G, ws, dphi, ncell, remap, s); break;  \
-      case 30: e = fus::launch_stiffness_plan<T, PP, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-FUS_EXPERIMENT_CASES(PP)                                                                             \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, 1, fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
     }                                                                                                     \
     break;
@@ -175,17 +156,34 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
-  int av = g_plan_variant.load(std::memory_order_relaxed);
-  if (av < 40 || av > 42) av = (P <= 4) ? 40 : 41;  // auto: unpadded 5-waves build up to P = 4 (+8 %, profiles/r01f_affine_fast_path.log)
+  // P <= 4: unpadded LDS + 5 waves per SIMD (+8 %, profiles/r01f_affine_fast_path.log); above, registers do
+  // not allow 5 waves without spilling: padded build, compiler's own allocation
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    switch (av) {                                                                                        \
-      case 40: e = fus::launch_stiffness_plan<T, PP, true, false, 5, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break; \
-      case 41: e = fus::launch_stiffness_plan<T, PP, true, true, 5, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break;  \
-      case 42: e = fus::launch_stiffness_plan<T, PP, false, true, 1, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break; \
-      default: e = fus::launch_stiffness_plan<T, PP, true, true, 1, 64>(x, cc, y, G, ws, dphi, ncell, 0, s, wratio); break;  \
-    }                                                                                                    \
+    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s); \
+    break;
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return hip_rc(e);
+}
+
+template <typename T>
+int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs, const T* pts,
+                                 const T* wts, const void* ws, const T* dphi, int P, int64_t ncell, void* stream) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
+  if (ncell == 0) return FUS_OK;
+  if (!x || !cc || !y || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipErrorInvalidValue;
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>()>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -290,13 +288,6 @@ int fus_set_tuning(int key, int value) {
     case FUS_TUNE_MASS_VARIANT: g_mass_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_VARIANT: g_plan_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_RUNS: g_plan_runs = value; return FUS_OK;
-    case FUS_TUNE_PLAN_THREADS:
-#ifdef FUS_EXPERIMENTS
-      g_plan_threads = (value == 128) ? 128 : 256;
-      return FUS_OK;
-#else
-      return value == 256 ? FUS_OK : FUS_ERR_INVALID_ARGUMENT;  // only the experimental builds 10/11 read 128-thread plans
-#endif
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -308,7 +299,6 @@ int fus_get_tuning(int key) {
     case FUS_TUNE_MASS_VARIANT: return g_mass_variant;
     case FUS_TUNE_PLAN_VARIANT: return g_plan_variant;
     case FUS_TUNE_PLAN_RUNS: return g_plan_runs;
-    case FUS_TUNE_PLAN_THREADS: return g_plan_threads;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -362,8 +352,7 @@ int fus_plan_entities_per_batch(int N) {
   // cells (N = n^3): the stiffness kernel's batch size, so one plan serves both operators
   for (int P = FUS_MIN_DEGREE; P <= FUS_MAX_DEGREE; ++P)
     if ((P + 1) * (P + 1) * (P + 1) == N) {
-      const int tgt = g_plan_threads.load(std::memory_order_relaxed);
-      return tgt / ((P + 1) * (P + 1)) > 0 ? tgt / ((P + 1) * (P + 1)) : 1;
+      return 256 / ((P + 1) * (P + 1)) > 0 ? 256 / ((P + 1) * (P + 1)) : 1;
     }
   const int epb = 1280 / N;  // ~5 entries per thread of a 256-thread workgroup
   return epb > 0 ? epb : 1;
@@ -467,6 +456,16 @@ FUS_GEOM(float, f32)
 FUS_AFFINE(double, f64)
 FUS_AFFINE(float, f32)
 #undef FUS_AFFINE
+
+#define FUS_GEOMK(T, SUF)                                                                                        \
+  int fus_stiffness_apply_planned_geom_##SUF(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs, \
+                                             const T* pts, const T* wts, const void* ws, const T* dphi, int P,   \
+                                             int64_t ncell, void* s) {                                           \
+    return stiffness_apply_planned_geom<T>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, P, ncell, s);              \
+  }
+FUS_GEOMK(double, f64)
+FUS_GEOMK(float, f32)
+#undef FUS_GEOMK
 
 #define FUS_WEST(T, SUF)                                                                                          \
   int fus_westervelt_cell_apply_planned_##SUF(const T* u, const T* v, const T* c2, const T* c3, const T* c4,      \

@@ -1,0 +1,197 @@
+// Planned stiffness apply with the geometric factor formed IN THE KERNEL from the cell's 8 vertices
+// (second half): no G stream at all.  Reported as its own line with its own bytes
+// contract (bench.py --mode stiffness_geom), never mixed into the headline, whose contract is the
+// general G array.
+//
+// Same formulas and conventions as the reference's host precompute
+//   numba-cpu/precompute.py:115-163  compute_scaled_geometrical_factor
+// (J_[a][d] = sum_v dphi[a][q][v] X[v][d], G = w |det J_| inv(J_)^T inv(J_) upper triangle, indexed
+// by reference directions), specialised to what its callers pass: P1 (trilinear, 8-vertex)
+// hexahedra, vertex v = vx + 2 vy + 4 vz, and the tensor GLL rule q = qx n^2 + qy n + qz
+// (numba-cpu/test_operators.py:98-107).  For a trilinear map the three rows of J_ along a column
+// (qy, qz fixed -- exactly what one thread owns) are
+//   J_[0] = bilinear in (xi_y, xi_z) of the x-edge vectors            -- constant along the column
+//   J_[1] = (1 - xi_x) A + xi_x B,   J_[2] = (1 - xi_x) C + xi_x D    -- linear in xi_x
+// so a thread keeps 15 values instead of the 6 n of the G slab and forms adj(J_), det and the six
+// entries of G per quadrature point in registers (~60 flops on top of the ~80 of the contractions;
+// the kernel stays far below the fp64 vector peak).  The 24 vertex coordinates of each cell are
+// gathered once per cell into LDS (x_dofs -> x_g, one value per thread) alongside the x gather.
+#pragma once
+
+#include "stiffness_plan.hpp"
+
+namespace fus {
+
+// Occupancy hint of the shipped builds (waves per SIMD the register allocation must allow).
+template <typename T, int P>
+__host__ __device__ constexpr int geom_min_waves() {
+  return 1;
+}
+
+template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW>
+__global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
+    stiffness_plan_geom_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
+                               const T* __restrict__ x_g, const int32_t* __restrict__ x_dofs,
+                               const T* __restrict__ pts, const T* __restrict__ wts,
+                               const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
+                               const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell) {
+  using Sh = PlanShape<T, P, CPB, PADLDS>;
+  constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
+  constexpr int VPT = (CPB * 24 + BLOCK - 1) / BLOCK;  // vertex coordinates staged per thread (1 for P >= 4)
+
+  __shared__ T sD[n2];
+  __shared__ T sP[n], sW[n];
+  __shared__ T sX[CPB * 24];
+  __shared__ T su[CPB * S];
+  __shared__ T sfy[CPB * S];
+  __shared__ T sfz[CPB * S];
+  __shared__ T sxy_own[ALIAS ? 1 : M];
+  __shared__ int s_runs[2 * kPlanMaxRuns];
+  T* const sx = ALIAS ? sfy : sxy_own;
+  T* const sy = ALIAS ? su : sxy_own;
+
+  const int tid = threadIdx.x;
+  const unsigned batch = blockIdx.x;
+  const int lc = tid / n2;
+  const int t = tid - lc * n2;
+  const int ty = t / n, tz = t - ty * n;
+  const int64_t cell0 = (int64_t)batch * CPB;
+  const int64_t cell = cell0 + lc;
+  const bool active = (lc < CPB) && (cell < ncell);
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
+  const int32_t* ud = udofs + (int64_t)batch * M;
+
+  if (tid < n2) sD[tid] = dphi[tid];
+  if (tid < n) {
+    sP[tid] = pts[tid];
+    sW[tid] = wts[tid];
+  }
+
+  int32_t mydof[SPT];
+  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
+  // vertex indices of the batch's cells: entry e = (cell in batch) * 24 + vertex * 3 + axis
+  int32_t vid[VPT];
+#pragma unroll
+  for (int r = 0; r < VPT; ++r) {
+    const int e = tid + r * BLOCK;
+    const int c = e / 24, v = (e - c * 24) / 3;
+    const bool ok = (e < CPB * 24) && (cell0 + c < ncell);
+    vid[r] = ok ? x_dofs[(cell0 + c) * 8 + v] : 0;
+  }
+  uint16_t sl[n];
+  T coeff = T(0);
+  if (active) {
+    const uint16_t* sp = slot + cell * Nd + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+    coeff = cell_constants[cell];
+  }
+  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
+#pragma unroll
+  for (int r = 0; r < VPT; ++r) {
+    const int e = tid + r * BLOCK;
+    const int d = e % 3;
+    if (e < CPB * 24) sX[e] = x_g[(int64_t)vid[r] * 3 + d];
+  }
+
+  T u[n];
+  plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sl, sx, su + lc * S + t, u);
+  if constexpr (!ALIAS) plan_zero<T, SPT, BLOCK>(sy, nu_b, tid);
+
+  T fx[n];
+  if (active) {
+    // ---- column geometry: rows of J_ as functions of xi_x --------------------------------------
+    const T* X = sX + lc * 24;  // X[(vx + 2 vy + 4 vz) * 3 + d]
+    const T ey = sP[ty], ez = sP[tz];
+    const T fy0 = T(1) - ey, fz0 = T(1) - ez;
+    T J0[3], Ja[3], Jba[3], Jc[3], Jdc[3];
+#pragma unroll
+    for (int d = 0; d < 3; ++d) {
+      const T x000 = X[0 * 3 + d], x100 = X[1 * 3 + d], x010 = X[2 * 3 + d], x110 = X[3 * 3 + d];
+      const T x001 = X[4 * 3 + d], x101 = X[5 * 3 + d], x011 = X[6 * 3 + d], x111 = X[7 * 3 + d];
+      // d/dxi_x: bilinear in (xi_y, xi_z) of the four x-edges
+      J0[d] = fz0 * (fy0 * (x100 - x000) + ey * (x110 - x010)) + ez * (fy0 * (x101 - x001) + ey * (x111 - x011));
+      // d/dxi_y at xi_x = 0 (A) and 1 (B): linear in xi_z of the y-edges
+      const T A = fz0 * (x010 - x000) + ez * (x011 - x001);
+      const T B = fz0 * (x110 - x100) + ez * (x111 - x101);
+      // d/dxi_z at xi_x = 0 (C) and 1 (D): linear in xi_y of the z-edges
+      const T C = fy0 * (x001 - x000) + ey * (x011 - x010);
+      const T D = fy0 * (x101 - x100) + ey * (x111 - x110);
+      Ja[d] = A;
+      Jba[d] = B - A;
+      Jc[d] = C;
+      Jdc[d] = D - C;
+    }
+    const T cw = coeff * sW[ty] * sW[tz];
+
+    T dy[n], dz[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      dy[i] = sD[ty * n + i];
+      dz[i] = sD[tz * n + i];
+    }
+    const T* cu_y = su + lc * S + tz;
+    const T* cu_z = su + lc * S + ty * n;
+    T* cfy = sfy + lc * S + t;
+    T* cfz = sfz + lc * S + t;
+#pragma unroll
+    for (int qx = 0; qx < n; ++qx) {
+      T vx, vy, vz;
+      plan_grad_at<T, n, n2>(qx, dphi, u, dy, dz, cu_y, cu_z, vx, vy, vz);
+      const T ex = pts[qx];  // compile-time index: scalar load
+      T J1[3], J2[3];
+#pragma unroll
+      for (int d = 0; d < 3; ++d) {
+        J1[d] = Ja[d] + ex * Jba[d];
+        J2[d] = Jc[d] + ex * Jdc[d];
+      }
+      // adj(J_): A[d][a], inv(J_) = A / det  (same expressions as geometry_kernel, geometry.hpp)
+      T A[3][3];
+      A[0][0] = J1[1] * J2[2] - J1[2] * J2[1];
+      A[0][1] = J0[2] * J2[1] - J0[1] * J2[2];
+      A[0][2] = J0[1] * J1[2] - J0[2] * J1[1];
+      A[1][0] = J1[2] * J2[0] - J1[0] * J2[2];
+      A[1][1] = J0[0] * J2[2] - J0[2] * J2[0];
+      A[1][2] = J0[2] * J1[0] - J0[0] * J1[2];
+      A[2][0] = J1[0] * J2[1] - J1[1] * J2[0];
+      A[2][1] = J0[1] * J2[0] - J0[0] * J2[1];
+      A[2][2] = J0[0] * J1[1] - J0[1] * J1[0];
+      const T det = J0[0] * A[0][0] + J0[1] * A[1][0] + J0[2] * A[2][0];
+      // coeff * w_q |det| / det^2 = coeff * w_q / |det|
+      const T s = cw * wts[qx] / (det < T(0) ? -det : det);
+      const T g00 = A[0][0] * A[0][0] + A[1][0] * A[1][0] + A[2][0] * A[2][0];
+      const T g01 = A[0][0] * A[0][1] + A[1][0] * A[1][1] + A[2][0] * A[2][1];
+      const T g02 = A[0][0] * A[0][2] + A[1][0] * A[1][2] + A[2][0] * A[2][2];
+      const T g11 = A[0][1] * A[0][1] + A[1][1] * A[1][1] + A[2][1] * A[2][1];
+      const T g12 = A[0][1] * A[0][2] + A[1][1] * A[1][2] + A[2][1] * A[2][2];
+      const T g22 = A[0][2] * A[0][2] + A[1][2] * A[1][2] + A[2][2] * A[2][2];
+      fx[qx] = s * (g00 * vx + g01 * vy + g02 * vz);
+      cfy[qx * n2] = s * (g01 * vx + g11 * vy + g12 * vz);
+      cfz[qx * n2] = s * (g02 * vx + g12 * vy + g22 * vz);
+    }
+  }
+  __syncthreads();
+  if constexpr (ALIAS) {
+    plan_zero<T, SPT, BLOCK>(sy, nu_b, tid);
+    __syncthreads();
+  }
+
+  plan_backward<T, n, n2>(dphi, sD, ty, tz, active, fx, sfy + lc * S + tz, sfz + lc * S + ty * n, sl, sy);
+  plan_flush<T, SPT, BLOCK>(y, mydof, nu_b, tid, sy);
+}
+
+template <typename T, int P, bool ALIAS, bool PADLDS, int MINW>
+inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs,
+                                             const T* pts, const T* wts, const void* workspace, const T* dphi,
+                                             int64_t ncell, hipStream_t stream) {
+  constexpr int CPB = plan_cells_per_batch<P>();
+  if (ncell <= 0) return hipSuccess;
+  PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
+  constexpr int threads = col_block_threads<P, CPB>();
+  hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW>), dim3((unsigned)v.nbatch),
+                     dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell);
+  return hipGetLastError();
+}
+
+}  // namespace fus

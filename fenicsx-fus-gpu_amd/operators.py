@@ -153,7 +153,7 @@ mass_operator = _MassOperator()
 class _StiffnessOperator(_Launchable):
     """Returned by ``stiffness_operator``; callable both ways."""
 
-    def __init__(self, P: int, float_type, dphi=None, affine_weights=None):
+    def __init__(self, P: int, float_type, dphi=None, affine_weights=None, geometry=None):
         self.P = int(P)
         if not (1 <= self.P <= 10):
             raise ValueError(f"polynomial degree {P} outside the supported range 1..10")
@@ -175,6 +175,26 @@ class _StiffnessOperator(_Launchable):
             self._wratio = torch.from_numpy(w / w[0]).to(device=dev, dtype=self.dtype).contiguous()
             self._fn_affine = getattr(_lib.load(), f"fus_stiffness_apply_planned_affine_{_lib.suffix(self.dtype)}")
 
+        # opt-in in-kernel geometry: (x_dofs int32[ncell, 8], x_g T[nvert, 3], pts T[n], wts T[n]);
+        # the G argument of the apply is then ignored (may be None)
+        self._geom = None
+        if geometry is not None:
+            x_dofs, x_g, pts, wts = geometry
+            dev = torch.device("cuda", torch.cuda.current_device())
+
+            def dev_t(a, dtype):
+                t = a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))
+                return t.to(device=dev, dtype=dtype).contiguous()
+
+            xd, xg = dev_t(x_dofs, torch.int32), dev_t(x_g, self.dtype)
+            pt, wt = dev_t(pts, self.dtype).reshape(-1), dev_t(wts, self.dtype).reshape(-1)
+            if xd.dim() != 2 or xd.shape[1] != 8 or xg.dim() != 2 or xg.shape[1] != 3:
+                raise ValueError("geometry: x_dofs must be [ncell, 8] and x_g [nvert, 3] (P1 hexahedra)")
+            if pt.numel() != self.n or wt.numel() != self.n:
+                raise ValueError(f"geometry: pts / wts must hold the {self.n} 1-D GLL points / weights")
+            self._geom = (xd, xg, pt, wt)
+            self._fn_geom = getattr(_lib.load(), f"fus_stiffness_apply_planned_geom_{_lib.suffix(self.dtype)}")
+
     def _table(self, dphi):
         """Accept the flat ``[q*n+i]`` (numba-cpu) or 2-D ``[q, i]`` (cuda) table, host or device."""
         if isinstance(dphi, torch.Tensor):
@@ -191,19 +211,31 @@ class _StiffnessOperator(_Launchable):
         _req(x, dt, "x")
         _req(cell_constants, dt, "cell_constants")
         _req(y, dt, "y")
-        _req(G, dt, "G")
+        if self._geom is None:
+            _req(G, dt, "G")
         _req(dofmap, torch.int32, "dofmap")
         nd = self.n**3
         if dofmap.dim() != 2 or dofmap.shape[1] != nd:
             raise ValueError(f"dofmap must be [ncell, {nd}] for P={self.P}")
         ncell = dofmap.shape[0]
-        if G.numel() != ncell * nd * 6:
+        if self._geom is None and G.numel() != ncell * nd * 6:
             raise ValueError(f"G must be [ncell, {nd}, 6]")
         if cell_constants.numel() != ncell:
             raise ValueError("cell_constants must have one value per cell")
         if ncell == 0:
             return
-        if self._wratio is not None:
+        if self._geom is not None:
+            xd, xg, pt, wt = self._geom
+            if xd.shape[0] != ncell:
+                raise ValueError(f"geometry: x_dofs has {xd.shape[0]} cells, dofmap has {ncell}")
+            ws, _ = _PLANS.get(dofmap)
+            _lib.check(
+                self._fn_geom(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), xg.data_ptr(), xd.data_ptr(),
+                              pt.data_ptr(), wt.data_ptr(), ws.data_ptr(), dphi_t.data_ptr(), self.P, int(ncell),
+                              _lib.stream_ptr()),
+                "fus_stiffness_apply_planned_geom",
+            )
+        elif self._wratio is not None:
             ws, _ = _PLANS.get(dofmap)
             _lib.check(
                 self._fn_affine(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(),
@@ -246,18 +278,23 @@ class _StiffnessOperator(_Launchable):
         self._apply(x, entity_constants, y, G_entity, entity_dofmap, self._dphi_cuda)
 
 
-def stiffness_operator(P, *args, affine_weights=None):
+def stiffness_operator(P, *args, affine_weights=None, geometry=None):
     """``stiffness_operator(P, dphi, float_type)`` (numba-cpu/operators.py:71) or
     ``stiffness_operator(P, float_type)`` (cuda/operators.py:73).
 
     ``affine_weights`` (keyword, no reference counterpart): opt into the affine-cell fast path by
     passing the tensor quadrature weights ``[n^3]``; the operator then reads only ``G[c, 0, :]`` of
-    each cell.  Only valid when every cell is affine (``is_affine_geometry`` checks)."""
+    each cell.  Only valid when every cell is affine (``is_affine_geometry`` checks).
+
+    ``geometry`` (keyword, no reference counterpart): ``(x_dofs, x_g, pts, wts)`` -- the reference's
+    mesh pair of numba-cpu/precompute.py:115 plus the 1-D GLL points / weights; the operator then
+    forms G in the kernel from the 8 vertices of each (trilinear) cell and ignores its ``G``
+    argument.  ``x_dofs`` rows must be in the dofmap's cell order."""
     if len(args) == 2:
         dphi, float_type = args
-        return _StiffnessOperator(P, float_type, dphi, affine_weights)
+        return _StiffnessOperator(P, float_type, dphi, affine_weights, geometry)
     if len(args) == 1:
-        return _StiffnessOperator(P, args[0], None, affine_weights)
+        return _StiffnessOperator(P, args[0], None, affine_weights, geometry)
     raise TypeError("stiffness_operator(P, dphi, float_type) or stiffness_operator(P, float_type)")
 
 

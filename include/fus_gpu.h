@@ -50,7 +50,6 @@ int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_byt
 #define FUS_TUNE_XCD_REMAP 2         /* 1 = give each XCD a contiguous range of cell batches */
 #define FUS_TUNE_MASS_VARIANT 3
 #define FUS_TUNE_PLAN_VARIANT 4      /* planned stiffness kernel build: see csrc/fus_gpu.hip */
-#define FUS_TUNE_PLAN_THREADS 6      /* EXPERIMENT: cell batches cut for 128- instead of 256-thread workgroups (plan build + builds 10/11) */
 #define FUS_TUNE_PLAN_RUNS 5         /* run-length coded dof lists in plans: 0 never, 1 auto (default), 2 always; read at plan build */
 int fus_set_tuning(int key, int value);
 int fus_get_tuning(int key);
@@ -109,6 +108,23 @@ int fus_stiffness_apply_planned_affine_f64(const double* x, const double* cell_c
 int fus_stiffness_apply_planned_affine_f32(const float* x, const float* cell_constants, float* y, const float* G,
                                            const float* wratio, const void* workspace, const float* dphi, int P,
                                            int64_t ncell, void* stream);
+
+/*
+ * Stiffness apply with the geometric factor formed in the kernel from the 8 vertices of each cell
+ * (its own bytes contract -- no G array is read -- and its own bench line).  The
+ * formulas are the reference's host precompute, numba-cpu/precompute.py:115-163
+ * compute_scaled_geometrical_factor, for what its callers pass: P1 (trilinear) hexahedra with
+ * vertex v = vx + 2 vy + 4 vz and the tensor GLL rule:
+ *   x_g T[nvert][3], x_dofs int32[ncell][8]  (the reference's ``(x_dofs, x_g)`` mesh pair, same cell order as the dofmap),
+ *   pts T[n], wts T[n]                       1-D GLL points on [0, 1] and weights (quadrature point q = qx n^2 + qy n + qz)
+ * Results equal fus_stiffness_apply_planned_* on G = compute_scaled_geometrical_factor(...) up to round-off.
+ */
+int fus_stiffness_apply_planned_geom_f64(const double* x, const double* cell_constants, double* y, const double* x_g,
+                                         const int32_t* x_dofs, const double* pts, const double* wts,
+                                         const void* workspace, const double* dphi, int P, int64_t ncell, void* stream);
+int fus_stiffness_apply_planned_geom_f32(const float* x, const float* cell_constants, float* y, const float* x_g,
+                                         const int32_t* x_dofs, const float* pts, const float* wts,
+                                         const void* workspace, const float* dphi, int P, int64_t ncell, void* stream);
 
 /*
  * Generic batch plan (any entity kind: cells N = n^3, boundary facets N = n^2) and planned mass

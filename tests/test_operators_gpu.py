@@ -271,10 +271,11 @@ def test_mass_planned_vs_oracle(gpu, oracle_c, plan_mode, P, dtype):
 
 
 @pytest.mark.parametrize("runs", [0, 2], ids=["rawplan", "runplan"])
-@pytest.mark.parametrize("pv", [0, 1, 2, 3])
-@pytest.mark.parametrize("P", [2, 4, 6])
+@pytest.mark.parametrize("pv", [0, 1, 2])
+@pytest.mark.parametrize("P", [2, 4, 6, 7])
 def test_planned_kernel_builds(gpu, oracle_c, P, pv, runs):
-    """Every build of the planned stiffness kernel (LDS aliasing / padding / occupancy hints)."""
+    """Every build of the planned stiffness kernel (0 own x/y buffer, 1 LDS-aliased, 2 LDS-aliased +
+    ring of G slabs) at every degree, whatever the auto dispatch would pick."""
     dev, ops = gpu
     lib = pkg("_lib")
     pb = build_problem(P, (5, 3, 4) if P < 6 else (3, 2, 3), perturb=0.16, seed=11)
@@ -422,3 +423,70 @@ def test_affine_fast_path(gpu, oracle_c, P, dtype):
     _check(y.copy_to_host(), y_ref, dtype, f"affine fast path P={P}")
     pert = build_problem(P, (3, 2, 2), dtype=dtype, perturb=0.16)
     assert not ops.is_affine_geometry(dev.to_device(pert["G"]), w3, rtol=1e-12 if dtype == np.float64 else 1e-5)
+
+
+@pytest.mark.parametrize("path", golden_files("ops_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_in_kernel_geometry_vs_reference(gpu, path):
+    """Stiffness apply with G formed in the kernel from the 8 cell vertices (no G array) against the
+    reference's own stiffness output, which consumed the G its precompute.py built from the same
+    vertices (numba-cpu/precompute.py:115-163 -> operators.py:71-227)."""
+    dev, ops = gpu
+    d = np.load(path)
+    P, dt = int(d["P"]), d["x"].dtype
+    y = dev.to_device(d["y0"])
+    op = ops.stiffness_operator(P, d["dphi_1d"].flatten(), dt, geometry=(d["x_dofs"], d["x_g"], d["pts"], d["wts"]))
+    op(dev.to_device(d["x"]), dev.to_device(d["cell_constants"]), y, None, dev.to_device(d["dofmap"]))
+    _check(y.copy_to_host(), d["ref_y_stiffness"], dt, "stiffness, in-kernel geometry")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", list(range(1, 11)))
+def test_in_kernel_geometry_all_degrees(gpu, oracle_c, P, dtype):
+    """P = 1..10, strongly perturbed trilinear cells, ragged last batch, random cell constants."""
+    dev, ops = gpu
+    pb = build_problem(P, (3, 2, 3) if P <= 6 else (2, 1, 2), dtype=dtype, perturb=0.25, seed=100 + P)
+    mesh = pb["mesh"]
+    y0 = np.random.default_rng(P).standard_normal(mesh.ndofs).astype(dtype)
+    y_ref = y0.copy()
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    y = dev.to_device(y0)
+    op = ops.stiffness_operator(P, pb["D"].flatten(), dtype, geometry=(mesh.x_dofs, mesh.x_g, pb["pts"], pb["wts"]))
+    op(dev.to_device(pb["x"]), dev.to_device(pb["cc"]), y, None, dev.to_device(mesh.dofmap))
+    _check(y.copy_to_host(), y_ref, dtype, f"in-kernel geometry P={P}")
+
+
+def test_in_kernel_geometry_full_size_properties(gpu):
+    """BASELINE config 3 size (P = 4, 54^3 perturbed cells): size-independent properties of the
+    in-kernel-geometry operator -- K 1 = 0, symmetry v.Ku = u.Kv, and agreement with the general-G
+    kernel fed by the device precompute of the same vertices."""
+    import torch
+
+    dev, ops = gpu
+    gll, boxmesh, pre = pkg("gll"), pkg("boxmesh"), pkg("precompute")
+    P, N = 4, 54
+    mesh = boxmesh.BoxMesh(P, N, perturb=0.16, seed=0)
+    pts, wts, D = gll.tabulate_1d(P, np.float64)
+    d = torch.device("cuda", 0)
+    dm, xd, xg = (torch.from_numpy(a).to(d) for a in (mesh.dofmap, mesh.x_dofs, mesh.x_g))
+    cc = torch.from_numpy(1.0 + 0.25 * np.random.default_rng(5).standard_normal(mesh.ncells)).to(d)
+    opg = ops.stiffness_operator(P, D.flatten(), np.float64, geometry=(xd, xg, pts, wts))
+    g = torch.Generator(device=d).manual_seed(3)
+    u = torch.randn(mesh.ndofs, dtype=torch.float64, device=d, generator=g)
+    v = torch.randn(mesh.ndofs, dtype=torch.float64, device=d, generator=g)
+    one = torch.ones_like(u)
+    Ku, Kv, K1 = torch.zeros_like(u), torch.zeros_like(u), torch.zeros_like(u)
+    opg(u, cc, Ku, None, dm)
+    opg(v, cc, Kv, None, dm)
+    opg(one, cc, K1, None, dm)
+    scale = float(Ku.abs().max())
+    assert float(K1.abs().max()) < 1e-10 * scale
+    a, b = float(torch.dot(v, Ku)), float(torch.dot(u, Kv))
+    assert abs(a - b) < 1e-11 * max(abs(a), abs(b))
+    G = torch.empty((mesh.ncells, (P + 1) ** 3, 6), dtype=torch.float64, device=d)
+    pre.compute_scaled_geometrical_factor_device(
+        G, (xd, xg), mesh.ncells, torch.from_numpy(pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))).to(d),
+        torch.from_numpy(gll.tensor_weights_3d(wts)).to(d))
+    Ku2 = torch.zeros_like(u)
+    ops.stiffness_operator(P, D.flatten(), np.float64)(u, cc, Ku2, G, dm)
+    err = float((Ku - Ku2).norm() / Ku2.norm())
+    assert err < 1e-12, err

@@ -1,0 +1,84 @@
+"""Pins the register allocation of the shipped kernel builds (an edit next to
+the product template silently cost the default P = 4 build one workgroup per CU).  hipcc
+cross-compiles gfx950 without a GPU; one device-only compile of csrc/fus_gpu.hip (~45 s, cached
+under csrc/_asm while the sources are unchanged) yields every kernel's VGPR / scratch / occupancy.
+
+The bounds are the allocation steps of gfx950 (512 registers per SIMD lane, granule 8:
+<= 128 VGPRs -> 4 waves per SIMD, <= 168 -> 3, <= 96 -> 5; MI355X_MICROARCH.md "Register files"),
+i.e. what decides how many workgroups a CU holds -- not the exact count the compiler reports."""
+import os
+import re
+import shutil
+import sys
+
+import pytest
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, os.path.join(ROOT, "tools"))
+
+pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists("/opt/rocm/bin/hipcc"),
+                                reason="hipcc not available")
+
+
+@pytest.fixture(scope="module")
+def table():
+    import resource_usage as ru
+
+    return ru.parse(ru.cached_remarks())
+
+
+def _find(table, pattern):
+    hits = [(k, v) for k, v in table.items() if re.search(pattern, k)]
+    assert len(hits) == 1, f"{pattern!r} matches {len(hits)} kernels: {[k for k, _ in hits]}"
+    return hits[0][1]
+
+
+# (kernel regex, max VGPRs, min waves per SIMD) of the builds the auto dispatch of csrc/fus_gpu.hip picks
+SHIPPED = [
+    # general-G planned stiffness: P <= 3 build 0, P = 4 / 5 build 1 (LDS-aliased), P >= 6 build 2 (G ring)
+    (r"stiffness_plan_kernel<double, 2, 28, false, true, 1, 3>", 128, 4),
+    (r"stiffness_plan_kernel<double, 4, 10, true, true, 1, 5>", 128, 4),   # the headline kernel
+    (r"stiffness_plan_kernel<double, 6, 5, true, true, 1, 4>", 168, 3),
+    (r"stiffness_plan_kernel<float, 2, 28, false, true, 5, 3>", 96, 5),
+    (r"stiffness_plan_kernel<float, 4, 10, false, true, 5, 5>", 96, 5),
+    (r"stiffness_plan_kernel<float, 6, 5, true, true, 1, 4>", 96, 5),
+    # in-kernel geometry
+    (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, \d>", 168, 3),
+    (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, \d>", 168, 3),
+    (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, \d>", 96, 5),
+    # affine fast path
+    (r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>", 96, 5),
+    (r"stiffness_plan_affine_kernel<double, 6, 5, true, true, 1>", 168, 3),
+    # fused Westervelt cell pass
+    (r"westervelt_cell_kernel<double, 4, 10>", 168, 3),
+    (r"westervelt_cell_kernel<double, 6, 5>", 256, 2),
+    (r"westervelt_cell_kernel<float, 4, 10>", 96, 5),
+    # plan-free column kernel
+    (r"stiffness_col_kernel<double, 4, 10>", 128, 4),
+]
+
+
+@pytest.mark.parametrize("pattern,max_vgpr,min_occ", SHIPPED, ids=[s[0].split("<")[0] + "<" + s[0].split("<")[1][:14] for s in SHIPPED])
+def test_shipped_build_occupancy(table, pattern, max_vgpr, min_occ):
+    d = _find(table, pattern)
+    assert d["agpr"] == 0
+    assert d["vgpr"] <= max_vgpr, f"{pattern}: {d['vgpr']} VGPRs > {max_vgpr}"
+    assert d["occupancy"] >= min_occ, f"{pattern}: {d['occupancy']} waves/SIMD < {min_occ}"
+
+
+def test_no_scratch(table):
+    """No shipped kernel spills, except the one measured build that trades a 20-byte spill for a fifth
+    wave per SIMD (affine P = 4 fp64: +8 %, profiles/r01f_affine_fast_path.log)."""
+    allowed = {r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>": 32}
+    bad = []
+    for name, d in table.items():
+        lim = next((v for k, v in allowed.items() if re.search(k, name)), 0)
+        if d["scratch"] > lim:
+            bad.append((name, d["scratch"]))
+    assert not bad, f"kernels with scratch (register spills): {bad}"
+
+
+def test_headline_kernel_lds_allows_four_workgroups(table):
+    d = _find(table, r"stiffness_plan_kernel<double, 4, 10, true, true, 1, 5>")
+    assert 4 * d["lds"] <= 160 * 1024
+    assert d["sgpr"] <= 80  # 8 blocks/CU admission limit of the SGPR file is not the binding one

@@ -1,15 +1,17 @@
 #!/usr/bin/env python3
-"""Interleaved A/B timing of stiffness-kernel tunings in ONE process (guide rule 24):
-N variants x M rounds on the BASELINE config-3 workload; prints median / min per variant.
+"""Interleaved A/B timing of stiffness-kernel builds in ONE process (guide rule 24):
+N variants x M rounds on one workload; prints median / min per variant.
 
-    python tools/ab_stiffness.py [--cells 54] [--degree 4] [--rounds 7] [--reps 10] v:r [v:r ...]
-where each ``v:r`` is (kernel):(xcd remap).  Kernels: ``0``/``1`` = plan-free column kernel with
-~256 / ~128-thread workgroups; ``p`` = planned kernel on a run-length coded plan, ``r`` = planned
-kernel on a raw plan; ``100 + k`` = build k of the planned kernel (FUS_TUNE_PLAN_VARIANT, see
-csrc/fus_gpu.hip: 0 default, 1 LDS-aliased, 2/3 occupancy hints, 30 fp32 5-waves build; k >= 4
-are the experimental builds -- SoA G, ablations, volatile LDS reads, G streaming, 128-thread
-batches, persistent kernel -- and need ``make -C fenicsx-fus-gpu_amd/csrc EXPERIMENTS=1``).
-Results of the studies run with this tool: profiles/r01*_ab_*.log, r01d_ablation_and_experiments.log."""
+    python tools/ab_stiffness.py [--cells 54] [--degree 4] [--rounds 7] [--reps 10] [--dtype f64] cfg [cfg ...]
+
+``cfg``:  ``plan``      shipped planned kernel, auto build
+          ``plan:K``    planned kernel build K (FUS_TUNE_PLAN_VARIANT, csrc/fus_gpu.hip: 0 three cubes + own
+                        buffer, 1 LDS-aliased, 2 LDS-aliased + G ring, 30 fp32 5-waves)
+          ``raw:K``     the same on a plan without run-length coded dof lists
+          ``geom``      geometry formed in the kernel from the 8 vertices (no G stream)
+          ``col:V``     plan-free column kernel, workgroup variant V (0: ~256 threads, 1: ~128)
+Add ``@x`` to a cfg to run it with the XCD remap on.  Two builds of the library are compared by
+alternating runs of this tool with FUS_LIB_PATH=<other libfusgpu.so> on one box.  Results of the studies run with this tool: profiles/r0*_ab_*.log."""
 import argparse
 import os
 import sys
@@ -28,7 +30,8 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="f64")
-    ap.add_argument("configs", nargs="*", default=["p:1", "p:0", "0:1", "1:0"])
+    ap.add_argument("--order", default="lex", choices=["lex", "random", "morton"], help="cell order of the dofmap")
+    ap.add_argument("configs", nargs="*", default=["plan", "plan:0", "plan:1", "plan:2"])
     a = ap.parse_args()
     import torch
 
@@ -38,63 +41,67 @@ def main():
 
     lib = fusgpu_loader.submodule("_lib")
     ops = fusgpu_loader.submodule("operators")
+    gll = fusgpu_loader.submodule("gll")
     dt = np.float64 if a.dtype == "f64" else np.float32
     pb = build_problem(a.degree, a.cells, dtype=dt, perturb=0.16)
     mesh = pb["mesh"]
     dev = torch.device("cuda", 0)
+    perm = np.arange(mesh.ncells)
+    if a.order == "random":
+        perm = np.random.default_rng(7).permutation(mesh.ncells)
     x = torch.from_numpy(pb["x"]).to(dev)
-    cc = torch.from_numpy(pb["cc"]).to(dev)
-    G = torch.from_numpy(pb["G"]).to(dev)
-    dm = torch.from_numpy(mesh.dofmap).to(dev)
+    cc = torch.from_numpy(pb["cc"][perm]).to(dev)
+    G = torch.from_numpy(pb["G"][perm]).to(dev)
+    dm = torch.from_numpy(mesh.dofmap[perm]).to(dev)
+    xd = torch.from_numpy(mesh.x_dofs[perm]).to(dev)
+    xg = torch.from_numpy(mesh.x_g.astype(dt)).to(dev)
     y = torch.zeros(mesh.ndofs, dtype=x.dtype, device=dev)
+    pts, wts, _ = gll.tabulate_1d(a.degree, dt)
     op = ops.stiffness_operator(a.degree, pb["D"].flatten(), dt)
-    # "p" = planned (run-length plan), "r" = planned with a raw (uncompressed) plan
-    cfgs = [tuple({"p": -1, "r": -2}.get(v, None) if v in ("p", "r") else int(v) for v in c.split(":")) for c in a.configs]
-    G_soa = G.permute(0, 2, 1).contiguous().reshape(G.shape)  # experiment 104: [cell][6][n^3] bytes in a [cell][n^3][6]-shaped tensor
+    opg = ops.stiffness_operator(a.degree, pb["D"].flatten(), dt, geometry=(xd, xg, pts, wts))
     dm_raw = dm.clone()  # a second dofmap array => its own cached plan, built with runs disabled
     lib.set_tuning(lib.TUNE_PLAN_RUNS, 0)
-    ops.use_plan(True)
     op(x, cc, y, G, dm_raw)
     torch.cuda.synchronize()
-    lib.set_tuning(lib.TUNE_PLAN_RUNS, 2)  # "p" = run-length plan
-    op(x, cc, y, G, dm)
-    torch.cuda.synchronize()
     lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
-    dm_128 = dm.clone()  # a third dofmap array: plan cut for 128-thread workgroups (builds 110 / 111)
-    lib.set_tuning(lib.TUNE_PLAN_THREADS, 128)
-    lib.set_tuning(lib.TUNE_PLAN_VARIANT, 10)
-    op(x, cc, y, G, dm_128)
-    torch.cuda.synchronize()
-    lib.set_tuning(lib.TUNE_PLAN_THREADS, 256)
-    lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
-    times = {c: [] for c in cfgs}
+
+    def parse(c):
+        remap = c.endswith("@x")
+        c = c[:-2] if remap else c
+        kind, _, k = c.partition(":")
+        return kind, int(k) if k else -1, remap
+
+    cfgs = [parse(c) for c in a.configs]
+    times = {c: [] for c in a.configs}
     for rnd in range(a.rounds + 1):
-        for c in cfgs:
-            ops.use_plan(c[0] < 0 or c[0] >= 100)
-            if c[0] >= 100:  # 100 + k = planned kernel build k
-                lib.set_tuning(lib.TUNE_PLAN_VARIANT, c[0] - 100)
-            elif c[0] >= 0:
-                lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, c[0])
+        for name, (kind, k, remap) in zip(a.configs, cfgs):
+            lib.set_tuning(lib.TUNE_XCD_REMAP, int(remap))
+            ops.use_plan(kind != "col")
+            fn, d_ = op, dm
+            if kind == "col":
+                lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, max(k, 0))
+            elif kind == "geom":
+                fn = opg
             else:
-                lib.set_tuning(lib.TUNE_PLAN_VARIANT, 0)
-            lib.set_tuning(lib.TUNE_XCD_REMAP, c[1])
+                lib.set_tuning(lib.TUNE_PLAN_VARIANT, k)
+                d_ = dm_raw if kind == "raw" else dm
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            d_ = dm_raw if (c[0] == -2 or c[0] >= 120) else (dm_128 if c[0] in (110, 111) else dm)  # persistent builds (120+) read raw plans
-            G_ = G_soa if c[0] == 104 else G
-            op(x, cc, y, G_, d_)
+            fn(x, cc, y, G, d_)
             e0.record()
             for _ in range(a.reps):
-                op(x, cc, y, G_, d_)
+                fn(x, cc, y, G, d_)
             e1.record()
             torch.cuda.synchronize()
             if rnd > 0:
-                times[c].append(e0.elapsed_time(e1) / a.reps)
+                times[name].append(e0.elapsed_time(e1) / a.reps)
+    lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
     bpc = bench.stiffness_bytes_per_cell(a.degree, np.dtype(dt).itemsize)
-    for c in cfgs:
-        t = np.array(times[c])
+    print(f"P={a.degree} cells={a.cells}^3 dtype={a.dtype} order={a.order} dofs={mesh.ndofs} lib={lib.LIB_PATH}")
+    for name in a.configs:
+        t = np.array(times[name])
         gbs = mesh.ncells * bpc / (np.median(t) * 1e-3) / 1e9
-        print(f"variant {c[0]} remap {c[1]}: median {np.median(t):.4f} ms  min {t.min():.4f} ms  "
-              f"{gbs:.0f} GB/s  ({100 * gbs / 8000:.1f}% of 8 TB/s)  {mesh.ndofs / np.median(t) / 1e6:.2f} GDOF/s")
+        print(f"{name:12s}: median {np.median(t):.4f} ms  min {t.min():.4f} ms  {gbs:.0f} GB/s of general-G bytes "
+              f"({100 * gbs / 8000:.1f}% of 8 TB/s)  {mesh.ndofs / np.median(t) / 1e6:.2f} GDOF/s")
 
 
 if __name__ == "__main__":
