@@ -6,6 +6,10 @@ P = 4 hexahedral box, on N MI355X GPUs of one node.
     python bench.py --gpus N --steps K --warmup W
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
 
+Both forms work for N > 1: started without a launcher (no RANK in the environment), this
+script starts its own N ranks -- one child process per GPU, before the parent makes any GPU
+call -- relays rank 0's JSON line and exits non-zero if any rank failed.
+
 One "step" = one apply ``y += K x`` over the whole (partitioned) mesh:
 forward halo of x, stiffness kernel over all local cells, reverse halo of y
 (the halo legs exist only for N > 1).  ``y`` is zeroed outside the timed region
@@ -44,6 +48,14 @@ def stiffness_bytes_per_cell(P, T):
     return 6 * nd * T + 4 * nd + T * P**3 + 2 * T * P**3 + T
 
 
+def geom_bytes_per_cell(P, T):
+    """Algorithmic HBM bytes per cell of the in-kernel-geometry apply: dofmap + x once + y RMW +
+    constant + the cell's vertex ids (8 int32) + vertex coordinates, each vertex read once
+    (3 T per cell asymptotically).  DESIGN.md 3.3."""
+    nd = (P + 1) ** 3
+    return 4 * nd + 3 * T * P**3 + T + 32 + 3 * T
+
+
 def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
@@ -58,6 +70,150 @@ def host_cores():
     except Exception:
         pass
     return n
+
+
+def lib_sha():
+    """Short hash of the libfusgpu.so this run loads (ties a bench line to the profiled binary)."""
+    import hashlib
+
+    import fusgpu_loader
+
+    path = fusgpu_loader.submodule("_lib").LIB_PATH
+    try:
+        with open(path, "rb") as f:
+            return hashlib.sha256(f.read()).hexdigest()[:12]
+    except OSError:
+        return None
+
+
+def _free_port():
+    import socket
+
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    p = s.getsockname()[1]
+    s.close()
+    return p
+
+
+def spawn_ranks(n, argv):
+    """``bench.py --gpus N`` started without a launcher: run N copies of this script, one rank per
+    GPU, rendezvous on 127.0.0.1.  The parent never touches the GPU (no HIP call, no torch import);
+    rank 0's stdout is relayed, every rank's stderr is inherited.  Returns the exit code."""
+    import subprocess
+
+    port = os.environ.get("MASTER_PORT") or str(_free_port())
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n),
+                   MASTER_ADDR="127.0.0.1", MASTER_PORT=port)
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # dmabuf IPC: required by RCCL on this driver
+        env.setdefault("OMP_NUM_THREADS", str(max(1, host_cores() // n)))
+        procs.append(subprocess.Popen([sys.executable, os.path.abspath(__file__), *argv], env=env,
+                                      stdout=subprocess.PIPE if r == 0 else subprocess.DEVNULL, text=True))
+    rc = 0
+    out0 = None
+    pending = set(range(n))
+    while pending:
+        for r in sorted(pending):
+            try:
+                if r == 0 and out0 is None:
+                    out0, _ = procs[0].communicate(timeout=0.5)
+                else:
+                    procs[r].wait(timeout=0.5)
+            except subprocess.TimeoutExpired:
+                continue
+            pending.discard(r)
+            if procs[r].returncode != 0 and rc == 0:
+                rc = procs[r].returncode or 1
+                log(f"rank {r} exited with code {procs[r].returncode}: stopping the other ranks")
+                for q in pending:  # they would hang in the next collective
+                    procs[q].terminate()
+    if out0:
+        sys.stdout.write(out0)
+        sys.stdout.flush()
+    return rc
+
+
+class _DryRunKernels:
+    """pack / unpack with plain torch indexing -- ONLY for ``--dry-run`` (launcher / rendezvous /
+    halo-plan rehearsal on CPU under gloo; nothing is measured and no operator is applied)."""
+
+    def index_tensor(self, idx_np):
+        import torch
+
+        return torch.from_numpy(np.ascontiguousarray(idx_np, dtype=np.int64))
+
+    def buffer(self, n):
+        import torch
+
+        return torch.empty(int(n), dtype=torch.float64)
+
+    def pack_fwd(self, in_, out, index):
+        out.copy_(in_[index])
+
+    def unpack_fwd(self, in_, out, index, N):
+        out[index + N] = in_
+
+    def pack_rev(self, in_, out, index, N):
+        out.copy_(in_[index + N])
+
+    def unpack_rev(self, in_, out, index):
+        out.index_add_(0, index, in_)
+
+
+def dry_run(args, rank, world):
+    """Rehearsal of the N-rank path without a GPU: spawn / rendezvous (gloo), partition, halo plan
+    exchange, forward + reverse all-to-all-v with the real per-neighbour counts, barrier + max-over-ranks
+    timing, one JSON line.  The line is marked invalid: nothing here is a measurement."""
+    import torch
+    import torch.distributed as dist
+
+    import fusgpu_loader
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29512")
+    os.environ.setdefault("RANK", "0")
+    os.environ.setdefault("WORLD_SIZE", "1")
+    dist.init_process_group("gloo")
+    if os.environ.get("FUS_BENCH_TEST_FAIL_RANK") == str(rank):  # launcher test: one rank dies after rendezvous
+        os._exit(3)
+    boxmesh, scat, utils = (fusgpu_loader.submodule(m) for m in ("boxmesh", "scatterer", "utils"))
+    P = args.degree
+    grid = boxmesh.default_grid(world)
+    cells = min(args.cells, 4)
+    mesh = boxmesh.BoxMesh(P, tuple(cells * g for g in grid), grid=grid, rank=rank)
+    comm = scat.TorchComm()
+    od, gd = utils.compute_scatterer_data_flat(mesh.index_map, comm if world > 1 else None)
+    k = _DryRunKernels()
+    fwd = scat.scatter_forward(comm, od, gd, mesh.nlocal, np.float64, kernels=k)
+    rev = scat.scatter_reverse(comm, od, gd, mesh.nlocal, np.float64, kernels=k)
+    lex = torch.from_numpy(mesh.global_lexicographic_ids().astype(np.float64))
+    x = lex.clone()
+    x[mesh.nlocal:] = -1.0
+    for _ in range(args.warmup):
+        fwd(x)
+    dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        fwd(x)
+        rev(torch.zeros_like(x))
+    dist.barrier()
+    el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64)
+    dist.all_reduce(el, op=dist.ReduceOp.MAX)
+    ok = torch.tensor([float(torch.equal(x, lex))])  # every ghost now holds its owner's value
+    dist.all_reduce(ok, op=dist.ReduceOp.MIN)
+    if rank == 0:
+        print(json.dumps({
+            "metric": "stiffness_apply_dof_per_s", "value": None, "unit": "DOF/s", "n_gpus": world, "steps": args.steps,
+            "warmup": args.warmup, "ms_per_step": float(el.item()) / args.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dry_run": True,
+            "valid": False, "halo_ok": bool(ok.item() == 1.0), "ranks": dist.get_world_size(), "backend": "gloo",
+            "config": {"workload": f"DRY RUN (CPU, gloo): halo exchange only, P={P}, {cells}^3 cells per rank",
+                       "partition": f"{grid[0]}x{grid[1]}x{grid[2]} blocks", "global_dofs": mesh.ndofs_global},
+            "roofline": None, "cpu_baseline": None}), flush=True)
+    dist.destroy_process_group()
+    return 0 if ok.item() == 1.0 else 1
 
 
 def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
@@ -111,17 +267,22 @@ def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
     }
 
 
-def load_traffic(P, ncell):
-    """Per-launch HBM bytes from the committed rocprofv3 PMC passes (profiles/), or None."""
+def load_traffic(P, ncell, sha):
+    """(per-launch HBM bytes, source) from the committed rocprofv3 PMC passes (profiles/), or
+    (None, reason).  PMC counters cannot be read from inside the run, so this is a REPLAYED figure:
+    it is reported only when the profiled library is the one loaded now (same hash), and the
+    line names its source."""
     path = os.path.join(ROOT, "profiles", "traffic_latest.json")
     try:
         with open(path) as f:
             t = json.load(f)
-        if int(t.get("P", -1)) == P and int(t.get("ncell", -1)) == ncell:
-            return float(t["hbm_bytes_per_launch"])
     except Exception:
-        pass
-    return None
+        return None, "no profiles/traffic_latest.json"
+    if int(t.get("P", -1)) != P or int(t.get("ncell", -1)) != ncell:
+        return None, "profiled workload differs from this run"
+    if t.get("lib_sha") != sha:
+        return None, f"profiled library {t.get('lib_sha')} is not the loaded one ({sha})"
+    return float(t["hbm_bytes_per_launch"]), f"replayed from {t.get('source')} (rocprofv3 --pmc, same library hash)"
 
 
 def bench_rk4(args, rank, world, device):
@@ -204,22 +365,37 @@ def main():
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--xcd-remap", type=int, default=None)
     ap.add_argument("--no-plan", action="store_true", help="plan-free kernel (reads dofmap directly)")
-    ap.add_argument("--mode", default="stiffness", choices=["stiffness", "rk4", "westervelt"],
-                    help="stiffness: the headline metric; rk4 / westervelt: one full RK4 time step of the linear / "
-                         "Westervelt solver per 'step' (auxiliary metrics)")
+    ap.add_argument("--mode", default="stiffness", choices=["stiffness", "stiffness_geom", "rk4", "westervelt"],
+                    help="stiffness: the headline metric; stiffness_geom: the same apply with G formed in the kernel "
+                         "from the cell vertices (own bytes contract, separate line); rk4 / westervelt: one full RK4 "
+                         "time step of the linear / Westervelt solver per 'step' (auxiliary metrics)")
+    ap.add_argument("--dry-run", action="store_true",
+                    help="CPU rehearsal of the N-rank path (gloo): launcher, partition, halo plan and exchange; no "
+                         "GPU, no operator, the printed line is marked invalid")
+    ap.add_argument("--halo", default=os.environ.get("FUS_HALO", "native"), choices=["native", "torch"],
+                    help="N > 1 transport: native = grouped ncclSend/ncclRecv issued by libfusgpu.so on its own "
+                         "stream (default); torch = torch.distributed all_to_all_single")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        raise SystemExit("--gpus must be >= 1")
+    if "RANK" not in os.environ and args.gpus > 1:
+        # no launcher: become one.  Nothing above imported torch or touched the GPU.
+        raise SystemExit(spawn_ranks(args.gpus, sys.argv[1:]))
+
+    rank = int(os.environ.get("RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    if args.dry_run:
+        raise SystemExit(dry_run(args, rank, world))
 
     import torch
     import torch.distributed as dist
 
     import fusgpu_loader
 
-    rank = int(os.environ.get("RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("--gpus N > 1 must be launched with torch.distributed.run --nproc-per-node N")
     ndev = max(torch.cuda.device_count(), 1)
     local_rank = local_rank % ndev  # a launcher that masks devices per rank leaves one visible device
     torch.cuda.set_device(local_rank)
@@ -285,12 +461,22 @@ def main():
     if rank == 0:
         log(f"setup {time.time() - t0:.1f}s: P={P} cells/GPU={mesh.ncells} local dofs={mesh.ndofs} "
             f"global dofs={mesh.ndofs_global} grid={grid} G={G_d.numel() * T / 1e6:.0f} MB")
-    op = ops.stiffness_operator(P, D.flatten(), dt)
+    geom = args.mode == "stiffness_geom"
+    if geom and use_dist:
+        raise SystemExit("--mode stiffness_geom is a single-GPU line")
+    if geom:
+        # own bytes contract: no G array exists for this operator
+        op = ops.stiffness_operator(P, D.flatten(), dt, geometry=(mesh.x_dofs, mesh.x_g, pts, wts))
+        del G_d
+        G_d = None
+    else:
+        op = ops.stiffness_operator(P, D.flatten(), dt)
 
     halo = None
     if use_dist:
         scat = fusgpu_loader.submodule("scatterer")
-        halo = scat.HaloApply(mesh, op, scat.TorchComm(), dt, overlap=os.environ.get("FUS_HALO_OVERLAP", "1") != "0")
+        comm = scat.NativeComm() if args.halo == "native" else scat.TorchComm()
+        halo = scat.HaloApply(mesh, op, comm, dt, overlap=os.environ.get("FUS_HALO_OVERLAP", "1") != "0")
 
     def step():
         if halo is None:
@@ -371,11 +557,17 @@ def main():
 
     ndofs_global = mesh.ndofs_global
     value = ndofs_global / (elapsed / args.steps)
-    bpc = stiffness_bytes_per_cell(P, T)
+    bpc = geom_bytes_per_cell(P, T) if geom else stiffness_bytes_per_cell(P, T)
     achieved = mesh.ncells * bpc / (kern_ms * 1e-3) / 1e9
+    sha = lib_sha()
+    traffic, traffic_source = (None, "not profiled for this mode") if geom else load_traffic(P, mesh.ncells, sha)
+    if geom:
+        kname = "fus::stiffness_plan_geom_kernel"
+    else:
+        kname = "fus::stiffness_plan_kernel" if ops._USE_PLAN else "fus::stiffness_col_kernel"
 
     out = {
-        "metric": "stiffness_apply_dof_per_s",
+        "metric": "stiffness_apply_in_kernel_geometry_dof_per_s" if geom else "stiffness_apply_dof_per_s",
         "value": value,
         "unit": "DOF/s",
         "n_gpus": world,
@@ -394,11 +586,18 @@ def main():
             "cells_per_gpu": mesh.ncells,
             "global_dofs": ndofs_global,
             "partition": f"{grid[0]}x{grid[1]}x{grid[2]} blocks",
-            "geometry": "general per-quadrature-point G[ncell][n^3][6] (no affine shortcut)",
+            "geometry": ("formed in the kernel from the 8 vertices of each trilinear cell (no G array; NOT the headline "
+                         "bytes contract)") if geom else "general per-quadrature-point G[ncell][n^3][6] (no affine shortcut)",
             "stiffness_kernel": "planned (batch plan, LDS pre-reduction)" if ops._USE_PLAN else f"plan-free variant {lib.get_tuning(lib.TUNE_STIFFNESS_VARIANT)}",
             "xcd_remap": lib.get_tuning(lib.TUNE_XCD_REMAP),
             "halo": None if halo is None else ("overlapped" if halo.overlap else "sequential"),
+            "halo_transport": None if halo is None else (
+                "libfusgpu.so: grouped ncclSend/ncclRecv on a library-owned stream" if args.halo == "native"
+                else "torch.distributed.all_to_all_single (RCCL)"),
             "halo_exposed_ms": None if halo is None else max(0.0, ms_per_step - kern_ms),
+            "halo_exposed_frac": None if halo is None else max(0.0, ms_per_step - kern_ms) / kern_ms,
+            "ranks": world,
+            "lib_sha": sha,
         },
         "roofline": {
             "bound": "hbm",
@@ -406,8 +605,9 @@ def main():
             "peak": HBM_PEAK_GBS,
             "unit": "GB/s",
             "frac": achieved / HBM_PEAK_GBS,
-            "traffic": load_traffic(P, mesh.ncells),
-            "kernel": "fus::stiffness_plan_kernel" if ops._USE_PLAN else "fus::stiffness_col_kernel",
+            "traffic": traffic,
+            "traffic_source": traffic_source,
+            "kernel": kname,
             "kernel_ms": kern_ms,
             "step_ms_min": float(ev_ms.min()),
             "step_ms_std": float(ev_ms.std()),
@@ -419,7 +619,7 @@ def main():
         },
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and not args.no_cpu_baseline and not geom:
             G = G_d.cpu().numpy()  # the CPU baseline streams the same G the GPU did
             pb = dict(mesh=mesh, D=D, x=x.astype(np.float64), cc=cc.astype(np.float64), G=G.astype(np.float64))
             if dt != np.float64:

@@ -34,6 +34,24 @@ def _signatures():
         "fus_plan_bytes": [_int, _int, _i64],
         "fus_plan_build": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_stiffness_plan_build": [_vp, _int, _i64, _vp, _i64, _vp],
+        # communicator + halo exchange (csrc/halo_comm.hpp)
+        "fus_comm_unique_id": [_vp],
+        "fus_comm_create": [_vp, _int, _int, C.POINTER(_vp)],
+        "fus_comm_create_local": [_int, _int, _int, C.POINTER(_vp)],
+        "fus_comm_rank": [_vp],
+        "fus_comm_size": [_vp],
+        "fus_comm_stream": [_vp],
+        "fus_comm_last_error": [_vp],
+        "fus_comm_destroy": [_vp],
+        "fus_halo_create": [_vp, _int, _i64, _i64, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp, C.POINTER(_vp)],
+        "fus_halo_is_direct": [_vp],
+        "fus_halo_destroy": [_vp],
+        "fus_halo_forward_begin": [_vp, _vp, _vp],
+        "fus_halo_forward_end": [_vp, _vp, _vp],
+        "fus_halo_reverse_begin": [_vp, _vp, _vp],
+        "fus_halo_reverse_end": [_vp, _vp, _vp],
+        "fus_halo_forward": [_vp, _vp, _vp],
+        "fus_halo_reverse": [_vp, _vp, _vp],
     }
     for suf, ct in _SUFFIXES:
         sig[f"fus_stiffness_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
@@ -90,16 +108,23 @@ def load():
     for name, argtypes in SIGNATURES.items():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
-        fn.restype = _i64 if name in ("fus_stiffness_plan_bytes", "fus_plan_bytes") else _int
+        fn.restype = {"fus_stiffness_plan_bytes": _i64, "fus_plan_bytes": _i64, "fus_comm_stream": _vp,
+                      "fus_comm_last_error": C.c_char_p}.get(name, _int)
     lib.fus_error_string.argtypes = [_int]
     lib.fus_error_string.restype = C.c_char_p
     _lib = lib
     return lib
 
 
-def check(rc: int, what: str = ""):
+ERR_COMM = -5
+
+
+def check(rc: int, what: str = "", comm=None):
     if rc != 0:
         msg = load().fus_error_string(rc).decode()
+        if rc == ERR_COMM:
+            detail = load().fus_comm_last_error(comm)
+            msg += ": " + (detail.decode() if detail else "?")
         raise FusGpuError(f"{what or 'libfusgpu call'} failed: {msg} (code {rc})")
 
 

@@ -114,6 +114,11 @@ class BoxMesh:
     num_boundary_cells : cells [0, num_boundary_cells) touch at least one ghost
         dof (they need the forward halo before, and feed the reverse halo
         after, an operator apply); the rest are interior.
+
+    ``ghost_order``: "owner" (default) numbers the ghosts owner by owner, which lets the halo
+    exchange use the ghost block of a vector as its message buffer; "lex" (lexicographic in the local
+    grid, owners interleaved) or an integer seed (random) reproduce what a general dolfinx
+    ``IndexMap`` looks like and exercise the unpack_fwd / pack_rev kernels.
     """
 
     def __init__(
@@ -127,6 +132,7 @@ class BoxMesh:
         seed: int = 0,
         warp=None,
         dtype=np.float64,
+        ghost_order="owner",
     ):
         if np.isscalar(ncells):
             ncells = (int(ncells),) * 3
@@ -178,7 +184,12 @@ class BoxMesh:
             gi_, gj_, gk_ = np.unravel_index(gpos, fdim)
             orc = [rc[a] - ((np.array((gi_, gj_, gk_)[a]) == 0) & has_lower[a]).astype(np.int64) for a in range(3)]
             gowner = (orc[0] * self.grid[1] + orc[1]) * self.grid[2] + orc[2]
-            gpos = gpos[np.argsort(gowner, kind="stable")]
+            if ghost_order == "owner":
+                gpos = gpos[np.argsort(gowner, kind="stable")]
+            elif ghost_order == "lex":
+                pass  # lexicographic in the local grid: owners interleave, like a dolfinx IndexMap in general
+            else:  # int seed: arbitrary ghost numbering
+                gpos = gpos[np.random.default_rng(int(ghost_order)).permutation(gpos.size)]
         lid.reshape(-1)[gpos] = nlocal + np.arange(nghost, dtype=np.int32)
         self._lid = lid
         self.nlocal, self.nghost = nlocal, int(nghost)

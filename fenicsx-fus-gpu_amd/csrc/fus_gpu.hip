@@ -10,6 +10,7 @@
 
 #include "geometry.hpp"
 #include "halo.hpp"
+#include "halo_comm.hpp"
 #include "mass.hpp"
 #include "plan.hpp"
 #include "rk4.hpp"
@@ -261,6 +262,7 @@ const char* fus_error_string(int code) {
     case FUS_ERR_UNSUPPORTED_DEGREE: return "unsupported polynomial degree";
     case FUS_ERR_UNSUPPORTED_ENTITY: return "unsupported entity size";
     case FUS_ERR_NO_DEVICE: return "no HIP device";
+    case FUS_ERR_COMM: return "communicator / RCCL failure (see fus_comm_last_error)";
     default:
       if (code <= FUS_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(FUS_ERR_HIP_BASE - code));
       return "unknown error";
@@ -498,5 +500,198 @@ FUS_RK4(double, f64)
 FUS_RK4(float, f32)
 #undef FUS_RK4
 #undef FUS_VEC
+
+// ------------------------------------------------------------------ communicator + halo exchange
+struct fus_comm {
+  fus::Comm c;
+};
+struct fus_halo {
+  fus::Halo h;
+};
+
+static std::string g_comm_error;  // errors that happen before a communicator exists
+
+int fus_comm_unique_id(void* id) {
+  if (!id) return FUS_ERR_INVALID_ARGUMENT;
+  fus::RcclApi& api = fus::rccl();
+  if (!api.load()) {
+    g_comm_error = api.error;
+    return FUS_ERR_COMM;
+  }
+  ncclUniqueId uid;
+  static_assert(sizeof(uid) == FUS_UNIQUE_ID_BYTES, "unique id size");
+  const ncclResult_t r = api.GetUniqueId(&uid);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclGetUniqueId: ") + api.GetErrorString(r);
+    return FUS_ERR_COMM;
+  }
+  std::memcpy(id, &uid, sizeof(uid));
+  return FUS_OK;
+}
+
+int fus_comm_create(const void* id, int nranks, int rank, fus_comm_t* out) {
+  if (!id || !out || nranks < 1 || rank < 0 || rank >= nranks) return FUS_ERR_INVALID_ARGUMENT;
+  fus::RcclApi& api = fus::rccl();
+  if (!api.load()) {
+    g_comm_error = api.error;
+    return FUS_ERR_COMM;
+  }
+  auto* c = new fus_comm;
+  c->c.kind = fus::Comm::RCCL;
+  c->c.rank = rank;
+  c->c.nranks = nranks;
+  hipError_t e = fus::comm_make_stream(&c->c);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_rc(e);
+  }
+  ncclUniqueId uid;
+  std::memcpy(&uid, id, sizeof(uid));
+  const ncclResult_t r = api.CommInitRank(&c->c.nccl, nranks, uid, rank);
+  if (r != ncclSuccess) {
+    g_comm_error = std::string("ncclCommInitRank: ") + api.GetErrorString(r);
+    (void)hipStreamDestroy(c->c.stream);
+    delete c;
+    return FUS_ERR_COMM;
+  }
+  *out = c;
+  return FUS_OK;
+}
+
+int fus_comm_create_local(int world_id, int nranks, int rank, fus_comm_t* out) {
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks) return FUS_ERR_INVALID_ARGUMENT;
+  auto& worlds = fus::local_worlds();
+  std::shared_ptr<fus::LocalWorld> w = worlds[world_id].lock();
+  if (!w) {
+    w = std::make_shared<fus::LocalWorld>();
+    w->nranks = nranks;
+    w->halos.resize(nranks);
+    worlds[world_id] = w;
+  }
+  if (w->nranks != nranks) return FUS_ERR_INVALID_ARGUMENT;
+  auto* c = new fus_comm;
+  c->c.kind = fus::Comm::LOCAL;
+  c->c.rank = rank;
+  c->c.nranks = nranks;
+  c->c.world = w;
+  hipError_t e = fus::comm_make_stream(&c->c);
+  if (e != hipSuccess) {
+    delete c;
+    return hip_rc(e);
+  }
+  *out = c;
+  return FUS_OK;
+}
+
+int fus_comm_rank(fus_comm_t comm) { return comm ? comm->c.rank : FUS_ERR_INVALID_ARGUMENT; }
+int fus_comm_size(fus_comm_t comm) { return comm ? comm->c.nranks : FUS_ERR_INVALID_ARGUMENT; }
+void* fus_comm_stream(fus_comm_t comm) { return comm ? comm->c.stream : nullptr; }
+
+const char* fus_comm_last_error(fus_comm_t comm) {
+  return comm ? comm->c.last_error.c_str() : g_comm_error.c_str();
+}
+
+int fus_comm_destroy(fus_comm_t comm) {
+  if (!comm) return FUS_OK;
+  if (comm->c.stream) (void)hipStreamSynchronize(comm->c.stream);
+  if (comm->c.nccl) (void)fus::rccl().CommDestroy(comm->c.nccl);
+  if (comm->c.stream) (void)hipStreamDestroy(comm->c.stream);
+  delete comm;
+  return FUS_OK;
+}
+
+int fus_halo_create(fus_comm_t comm, int elem_bytes, int64_t nlocal, int64_t nghost, int n_owner_ranks,
+                    const int32_t* owner_ranks, const int64_t* owner_sizes, const int64_t* owners_idx,
+                    int n_ghost_ranks, const int32_t* ghost_ranks, const int64_t* ghost_sizes,
+                    const int64_t* ghosts_idx, fus_halo_t* out) {
+  if (!comm || !out || (elem_bytes != 4 && elem_bytes != 8) || nlocal < 0 || nghost < 0 || n_owner_ranks < 0 ||
+      n_ghost_ranks < 0)
+    return FUS_ERR_INVALID_ARGUMENT;
+  if ((n_owner_ranks > 0 && (!owner_ranks || !owner_sizes)) || (n_ghost_ranks > 0 && (!ghost_ranks || !ghost_sizes)))
+    return FUS_ERR_INVALID_ARGUMENT;
+  int64_t no = 0, ng = 0;
+  for (int i = 0; i < n_owner_ranks; ++i) {
+    if (owner_sizes[i] < 0 || owner_ranks[i] < 0 || owner_ranks[i] >= comm->c.nranks) return FUS_ERR_INVALID_ARGUMENT;
+    no += owner_sizes[i];
+  }
+  for (int i = 0; i < n_ghost_ranks; ++i) {
+    if (ghost_sizes[i] < 0 || ghost_ranks[i] < 0 || ghost_ranks[i] >= comm->c.nranks) return FUS_ERR_INVALID_ARGUMENT;
+    ng += ghost_sizes[i];
+  }
+  if (no > nghost || (no > 0 && !owners_idx) || (ng > 0 && !ghosts_idx)) return FUS_ERR_INVALID_ARGUMENT;
+  // out-of-range indices would fault in the pack / unpack kernels: check them here, once
+  bool direct = no > 0;
+  for (int64_t i = 0; i < no; ++i) {
+    if (owners_idx[i] < 0 || owners_idx[i] >= nghost) return FUS_ERR_INVALID_ARGUMENT;
+    if (owners_idx[i] != i) direct = false;
+  }
+  for (int64_t i = 0; i < ng; ++i)
+    if (ghosts_idx[i] < 0 || ghosts_idx[i] >= nlocal) return FUS_ERR_INVALID_ARGUMENT;
+  auto* hh = new fus_halo;
+  fus::Halo& h = hh->h;
+  h.comm = &comm->c;
+  h.eb = elem_bytes;
+  h.nlocal = nlocal;
+  h.nghost = nghost;
+  h.direct = direct;
+  hipError_t e = fus::side_init(h.owners, n_owner_ranks, owner_ranks, owner_sizes, owners_idx, comm->c.stream);
+  if (e == hipSuccess) e = fus::side_init(h.ghosts, n_ghost_ranks, ghost_ranks, ghost_sizes, ghosts_idx, comm->c.stream);
+  if (e == hipSuccess && no > 0) e = hipMalloc(&h.buf_owner, no * elem_bytes);
+  if (e == hipSuccess && ng > 0) e = hipMalloc(&h.buf_ghost, ng * elem_bytes);
+  for (hipEvent_t* ev : {&h.ev_ready, &h.ev_done, &h.ev_packed, &h.ev_pulled})
+    if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipStreamSynchronize(comm->c.stream);  // the index lists came from host arrays the caller may free
+  if (e != hipSuccess) {
+    fus_halo_destroy(hh);
+    return hip_rc(e);
+  }
+  if (comm->c.kind == fus::Comm::LOCAL) {
+    auto& mine = comm->c.world->halos[comm->c.rank];
+    h.index = (int)mine.size();
+    mine.push_back(&h);
+  }
+  *out = hh;
+  return FUS_OK;
+}
+
+int fus_halo_destroy(fus_halo_t halo) {
+  if (!halo) return FUS_OK;
+  fus::Halo& h = halo->h;
+  if (h.comm && h.comm->stream) (void)hipStreamSynchronize(h.comm->stream);
+  if (h.comm && h.comm->kind == fus::Comm::LOCAL && h.comm->world) {
+    auto& mine = h.comm->world->halos[h.comm->rank];
+    if (h.index < (int)mine.size() && mine[h.index] == &h) mine[h.index] = nullptr;
+  }
+  fus::side_free(h.owners);
+  fus::side_free(h.ghosts);
+  if (h.buf_owner) (void)hipFree(h.buf_owner);
+  if (h.buf_ghost) (void)hipFree(h.buf_ghost);
+  for (hipEvent_t ev : {h.ev_ready, h.ev_done, h.ev_packed, h.ev_pulled})
+    if (ev) (void)hipEventDestroy(ev);
+  delete halo;
+  return FUS_OK;
+}
+
+int fus_halo_is_direct(fus_halo_t halo) { return halo ? (halo->h.direct ? 1 : 0) : FUS_ERR_INVALID_ARGUMENT; }
+
+#define FUS_HALO_OP(NAME, FN, DIR)                                                  \
+  int NAME(fus_halo_t halo, void* buffer, void* stream) {                           \
+    if (!halo || !buffer) return FUS_ERR_INVALID_ARGUMENT;                          \
+    return fus::FN(&halo->h, buffer, static_cast<hipStream_t>(stream), DIR) == 0 ? FUS_OK : FUS_ERR_COMM; \
+  }
+FUS_HALO_OP(fus_halo_forward_begin, halo_begin, 0)
+FUS_HALO_OP(fus_halo_forward_end, halo_end, 0)
+FUS_HALO_OP(fus_halo_reverse_begin, halo_begin, 1)
+FUS_HALO_OP(fus_halo_reverse_end, halo_end, 1)
+#undef FUS_HALO_OP
+
+int fus_halo_forward(fus_halo_t halo, void* buffer, void* stream) {
+  const int rc = fus_halo_forward_begin(halo, buffer, stream);
+  return rc != FUS_OK ? rc : fus_halo_forward_end(halo, buffer, stream);
+}
+int fus_halo_reverse(fus_halo_t halo, void* buffer, void* stream) {
+  const int rc = fus_halo_reverse_begin(halo, buffer, stream);
+  return rc != FUS_OK ? rc : fus_halo_reverse_end(halo, buffer, stream);
+}
 
 }  // extern "C"

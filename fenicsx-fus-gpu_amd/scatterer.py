@@ -14,17 +14,24 @@ both in place on ``buffer`` (length nlocal + nghost, ghosts at ``[N:]``).
 MI355X-first differences from the reference:
   * one fused pack and one fused unpack launch for ALL neighbours (index lists
     concatenated) instead of one tiny kernel per neighbour;
-  * transport = one neighbour all-to-all-v (``torch.distributed`` -> RCCL grouped
-    send/recv over xGMI) instead of per-neighbour MPI Isend/Irecv on device
-    pointers; no host-blocking device synchronisation anywhere: ordering is by
-    stream (pack -> exchange -> unpack), so the host runs ahead;
+  * transport = one neighbour all-to-all-v as grouped RCCL send/recv over xGMI
+    instead of per-neighbour MPI Isend/Irecv on device pointers; no
+    host-blocking device synchronisation anywhere: ordering is by stream and
+    events (pack -> exchange -> unpack), so the host runs ahead;
   * split-phase ``begin()`` / ``end()`` so interior-cell operator application
     overlaps the exchange (``HaloApply`` below).
 
-``comm`` is a ``TorchComm`` (or anything with ``.rank``, ``.size``,
-``.alltoallv``); ``kernels`` selects the pack/unpack implementation: the HIP
-kernels of libfusgpu.so by default (GPU tensors; no CPU fallback) -- tests
-inject their own for gloo-on-CPU runs.
+``comm`` selects the transport:
+  * ``NativeComm`` (default of the drivers): the exchange lives in libfusgpu.so
+    (csrc/halo_comm.hpp, C ABI ``fus_halo_*``): pack, ``ncclGroupStart ...
+    ncclSend/ncclRecv ... ncclGroupEnd`` and unpack are issued from C++ on a
+    library-owned high-priority stream; torch.distributed only broadcasts the
+    RCCL unique id at start-up;
+  * ``TorchComm``: ``torch.distributed.all_to_all_single`` (backend "nccl" == RCCL,
+    or "gloo" for CPU tests) with the pack / unpack kernels launched from Python;
+    ``kernels`` then selects their implementation: the HIP kernels of libfusgpu.so
+    by default (GPU tensors; no CPU fallback) -- tests inject their own for
+    gloo-on-CPU runs.
 """
 
 from __future__ import annotations
@@ -65,6 +72,129 @@ class TorchComm:
 
     def barrier(self):
         dist.barrier(group=self.group)
+
+
+class NativeComm:
+    """Communicator owned by libfusgpu.so (RCCL over xGMI; csrc/halo_comm.hpp).
+
+    ``NativeComm()``: one rank per process / GPU.  The 128-byte RCCL unique id is created on rank 0
+    and broadcast through the default ``torch.distributed`` group (any backend: it is 128 bytes of
+    host data), which also carries the one-off integer index exchange of
+    ``compute_scatterer_data``; in a 1-rank world no process group is needed.
+    ``NativeComm(local=(world_id, nranks, rank))``: all ranks in THIS process (tests on a one-GPU
+    box), transport = stream-ordered device copies; every rank's ``begin`` of an exchange must be
+    called before any rank's ``end``."""
+
+    def __init__(self, group=None, local=None):
+        import ctypes as C
+
+        lib = _lib.load()
+        self._lib = lib
+        self.handle = C.c_void_p()
+        self._torch = None
+        if local is not None:
+            world_id, self.size, self.rank = (int(v) for v in local)
+            self.backend = "local"
+            _lib.check(lib.fus_comm_create_local(world_id, self.size, self.rank, C.byref(self.handle)), "fus_comm_create_local")
+            return
+        self.backend = "rccl"
+        if dist.is_available() and dist.is_initialized():
+            self._torch = TorchComm(group)
+            self.rank, self.size = self._torch.rank, self._torch.size
+        else:
+            self.rank, self.size = 0, 1
+        uid = torch.zeros(128, dtype=torch.uint8)
+        if self.rank == 0:
+            buf = C.create_string_buffer(128)
+            _lib.check(lib.fus_comm_unique_id(buf), "fus_comm_unique_id")
+            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        if self.size > 1:
+            dev = torch.device("cuda", torch.cuda.current_device()) if self._torch.backend == "nccl" else torch.device("cpu")
+            t = uid.to(dev)
+            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
+            uid = t.cpu()
+        raw = bytes(uid.numpy().tobytes())
+        _lib.check(lib.fus_comm_create(raw, self.size, self.rank, C.byref(self.handle)), "fus_comm_create")
+
+    def alltoallv_int64(self, send_np, send_counts, recv_counts):
+        """Set-up path (index exchange of compute_scatterer_data): through torch.distributed."""
+        if self._torch is None:
+            raise _lib.FusGpuError("NativeComm: the index exchange of a multi-rank world needs torch.distributed")
+        return self._torch.alltoallv_int64(send_np, send_counts, recv_counts)
+
+    def barrier(self):
+        if self._torch is not None:
+            self._torch.barrier()
+
+    def close(self):
+        if self.handle:
+            self._lib.fus_comm_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+
+class _NativeScatter:
+    """scatter_forward / scatter_reverse closure over ``fus_halo_*`` (the exchange is issued from C++)."""
+
+    def __init__(self, comm: NativeComm, owners_data, ghosts_data, N, float_type, reverse: bool, halo=None):
+        import ctypes as C
+
+        self.comm, self.N, self.reverse = comm, int(N), reverse
+        self.dtype = _lib.torch_dtype(float_type)
+        lib = _lib.load()
+        self._lib = lib
+        if halo is not None:  # share the plan + buffers of another closure (same vector never in flight twice)
+            self._owner, self.handle = halo, halo.handle
+        else:
+            o_idx, o_size, _, o_ranks = to_flat(owners_data)
+            g_idx, g_size, _, g_ranks = to_flat(ghosts_data)
+            self.handle = C.c_void_p()
+            self._owner = None
+
+            def arr(a, dt):
+                a = np.ascontiguousarray(a, dtype=dt)
+                return a, a.ctypes.data_as(C.c_void_p)
+
+            keep = [arr(o_ranks, np.int32), arr(o_size, np.int64), arr(o_idx, np.int64),
+                    arr(g_ranks, np.int32), arr(g_size, np.int64), arr(g_idx, np.int64)]
+            _lib.check(
+                lib.fus_halo_create(comm.handle, 8 if self.dtype == torch.float64 else 4, self.N, int(len(o_idx)),
+                                    len(o_ranks), keep[0][1], keep[1][1], keep[2][1],
+                                    len(g_ranks), keep[3][1], keep[4][1], keep[5][1], C.byref(self.handle)),
+                "fus_halo_create", comm.handle)
+        self.nghost = None
+        self.direct = bool(lib.fus_halo_is_direct(self.handle) == 1)
+        self.active = True
+        sfx = "reverse" if reverse else "forward"
+        self._begin, self._end = getattr(lib, f"fus_halo_{sfx}_begin"), getattr(lib, f"fus_halo_{sfx}_end")
+
+    def begin(self, buffer):
+        _lib.require_device_tensor(buffer, self.dtype, "buffer")
+        _lib.check(self._begin(self.handle, buffer.data_ptr(), _lib.stream_ptr()), "fus_halo_begin", self.comm.handle)
+        return None
+
+    def end(self, buffer, work=None):
+        _lib.check(self._end(self.handle, buffer.data_ptr(), _lib.stream_ptr()), "fus_halo_end", self.comm.handle)
+
+    def __call__(self, buffer):
+        self.begin(buffer)
+        self.end(buffer)
+
+    def close(self):
+        if self._owner is None and self.handle:
+            self._lib.fus_halo_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class HipHaloKernels:
@@ -173,10 +303,14 @@ class _Scatter:
 
 
 def scatter_reverse(comm, owners_data, ghosts_data, N, float_type, kernels=None):
+    if isinstance(comm, NativeComm):
+        return _NativeScatter(comm, owners_data, ghosts_data, N, float_type, True)
     return _Scatter(comm, owners_data, ghosts_data, N, float_type, True, kernels)
 
 
 def scatter_forward(comm, owners_data, ghosts_data, N, float_type, kernels=None):
+    if isinstance(comm, NativeComm):
+        return _NativeScatter(comm, owners_data, ghosts_data, N, float_type, False)
     return _Scatter(comm, owners_data, ghosts_data, N, float_type, False, kernels)
 
 
@@ -195,13 +329,15 @@ class HaloApply:
     (``mesh.num_boundary_cells``), as ``BoxMesh`` does.
     """
 
-    def __init__(self, mesh, op, comm, float_type, overlap=True, kernels=None, apply_fn=None):
+    def __init__(self, mesh, op, comm, float_type, overlap=True, kernels=None, apply_fn=None, plan=None):
         from .utils import compute_scatterer_data_flat
 
         self.mesh = mesh
         self.op = op
         self.comm = comm
-        od, gd = compute_scatterer_data_flat(mesh.index_map, comm)
+        # plan = (owners_data, ghosts_data) already computed (e.g. by the reference-style
+        # compute_scatterer_data of a driver); default: exchange the indices over ``comm`` now
+        od, gd = plan if plan is not None else compute_scatterer_data_flat(mesh.index_map, comm)
         self.owners_data, self.ghosts_data = od, gd
         self.fwd = scatter_forward(comm, od, gd, mesh.nlocal, float_type, kernels)
         self.rev = scatter_reverse(comm, od, gd, mesh.nlocal, float_type, kernels)
@@ -240,24 +376,41 @@ class HaloApply:
         G, detJ, dofmap, ...).  ``forward`` / ``reverse``: lists of ``(scatter closure, vector)``.
         ``boundary_terms()`` adds boundary-facet contributions; it runs after every forward scatter
         has landed and before the reverse scatters are posted (facet dofs can be ghosts)."""
+        for _ in self.schedule(cell_fn, percell, forward, reverse, boundary_terms):
+            pass
+
+    def schedule(self, cell_fn, percell, forward, reverse, boundary_terms=None):
+        """The stage of ``run`` as a generator that yields each time this rank has POSTED a set of
+        exchanges (``"forward"`` / ``"reverse"``) and is about to do work that does not depend on
+        them.  One rank per process never needs the yields (``run`` just exhausts them); a host
+        that drives several ranks from one thread (``NativeComm(local=...)``) advances all ranks'
+        generators in lock step, so every rank has posted before any rank completes."""
         def part(name):
             a, b = self.ranges[name]
             if b > a:
                 cell_fn(*self._views(name, percell))
 
         if not self.overlap:
-            for sc, vec in forward:
-                sc(vec)
+            fw = [(sc, vec, sc.begin(vec)) for sc, vec in forward]
+            yield "forward"
+            for sc, vec, wk in fw:
+                sc.end(vec, wk)
             for name in ("boundary", "interior1", "interior2"):
                 part(name)
             if boundary_terms is not None:
                 boundary_terms()
-            for sc, vec in reverse:
-                sc(vec)
+            rv = [(sc, vec, sc.begin(vec)) for sc, vec in reverse]
+            yield "reverse"
+            for sc, vec, wk in rv:
+                sc.end(vec, wk)
             return
-        on_gpu = self.side_stream and len(forward) > 0 and forward[0][1].is_cuda
+        on_gpu = self.side_stream and len(forward) > 0 and forward[0][1].is_cuda and not isinstance(self.comm, NativeComm)
         if not on_gpu:
+            # NativeComm: begin() hands pack -> exchange -> unpack to the library's own high-priority
+            # stream and returns; end() only makes this stream wait for it.  TorchComm: pack is
+            # enqueued here, the collective on RCCL's stream, the unpack in end().
             fw = [(sc, vec, sc.begin(vec)) for sc, vec in forward]
+            yield "forward"
             part("interior1")
             for sc, vec, wk in fw:
                 sc.end(vec, wk)
@@ -265,13 +418,14 @@ class HaloApply:
             if boundary_terms is not None:
                 boundary_terms()
             rv = [(sc, vec, sc.begin(vec)) for sc, vec in reverse]
+            yield "reverse"
             part("interior2")
             for sc, vec, wk in rv:
                 sc.end(vec, wk)
             return
-        # GPU: the whole exchange chain (pack -> all-to-all-v -> unpack) runs on a high-priority
-        # side stream, so not even the pack / unpack launches sit between the operator kernels of
-        # the main stream; the two streams meet only where data demands it:
+        # TorchComm on the GPU with FUS_HALO_SIDE_STREAM=1: the whole exchange chain (pack ->
+        # all-to-all-v -> unpack) runs on a high-priority side stream; the two streams meet only
+        # where data demands it:
         #   side waits for main   : vectors ready to pack (start; after the boundary cells)
         #   main waits for side   : ghosts refreshed (before the boundary cells); sums landed (end)
         # Hazards: interior cells never touch ghost entries (unpack_fwd writes, pack_rev reads them);
@@ -307,9 +461,14 @@ class HaloApply:
     def apply(self, x, cell_constants, y, G, dofmap, extra_forward=(), boundary_terms=None):
         """y += K x on the partitioned mesh (``extra_forward``: further ``(scatter_forward closure,
         vector)`` pairs to refresh alongside x, e.g. v_n of the RK stage)."""
+        for _ in self.apply_schedule(x, cell_constants, y, G, dofmap, extra_forward, boundary_terms):
+            pass
+
+    def apply_schedule(self, x, cell_constants, y, G, dofmap, extra_forward=(), boundary_terms=None):
+        """``apply`` as a generator (see ``schedule``)."""
         fn = self._apply_fn if self._apply_fn is not None else self.op
-        self.run(lambda c_, G_, d_: fn(x, c_, y, G_, d_), (cell_constants, G, dofmap),
-                 [(self.fwd, x)] + list(extra_forward), [(self.rev, y)], boundary_terms)
+        return self.schedule(lambda c_, G_, d_: fn(x, c_, y, G_, d_), (cell_constants, G, dofmap),
+                             [(self.fwd, x)] + list(extra_forward), [(self.rev, y)], boundary_terms)
 
     def prepare(self, x, cell_constants, G, dofmap):
         """Set-up, not an apply: build the batch plans of the three cell sub-ranges and bring the

@@ -34,6 +34,7 @@ extern "C" {
 #define FUS_ERR_UNSUPPORTED_DEGREE (-2) /* P outside [FUS_MIN_DEGREE, FUS_MAX_DEGREE] */
 #define FUS_ERR_UNSUPPORTED_ENTITY (-3)
 #define FUS_ERR_NO_DEVICE (-4)
+#define FUS_ERR_COMM (-5) /* RCCL / communicator failure: fus_comm_last_error() has the text */
 #define FUS_ERR_HIP_BASE (-1000) /* -(1000 + hipError_t) for launch/runtime failures */
 
 #define FUS_MIN_DEGREE 1
@@ -233,6 +234,70 @@ int fus_pack_rev_f64(const double* in, double* out, const int64_t* index, int64_
 int fus_pack_rev_f32(const float* in, float* out, const int64_t* index, int64_t count, int64_t N, void* stream);
 int fus_unpack_rev_f64(const double* in, double* out, const int64_t* index, int64_t count, void* stream);
 int fus_unpack_rev_f32(const float* in, float* out, const int64_t* index, int64_t count, void* stream);
+
+/*
+ * Ghost-dof halo exchange (one process per GPU, RCCL over xGMI).
+ * replaces  cuda/scatterer.py:104-188  scatter_reverse(comm, owners_data, ghosts_data, N, float_type) -> scatter(buffer)
+ *      and  cuda/scatterer.py:191-277  scatter_forward(...)                                           -> scatter(buffer)
+ *      and  numba-cpu/scatterer.py:78-141, 144-207 (the same closures over host arrays)
+ *      and  the C++ driver's scatter calls, cpp/common/Linear.hpp:120,193,196,212
+ * The reference packs with one kernel per neighbour, device-synchronises, posts MPI Isend/Irecv on
+ * device pointers and synchronises again; here an exchange is pack -> grouped ncclSend/ncclRecv ->
+ * unpack on a library-owned high-priority stream, ordered against the caller's stream by events only
+ * (no host synchronisation), and split in begin / end so interior-cell work overlaps it.
+ *
+ * Communicator.  fus_comm_unique_id: rank 0 obtains FUS_UNIQUE_ID_BYTES bytes and broadcasts them by any
+ * means the host has (MPI_Bcast in the reference's drivers, torch.distributed in this repo's);
+ * fus_comm_create: collective over all ranks, binds the CURRENT HIP device (ncclCommInitRank).
+ * librccl.so.1 is resolved with dlopen on first use; libfusgpu.so does not link against it.
+ * fus_comm_create_local: all ranks live in one process (tests on a one-GPU box; one process driving
+ * several GPUs); ranks that pass the same world_id form a world.  Host-side contract of this transport:
+ * every rank's *_begin of an exchange is called before any rank's *_end of it.
+ */
+#define FUS_UNIQUE_ID_BYTES 128
+typedef struct fus_comm* fus_comm_t;
+typedef struct fus_halo* fus_halo_t;
+int fus_comm_unique_id(void* id /* FUS_UNIQUE_ID_BYTES */);
+int fus_comm_create(const void* id, int nranks, int rank, fus_comm_t* comm);
+int fus_comm_create_local(int world_id, int nranks, int rank, fus_comm_t* comm);
+int fus_comm_rank(fus_comm_t comm);
+int fus_comm_size(fus_comm_t comm);
+void* fus_comm_stream(fus_comm_t comm); /* the hipStream_t the exchanges run on */
+const char* fus_comm_last_error(fus_comm_t comm /* NULL: errors raised before a communicator existed */);
+int fus_comm_destroy(fus_comm_t comm);
+
+/*
+ * Halo plan = the reference's (owners_data, ghosts_data) of cuda/utils.py:8-78 compute_scatterer_data,
+ * passed as HOST arrays (copied at creation):
+ *   owners side: my ghost dofs grouped by owning rank -- owner_ranks[n_owner_ranks], owner_sizes[...],
+ *                owners_idx = concatenated positions inside my ghost block (vector index = nlocal + idx)
+ *   ghosts side: my owned dofs that other ranks ghost -- ghost_ranks, ghost_sizes,
+ *                ghosts_idx = concatenated local indices, in the order the ghosting rank packs them
+ * elem_bytes: 8 (double) or 4 (float).  Indices are range-checked here (the reference does not).
+ * If owners_idx == 0,1,2,... (ghosts numbered owner by owner) the ghost block of the vector is used as
+ * the message buffer of that side (fus_halo_is_direct() == 1): no unpack_fwd / pack_rev launch.
+ */
+int fus_halo_create(fus_comm_t comm, int elem_bytes, int64_t nlocal, int64_t nghost, int n_owner_ranks,
+                    const int32_t* owner_ranks, const int64_t* owner_sizes, const int64_t* owners_idx,
+                    int n_ghost_ranks, const int32_t* ghost_ranks, const int64_t* ghost_sizes,
+                    const int64_t* ghosts_idx, fus_halo_t* halo);
+int fus_halo_is_direct(fus_halo_t halo);
+int fus_halo_destroy(fus_halo_t halo);
+/*
+ * forward: buffer[nlocal + g] = owner's value, for every ghost g          (scatter_forward, overwrite)
+ * reverse: owner's buffer[i] += every ghosting rank's partial sum of i     (scatter_reverse, add)
+ * in place on ``buffer`` (device pointer, nlocal + nghost elements).  *_begin orders the exchange after
+ * everything already enqueued on ``stream`` and returns at once; *_end makes ``stream`` wait for its
+ * completion.  Between the two, work on ``stream`` must not touch what the exchange touches: the ghost
+ * entries (forward), or -- other than by atomic adds -- the owned entries being added to (reverse).
+ * One exchange per halo object may be in flight; use one object per vector exchanged concurrently.
+ */
+int fus_halo_forward_begin(fus_halo_t halo, void* buffer, void* stream);
+int fus_halo_forward_end(fus_halo_t halo, void* buffer, void* stream);
+int fus_halo_reverse_begin(fus_halo_t halo, void* buffer, void* stream);
+int fus_halo_reverse_end(fus_halo_t halo, void* buffer, void* stream);
+int fus_halo_forward(fus_halo_t halo, void* buffer, void* stream); /* begin + end */
+int fus_halo_reverse(fus_halo_t halo, void* buffer, void* stream);
 
 #ifdef __cplusplus
 }

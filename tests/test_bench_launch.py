@@ -1,0 +1,82 @@
+"""bench.py as the driver starts it (missing #1): ``python bench.py --gpus N`` with no
+launcher must start its own N ranks before touching the GPU, relay ONE JSON line and propagate
+failures; the torch.distributed.run form must keep working.  On CPU the ranks rehearse with
+``--dry-run`` (gloo; partition + halo plan + all-to-all-v with the real counts; nothing measured);
+on the GPU box the N = 1 line is run through the N > 1 code path (FUS_BENCH_FORCE_DIST=1: HaloApply
++ the RCCL communicator of libfusgpu.so / of torch)."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+from conftest import ROOT
+
+BENCH = os.path.join(ROOT, "bench.py")
+
+
+def _env(**kw):
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT", "MASTER_ADDR")}
+    env.update(OMP_NUM_THREADS="1", HSA_ENABLE_IPC_MODE_LEGACY="0", **kw)
+    return env
+
+
+def _one_json_line(stdout):
+    lines = [l for l in stdout.splitlines() if l.strip().startswith("{")]
+    assert len(lines) == 1, stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.parametrize("n", [2, 8])
+def test_self_spawn_dry_run(n):
+    r = subprocess.run([sys.executable, BENCH, "--gpus", str(n), "--dry-run", "--steps", "2", "--warmup", "1", "--degree", "2",
+                        "--cells", "2"], env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == n and out["ranks"] == n and out["dry_run"] is True and out["valid"] is False
+    assert out["halo_ok"] is True
+    assert out["scaling"] == "weak" and out["steps"] == 2 and out["warmup"] == 1
+
+
+def test_torchrun_form_dry_run():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), BENCH, "--gpus", "2", "--dry-run", "--steps", "2", "--warmup", "1", "--degree", "2", "--cells", "2"]
+    r = subprocess.run(cmd, env=_env(), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == 2 and out["halo_ok"] is True
+
+
+def test_failed_rank_fails_the_launch():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--degree", "2", "--cells", "2"],
+                       env=_env(FUS_BENCH_TEST_FAIL_RANK="1"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
+def test_gpus_mismatch_is_an_error():
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-run"], env=_env(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"),
+                       capture_output=True, text=True, timeout=120)
+    assert r.returncode != 0 and "launcher started 2 ranks" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("halo", ["native", "torch"])
+def test_distributed_code_path_on_one_gpu(halo):
+    """The N > 1 code path (HaloApply, three cell sub-ranges, halo begin/end, communicator bring-up) in a
+    1-rank world on the GPU box, through bench.py itself."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "5", "--warmup", "2", "--cells", "16", "--no-cpu-baseline",
+                        "--halo", halo], env=_env(FUS_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    cfg = out["config"]
+    assert out["n_gpus"] == 1 and cfg["ranks"] == 1 and cfg["halo"] == "overlapped"
+    assert cfg["halo_exposed_ms"] is not None and out["value"] > 0
+    assert ("libfusgpu" in cfg["halo_transport"]) == (halo == "native")
+    assert out["roofline"]["kernel_ms"] > 0 and cfg["lib_sha"]

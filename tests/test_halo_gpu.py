@@ -1,0 +1,282 @@
+"""GPU parity of the halo path (SURVEY 8 rows a8 / a9 / b):
+
+  * the four pack / unpack kernels (cuda/scatterer.py:18-101) against what the reference's own
+    scatter closures produced on the same partitions (tests/golden/scatter_*.npz), f64 and f32;
+  * the native exchange behind the C ABI (fus_halo_*, csrc/halo_comm.hpp) on the same fixtures,
+    all ranks in this process (in-process transport: stream-ordered device copies, no host sync),
+    owner-grouped ghosts (direct mode) and arbitrary ghost numberings (unpack_fwd / pack_rev);
+  * the overlapped partitioned apply (HaloApply) with 2 / 4 / 8 ranks sharing cuda:0, ghosts NOT
+    numbered owner by owner, asynchronous transport, against the serial oracle;
+  * the RCCL transport itself in a 1-rank world: a rank that is its own neighbour
+    (grouped ncclSend / ncclRecv to self).
+RCCL refuses two ranks on one device, so N > 1 RCCL cannot run on a one-GPU box."""
+
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import build_problem, golden_files, pkg, rel_l2, ref_field
+from halo_cpu import global_cell_constants
+
+pytestmark = pytest.mark.gpu
+
+_world_ids = itertools.count(1000)
+
+
+@pytest.fixture(scope="module")
+def gpu():
+    import torch
+
+    if not torch.cuda.is_available():
+        pytest.fail("GPU tests need a visible MI355X (no CPU fallback exists)")
+    torch.cuda.set_device(0)
+    return torch
+
+
+def _partition(d, ghost_order="owner"):
+    boxmesh, utils = pkg("boxmesh"), pkg("utils")
+    P, shape, grid = int(d["P"]), tuple(int(v) for v in d["shape"]), tuple(int(v) for v in d["grid"])
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, ghost_order=ghost_order) for r in range(R)]
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    return meshes, od, gd
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("path", golden_files("scatter_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_pack_unpack_kernels_vs_reference_closures(gpu, path, dtype):
+    """pack_fwd / unpack_fwd / pack_rev / unpack_rev, each launched explicitly (no direct-mode
+    short cut), messages carried between the simulated ranks through a host mailbox."""
+    torch = gpu
+    scat = pkg("scatterer")
+    d = np.load(path)
+    meshes, od, gd = _partition(d)
+    R = len(meshes)
+    k = scat.HipHaloKernels(torch.float64 if dtype == np.float64 else torch.float32)
+    dev = torch.device("cuda", 0)
+    for kind in ("fwd", "rev"):
+        bufs = [torch.from_numpy(d[f"in_{r}"].astype(dtype)).to(dev) for r in range(R)]
+        box = {}
+        for r in range(R):  # pack + "send"
+            N = meshes[r].nlocal
+            side = gd[r] if kind == "fwd" else od[r]
+            idx, size, off, ranks = side
+            send = k.buffer(len(idx))
+            if len(idx):
+                if kind == "fwd":
+                    k.pack_fwd(bufs[r], send, k.index_tensor(idx))
+                else:
+                    k.pack_rev(bufs[r], send, k.index_tensor(idx), N)
+            host = send.cpu().numpy()
+            for i, dst in enumerate(ranks):
+                box[(r, int(dst))] = host[off[i]:off[i + 1]]
+        for r in range(R):  # "recv" + unpack
+            N = meshes[r].nlocal
+            side = od[r] if kind == "fwd" else gd[r]
+            idx, size, off, ranks = side
+            if len(idx) == 0:
+                continue
+            recv = torch.from_numpy(np.concatenate([box[(int(src), r)] for src in ranks])).to(dev)
+            if kind == "fwd":
+                k.unpack_fwd(recv, bufs[r], k.index_tensor(idx), N)
+            else:
+                k.unpack_rev(recv, bufs[r], k.index_tensor(idx))
+        torch.cuda.synchronize()
+        for r in range(R):
+            ref = d[f"ref_{kind}_{r}"]
+            got = bufs[r].cpu().numpy()
+            if kind == "fwd":  # pure copies: exact
+                assert np.array_equal(got, ref.astype(dtype)), f"{kind} rank {r}"
+            else:
+                assert np.allclose(got, ref, rtol=0, atol=1e-13 if dtype == np.float64 else 2e-6), f"{kind} rank {r}"
+
+
+def _native_scatterers(meshes, od, gd, float_type):
+    scat = pkg("scatterer")
+    wid = next(_world_ids)
+    R = len(meshes)
+    comms = [scat.NativeComm(local=(wid, R, r)) for r in range(R)]
+    fwd = [scat.scatter_forward(comms[r], od[r], gd[r], meshes[r].nlocal, float_type) for r in range(R)]
+    rev = [scat.scatter_reverse(comms[r], od[r], gd[r], meshes[r].nlocal, float_type) for r in range(R)]
+    return comms, fwd, rev
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("path", golden_files("scatter_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_native_halo_vs_reference_closures(gpu, path, dtype):
+    """fus_halo_forward / fus_halo_reverse (C ABI) on the reference's fixtures; BoxMesh numbers its
+    ghosts owner by owner, so this is the direct mode (ghost block = message buffer)."""
+    torch = gpu
+    d = np.load(path)
+    meshes, od, gd = _partition(d)
+    R = len(meshes)
+    comms, fwd, rev = _native_scatterers(meshes, od, gd, dtype)
+    assert all(f.direct for f, m in zip(fwd, meshes) if m.nghost > 0)
+    dev = torch.device("cuda", 0)
+    for kind, closures in (("fwd", fwd), ("rev", rev)):
+        bufs = [torch.from_numpy(d[f"in_{r}"].astype(dtype)).to(dev) for r in range(R)]
+        for rep in range(2 if kind == "fwd" else 1):  # forward is idempotent: run it twice (buffer reuse)
+            for r in range(R):
+                closures[r].begin(bufs[r])
+            for r in range(R):
+                closures[r].end(bufs[r])
+        torch.cuda.synchronize()
+        for r in range(R):
+            ref, got = d[f"ref_{kind}_{r}"], bufs[r].cpu().numpy()
+            if kind == "fwd":
+                assert np.array_equal(got, ref.astype(dtype))
+            else:
+                assert np.allclose(got, ref, rtol=0, atol=1e-13 if dtype == np.float64 else 2e-6)
+
+
+@pytest.mark.parametrize("ghost_order", ["lex", 3, 11])
+@pytest.mark.parametrize("P,shape,grid", [(2, (4, 4, 2), (2, 2, 1)), (3, (4, 4, 4), (2, 2, 2)), (2, (6, 2, 2), (3, 1, 1))])
+def test_native_halo_arbitrary_ghost_numbering(gpu, P, shape, grid, ghost_order):
+    """Ghosts not grouped by owner (every real dolfinx IndexMap): the exchange must go through
+    unpack_fwd / pack_rev.  Checked against the numpy restatement of the reference's closures
+    (oracle/oracle_np.py, itself pinned by the golden fixtures) and by the owner-value property."""
+    from oracle import oracle_np
+
+    torch = gpu
+    boxmesh, utils = pkg("boxmesh"), pkg("utils")
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, ghost_order=ghost_order) for r in range(R)]
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    comms, fwd, rev = _native_scatterers(meshes, od, gd, np.float64)
+    if R > 3 and ghost_order != "lex":
+        assert not all(f.direct for f in fwd), "the test must exercise the non-direct path"
+    dev = torch.device("cuda", 0)
+    rng = np.random.default_rng(4)
+    host = [rng.standard_normal(m.ndofs) for m in meshes]
+    nl = [m.nlocal for m in meshes]
+    for kind, closures, oracle in (("fwd", fwd, oracle_np.scatter_forward_all), ("rev", rev, oracle_np.scatter_reverse_all)):
+        ref = [h.copy() for h in host]
+        oracle(ref, od, gd, nl)
+        bufs = [torch.from_numpy(h).to(dev) for h in host]
+        for r in range(R):
+            closures[r].begin(bufs[r])
+        for r in range(R):
+            closures[r].end(bufs[r])
+        torch.cuda.synchronize()
+        for r in range(R):
+            got = bufs[r].cpu().numpy()
+            assert np.allclose(got, ref[r], rtol=0, atol=1e-13), f"{kind} rank {r}"
+    # property: after a forward scatter of the global lexicographic id every ghost holds its own id
+    bufs = []
+    for r, m in enumerate(meshes):
+        lex = m.global_lexicographic_ids().astype(np.float64)
+        v = lex.copy()
+        v[m.nlocal:] = -1.0
+        bufs.append((torch.from_numpy(v).to(dev), lex))
+    for r in range(R):
+        fwd[r].begin(bufs[r][0])
+    for r in range(R):
+        fwd[r].end(bufs[r][0])
+    torch.cuda.synchronize()
+    for t, lex in bufs:
+        assert np.array_equal(t.cpu().numpy(), lex)
+
+
+@pytest.mark.parametrize("overlap", [True, False], ids=["overlap", "sequential"])
+@pytest.mark.parametrize("P,cells,grid,ghost_order", [
+    (4, (4, 4, 4), (2, 1, 1), "owner"),
+    (3, (4, 4, 2), (2, 2, 1), 7),
+    (2, (4, 4, 4), (2, 2, 2), 7),
+    (4, (6, 4, 4), (2, 2, 1), "lex"),
+], ids=["2ranks-direct", "4ranks-permuted", "8ranks-permuted", "4ranks-lex"])
+def test_partitioned_apply_async_transport_one_gpu(gpu, oracle_c, P, cells, grid, ghost_order, overlap):
+    """HaloApply with the exchange issued from C++ on its own stream, all ranks on cuda:0 in this
+    process, NO host synchronisation between pack, exchange, unpack and the operator kernels: the
+    begin | interior | end -> boundary -> begin | interior | end schedule runs with real
+    asynchrony.  Must equal the serial apply dof for dof."""
+    torch = gpu
+    boxmesh, scat, ops, gll, pre = (pkg(m) for m in ("boxmesh", "scatterer", "operators", "gll", "precompute"))
+    R = int(np.prod(grid))
+    wid = next(_world_ids)
+    dev = torch.device("cuda", 0)
+    pts, wts, D = gll.tabulate_1d(P)
+    n = P + 1
+    w3 = gll.tensor_weights_3d(wts)
+    dg = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))
+    op = ops.stiffness_operator(P, D.flatten(), np.float64)
+    ranks = []
+    for r in range(R):
+        mesh = boxmesh.BoxMesh(P, cells, grid=grid, rank=r, perturb=0.16, seed=3, ghost_order=ghost_order)
+        G = np.zeros((mesh.ncells, n**3, 6))
+        pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), mesh.ncells, dg, w3)
+        x = ref_field(mesh.dof_coordinates())
+        x[mesh.nlocal:] = -777.0  # ghosts are stale until the forward scatter
+        ranks.append(dict(mesh=mesh, x=torch.from_numpy(x).to(dev), y=torch.zeros(mesh.ndofs, dtype=torch.float64, device=dev),
+                          cc=torch.from_numpy(global_cell_constants(mesh)).to(dev), G=torch.from_numpy(G).to(dev),
+                          dm=torch.from_numpy(mesh.dofmap).to(dev)))
+
+    utils = pkg("utils")  # an in-process world: every rank's halo plan at once
+    od, gd = utils.compute_scatterer_data_all([rk["mesh"].index_map for rk in ranks])
+    halos = []
+    for r, rk in enumerate(ranks):
+        comm = scat.NativeComm(local=(wid, R, r))
+        halos.append(scat.HaloApply(rk["mesh"], op, comm, np.float64, overlap=overlap, plan=(od[r], gd[r])))
+    for rep in range(2):  # second apply: buffers / events reused while the first may still be in flight
+        for rk in ranks:
+            rk["y"].zero_()
+        gens = [h.apply_schedule(rk["x"], rk["cc"], rk["y"], rk["G"], rk["dm"]) for h, rk in zip(halos, ranks)]
+        live = list(gens)
+        while live:
+            nxt = []
+            for g in live:
+                try:
+                    next(g)
+                    nxt.append(g)
+                except StopIteration:
+                    pass
+            live = nxt
+    torch.cuda.synchronize()
+    # serial reference
+    pb = build_problem(P, cells, perturb=0.16, seed=3)
+    ms = pb["mesh"]
+    y_ser = np.zeros(ms.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], global_cell_constants(ms), y_ser, pb["G"], ms.dofmap)
+    seen = np.zeros(ms.ndofs, dtype=int)
+    for rk in ranks:
+        m = rk["mesh"]
+        lex = m.global_lexicographic_ids()
+        seen[lex[: m.nlocal]] += 1
+        assert rel_l2(rk["y"].cpu().numpy()[: m.nlocal], y_ser[lex[: m.nlocal]]) < 1e-12
+        assert np.allclose(rk["x"].cpu().numpy(), pb["x"][lex], rtol=0, atol=1e-12)  # ghosts refreshed
+    assert np.all(seen == 1)
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("direct", [True, False], ids=["direct", "permuted"])
+def test_rccl_self_exchange(gpu, dtype, direct):
+    """The RCCL transport (ncclGroupStart / ncclSend / ncclRecv / ncclGroupEnd issued by libfusgpu.so
+    on its own stream) in a 1-rank world whose only rank is its own neighbour."""
+    torch = gpu
+    scat = pkg("scatterer")
+    comm = scat.NativeComm()  # no process group: world size 1, unique id stays local
+    assert comm.size == 1 and comm.backend == "rccl"
+    rng = np.random.default_rng(12)
+    N, ng = 5000, 1200
+    o_idx = np.arange(ng) if direct else rng.permutation(ng)
+    g_idx = rng.choice(N, size=ng, replace=False)
+    od = [o_idx.astype(np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+    gd = [g_idx.astype(np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+    fwd = scat.scatter_forward(comm, od, gd, N, dtype)
+    rev = scat.scatter_reverse(comm, od, gd, N, dtype)
+    assert fwd.direct == direct
+    host = rng.standard_normal(N + ng).astype(dtype)
+    dev = torch.device("cuda", 0)
+    buf = torch.from_numpy(host).to(dev)
+    fwd(buf)
+    ref = host.copy()
+    ref[N + o_idx] = host[g_idx]
+    torch.cuda.synchronize()
+    assert np.array_equal(buf.cpu().numpy(), ref)
+    buf = torch.from_numpy(host).to(dev)
+    rev(buf)
+    ref = host.copy()
+    np.add.at(ref, g_idx, host[N + o_idx])
+    torch.cuda.synchronize()
+    assert np.allclose(buf.cpu().numpy(), ref, rtol=0, atol=1e-14 if dtype == np.float64 else 1e-6)
+    fwd.close(), rev.close(), comm.close()
