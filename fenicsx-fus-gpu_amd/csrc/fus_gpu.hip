@@ -135,7 +135,7 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
       case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, 1, fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
     }                                                                                                     \

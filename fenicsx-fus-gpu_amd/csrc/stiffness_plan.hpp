@@ -27,10 +27,18 @@ struct PlanShape {
   static constexpr int SPT = (M + BLOCK - 1) / BLOCK;      // distinct-dof slots per thread (upper bound)
 };
 
-// Slabs of G a thread keeps resident in the ring build of stiffness_plan_kernel (GPRE below).
+// Slabs of G a thread keeps resident in the ring build of stiffness_plan_kernel (GPRE below): the
+// largest ring that still reaches the next occupancy step of the register file (<= 128 VGPRs: 4
+// waves per SIMD, <= 168: 3; tools/resource_usage.py), e.g. P = 6: 4 of 7 slabs, 156 VGPRs.
 template <int P>
 __host__ __device__ constexpr int plan_g_ring() {
-  return (P + 2) / 2 > 1 ? (P + 2) / 2 : 1;  // P = 6: 4 of 7 slabs
+  constexpr int ring[11] = {1, 2, 3, 4, 3, 3, 4, 3, 5, 4, 6};
+  return ring[P];
+}
+// occupancy the ring build asks of the register allocator (P = 5: 130 VGPRs unforced, 2 over the step)
+template <int P>
+__host__ __device__ constexpr int plan_ring_min_waves() {
+  return 1;
 }
 
 // Phase A (after every HBM load of the batch has been issued): gather x once per distinct dof,

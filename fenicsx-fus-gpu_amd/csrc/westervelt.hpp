@@ -17,12 +17,17 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
-#include "plan.hpp"
+#include "stiffness_plan.hpp"
 
 namespace fus {
 
-template <typename T, int P, int CPB>
-__global__ void __launch_bounds__((col_block_threads<P, CPB>()))
+// GPRE: slabs of G held in registers (ring, as stiffness_plan_kernel): n = whole slab up front.
+// LDS: three cubes only.  The lumped-mass sums are accumulated EARLY, in the region that held the u
+// values, and flushed before the flux cubes are written -- while the G loads are still in flight --
+// instead of living in a fourth array to the end of the kernel (P = 6: 58 -> 45 KB, 3 workgroups
+// per CU instead of 2 once the registers allow it).
+template <typename T, int P, int CPB, int MINW, int GPRE>
+__global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     westervelt_cell_kernel(const T* __restrict__ u_in, const T* __restrict__ v_in, const T* __restrict__ c2,
                            const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
                            T* __restrict__ b, T* __restrict__ m, const T* __restrict__ G, const T* __restrict__ detJ,
@@ -33,16 +38,18 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
   constexpr int BLOCK = col_block_threads<P, CPB>();
   constexpr int M = CPB * Nd;
   constexpr int SPT = (M + BLOCK - 1) / BLOCK;
+  static_assert(GPRE >= 1 && GPRE <= n, "GPRE: slabs of G held in registers");
 
-  // regions: su (combined input cube, later the b accumulator), sfy (u values, later flux y),
-  // sfz (v values, later flux z), sm (m accumulator)
+  // regions: su (combined input cube, later the b accumulator), sfy (u values, then the m
+  // accumulator, later flux y), sfz (v values, later flux z)
   __shared__ T sD[n2];
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
-  __shared__ T sm[M];
+  __shared__ int s_runs[2 * kPlanMaxRuns];
   T* const sxu = sfy;
   T* const sxv = sfz;
+  T* const sm = sfy;
   T* const sb = su;
 
   const int tid = threadIdx.x;
@@ -52,7 +59,6 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
   const int ty = t / n, tz = t - ty * n;
   const int64_t cell = (int64_t)batch * CPB + lc;
   const bool active = (lc < CPB) && (cell < ncell);
-  __shared__ int s_runs[2 * kPlanMaxRuns];
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = packed >> 16;
   const int32_t* ud = udofs + (int64_t)batch * M;
@@ -62,44 +68,46 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
   int32_t mydof[SPT];
   const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
   uint16_t sl[n];
-  T g[n][6];
+  T g[GPRE][6];
   T dj[n];
   T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
+  const T* Gc = G + (cell * Nd + t) * 6;
   if (active) {
     const uint16_t* sp = slot + cell * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
-    const T* Gc = G + (cell * Nd + t) * 6;
-#pragma unroll
-    for (int ix = 0; ix < n; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
     const T* dc = detJ + cell * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) dj[ix] = dc[ix * n2];
+#pragma unroll
+    for (int ix = 0; ix < GPRE; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
     k2 = c2[cell];
     k3 = c3[cell];
     k4 = c4[cell];
     k5 = c5[cell];
   }
   batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
-  T xu[SPT], xv[SPT];
+  {
+    T xu[SPT], xv[SPT];
 #pragma unroll
-  for (int r = 0; r < SPT; ++r) {
-    xu[r] = u_in[mydof[r]];
-    xv[r] = v_in[mydof[r]];
-  }
+    for (int r = 0; r < SPT; ++r) {
+      xu[r] = u_in[mydof[r]];
+      xv[r] = v_in[mydof[r]];
+    }
 #pragma unroll
-  for (int r = 0; r < SPT; ++r) {
-    const int s = tid + r * BLOCK;
-    if (s < nu_b) {
-      sxu[s] = xu[r];
-      sxv[s] = xv[r];
-      sm[s] = T(0);
+    for (int r = 0; r < SPT; ++r) {
+      const int s = tid + r * BLOCK;
+      if (s < nu_b) {
+        sxu[s] = xu[r];
+        sxv[s] = xv[r];
+      }
     }
   }
   __syncthreads();  // B1
 
   T w[n];       // combined stiffness input  c3 u + c4 v
   T bextra[n];  // detJ c5 v^2
+  T madd[n];    // detJ c2 u   (lumped-mass contribution; dead after the early flush below)
   if (active) {
     T* cu = su + lc * S + t;
 #pragma unroll
@@ -107,11 +115,21 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
       const T uu = sxu[sl[ix]], vv = sxv[sl[ix]];
       w[ix] = k3 * uu + k4 * vv;
       bextra[ix] = dj[ix] * k5 * vv * vv;
-      lds_atomic_add(&sm[sl[ix]], dj[ix] * k2 * uu);
+      madd[ix] = dj[ix] * k2 * uu;
       cu[ix * n2] = w[ix];
     }
   }
-  __syncthreads();  // B2: u / v values are dead, the flux cubes may be written
+  __syncthreads();  // B2: u / v values are dead; the input cube is complete
+  // ---- lumped mass: pre-reduce in the dead u-value region and flush, under the shadow of the G loads
+  plan_zero<T, SPT, BLOCK>(sm, nu_b, tid);
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], madd[ix]);
+  }
+  __syncthreads();
+  plan_flush<T, SPT, BLOCK>(m, mydof, nu_b, tid, sm);
+  __syncthreads();  // the m sums have been read: the region becomes the flux-y cube
 
   T fx[n];
   if (active) {
@@ -127,27 +145,19 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
     T* cfz = sfz + lc * S + t;
 #pragma unroll
     for (int qx = 0; qx < n; ++qx) {
-      T vx = T(0);
-#pragma unroll
-      for (int ix = 0; ix < n; ++ix) vx += dphi[qx * n + ix] * w[ix];
-      T vy = T(0), vz = T(0);
-#pragma unroll
-      for (int i = 0; i < n; ++i) {
-        vy += dy[i] * cu_y[qx * n2 + i * n];
-        vz += dz[i] * cu_z[qx * n2 + i];
-      }
-      const T* gq = g[qx];
+      T vx, vy, vz;
+      plan_grad_at<T, n, n2>(qx, dphi, w, dy, dz, cu_y, cu_z, vx, vy, vz);
+      const T* gq = g[qx % GPRE];
       fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
       cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
       cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
+      if constexpr (GPRE < n) {
+        if (qx + GPRE < n) load_g6<T>(Gc + (int64_t)(qx + GPRE) * n2 * 6, g[qx % GPRE]);
+      }
     }
   }
   __syncthreads();  // B3: the input cube is dead: it becomes the b accumulator
-#pragma unroll
-  for (int r = 0; r < SPT; ++r) {
-    const int s = tid + r * BLOCK;
-    if (s < nu_b) sb[s] = T(0);
-  }
+  plan_zero<T, SPT, BLOCK>(sb, nu_b, tid);
   __syncthreads();  // B3.5
 
   if (active) {
@@ -173,15 +183,13 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()))
     }
   }
   __syncthreads();  // B4
+  plan_flush<T, SPT, BLOCK>(b, mydof, nu_b, tid, sb);
+}
 
-#pragma unroll
-  for (int r = 0; r < SPT; ++r) {
-    const int s = tid + r * BLOCK;
-    if (s < nu_b) {
-      unsafeAtomicAdd(b + mydof[r], sb[s]);
-      unsafeAtomicAdd(m + mydof[r], sm[s]);
-    }
-  }
+// Slabs of G resident per thread in the shipped build: whole slab up to P = 5, ring above.
+template <int P>
+__host__ __device__ constexpr int westervelt_g_ring() {
+  return P <= 3 ? P + 1 : plan_g_ring<P>();
 }
 
 template <typename T, int P>
@@ -192,8 +200,9 @@ inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, co
   if (ncell <= 0) return hipSuccess;
   PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
-  hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u, v, c2,
-                     c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell);
+  constexpr int MINW = 1;
+  hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, westervelt_g_ring<P>()>), dim3((unsigned)pv.nbatch),
+                     dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell);
   return hipGetLastError();
 }
 

@@ -31,10 +31,14 @@ from __future__ import annotations
 import numpy as np
 
 
-def _owners_side(index_map):
+def _owners_side(index_map, stable=True):
     owners = np.asarray(index_map.owners)
     unique_owners, owners_size = np.unique(owners, return_counts=True)
-    order = np.argsort(owners, kind="stable").astype(np.int64)
+    # stable: ghosts keep their relative order inside one owner's group, so ghosts numbered owner by
+    # owner give the identity list (direct mode of the exchange).  stable=False is the reference's
+    # ``np.argsort(owners)`` (cuda/utils.py:28, numpy's default introsort): same groups, possibly
+    # another order inside a group -- any order is a valid plan as both sides of an exchange share it
+    order = (np.argsort(owners, kind="stable") if stable else np.argsort(owners)).astype(np.int64)
     offsets = np.concatenate(([0], np.cumsum(owners_size))).astype(np.int64)
     return unique_owners.astype(np.int32), owners_size.astype(np.int64), offsets, order
 
@@ -48,7 +52,7 @@ def _ghosting_ranks(index_map):
     return unique_ghosts.astype(np.int32), ghosts_size.astype(np.int64)
 
 
-def compute_scatterer_data_all(index_maps):
+def compute_scatterer_data_all(index_maps, stable=True):
     """All ranks at once, in one process (tests / single-process simulation).
 
     Returns ``(owners_data_all, ghosts_data_all)`` in the flat 4-element format
@@ -58,7 +62,7 @@ def compute_scatterer_data_all(index_maps):
     owners_all, ghosts_all = [], []
     sent = {}
     for r, im in enumerate(index_maps):
-        uo, osz, ooff, order = _owners_side(im)
+        uo, osz, ooff, order = _owners_side(im, stable)
         owners_all.append([order, osz, ooff, uo])
         gl = np.asarray(im.ghosts)[order]
         for i, o in enumerate(uo):
@@ -75,10 +79,10 @@ def compute_scatterer_data_all(index_maps):
     return owners_all, ghosts_all
 
 
-def compute_scatterer_data_flat(index_map, comm=None):
+def compute_scatterer_data_flat(index_map, comm=None, stable=True):
     """One rank's halo plan, flat format; the index exchange uses ``comm``
     (``.rank``, ``.size``, ``.alltoallv_int64(send, send_counts, recv_counts)``)."""
-    uo, osz, ooff, order = _owners_side(index_map)
+    uo, osz, ooff, order = _owners_side(index_map, stable)
     ug, gsz = _ghosting_ranks(index_map)
     goff = np.concatenate(([0], np.cumsum(gsz))).astype(np.int64)
     if comm is None:
@@ -130,9 +134,9 @@ def to_flat(data):
     return [idx, size, off, np.asarray(ranks, dtype=np.int32)]
 
 
-def compute_scatterer_data(index_map, comm=None):
+def compute_scatterer_data(index_map, comm=None, stable=True):
     """cuda/utils.py:8-78 call surface (3-element list format)."""
-    od, gd = compute_scatterer_data_flat(index_map, comm)
+    od, gd = compute_scatterer_data_flat(index_map, comm, stable)
     return to_lists(od), to_lists(gd)
 
 

@@ -37,7 +37,25 @@ for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"
     if kernel_key in r["Name"]:
         stats = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])}
 bench = json.load(open(os.path.join(src, "bench_trace.json")))
-res = {"tag": tag, "kernel_stats": stats, "dispatch": meta, "counters": counters}
+res = {"tag": tag, "kernel_stats": stats, "dispatch": meta, "counters": counters, "lib_sha": bench.get("config", {}).get("lib_sha")}
+# back-to-back launches overlap at their tails: besides the per-dispatch durations of --stats, take the
+# longest run of consecutive dispatches of the kernel from the trace and divide its span by its length
+tr = os.path.join(src, "trace", "trace_kernel_trace.csv")
+if os.path.exists(tr):
+    rows = [(int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if kernel_key in r["Kernel_Name"]]
+    rows.sort()
+    best = (0, 0, 0)
+    i = 0
+    while i < len(rows):
+        j = i
+        while j + 1 < len(rows) and rows[j + 1][0] - rows[j][1] < 3000:  # next starts within 3 us of this one's end (or before it)
+            j += 1
+        if j - i + 1 > best[0]:
+            best = (j - i + 1, rows[i][0], rows[j][1])
+        i = j + 1
+    if best[0] > 1:
+        res["back_to_back_run"] = {"launches": best[0], "span_ns_per_launch": (best[2] - best[1]) / best[0],
+                                   "mean_dispatch_ns_in_trace": sum(e - b for b, e in rows) / len(rows)}
 if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     f, w = counters["FETCH_SIZE"]["mean_per_launch"], counters["WRITE_SIZE"]["mean_per_launch"]
     res["hbm_bytes_per_launch"] = (2 * f + w) * 1024
@@ -46,7 +64,8 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     ncell = bench["config"]["cells_per_gpu"]
     res["algorithmic_bytes_per_launch"] = ncell * bench["roofline"]["algorithmic_bytes_per_cell"]
     res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
-    json.dump({"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"], "source": f"profiles/{tag}_counters.json"},
+    json.dump({"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
+               "source": f"profiles/{tag}_counters.json", "lib_sha": res["lib_sha"]},
               open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
 if "TCC_EA0_ATOMIC_sum" in counters and stats:
     res["atomic_requests_per_s"] = counters["TCC_EA0_ATOMIC_sum"]["mean_per_launch"] / (stats["avg_ns"] * 1e-9)

@@ -59,9 +59,21 @@ def _install_stubs():
 
     MPI.Request = Request
     MPI.Comm = Comm
+    MPI.COMM_WORLD = None  # set to the FakeComm of the simulated rank before each reference call
     mpi.MPI = MPI
     sys.modules["mpi4py"] = mpi
     sys.modules["mpi4py.MPI"] = MPI
+
+    # cuda/utils.py imports dolfinx names it only uses in functions that are never called here
+    dfx = types.ModuleType("dolfinx")
+    dmesh = types.ModuleType("dolfinx.mesh")
+    dmesh.Mesh = object
+    dgeo = types.ModuleType("dolfinx.geometry")
+    dgeo.bb_tree = dgeo.compute_collisions_points = dgeo.compute_colliding_cells = None
+    dfx.mesh, dfx.geometry = dmesh, dgeo
+    sys.modules["dolfinx"] = dfx
+    sys.modules["dolfinx.mesh"] = dmesh
+    sys.modules["dolfinx.geometry"] = dgeo
 
 
 class FakeWorld:
@@ -104,7 +116,7 @@ def main():
         # numba-cpu/test_operators.py:274-279
         return 100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])
 
-    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter | plan
 
     # ---- operator + precompute fixtures --------------------------------------
     cases = []
@@ -229,6 +241,47 @@ def main():
         tag = f"scatter_P{P}_{shape[0]}x{shape[1]}x{shape[2]}_grid{grid[0]}x{grid[1]}x{grid[2]}"
         np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
         print("wrote", tag)
+
+
+    # ---- halo plan fixtures: the reference's own compute_scatterer_data -------------------
+    # cuda/utils.py:8-78, run rank by rank on BoxMesh index maps (which duck-type the dolfinx
+    # IndexMap members it touches: size_local, num_ghosts, owners, ghosts, local_range,
+    # index_to_dest_ranks()), MPI.COMM_WORLD = the simulated rank's FakeComm.
+    if only in ("all", "plan"):
+        import importlib.util
+        import mpi4py.MPI as MPI  # the stub
+
+        spec = importlib.util.spec_from_file_location("ref_cuda_utils", os.path.join(REF, "cuda", "utils.py"))
+        ref_utils = importlib.util.module_from_spec(spec)
+        spec.loader.exec_module(ref_utils)
+        plan_cases = [(2, (4, 2, 2), (2, 1, 1), "owner"), (3, (2, 4, 2), (1, 2, 1), "owner"), (2, (4, 4, 2), (2, 2, 1), "owner"),
+                      (2, (2, 2, 2), (2, 2, 2), "owner"), (2, (4, 4, 2), (2, 2, 1), 7), (2, (4, 4, 4), (2, 2, 2), "lex"),
+                      (3, (3, 3, 3), (3, 1, 1), 5)]
+        for P, shape, grid, ghost_order in plan_cases:
+            R = int(np.prod(grid))
+            meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, ghost_order=ghost_order) for r in range(R)]
+            world = FakeWorld()
+            results = [None] * R
+            for final in (False, True):  # pass 1 fills the mailbox with every rank's sends
+                for r in range(R):
+                    MPI.COMM_WORLD = FakeComm(world, r)
+                    try:
+                        results[r] = ref_utils.compute_scatterer_data(meshes[r].index_map)
+                    except KeyError:
+                        assert not final
+            out = {"P": P, "shape": np.array(shape), "grid": np.array(grid), "ghost_order": str(ghost_order)}
+            for r in range(R):
+                (o_idx, o_size, o_ranks), (g_idx, g_size, g_ranks) = results[r]
+                cat = lambda lst: np.concatenate([np.asarray(a, dtype=np.int64) for a in lst]) if len(lst) else np.zeros(0, np.int64)  # noqa: E731
+                out[f"owners_idx_{r}"] = cat(o_idx)
+                out[f"owners_size_{r}"] = np.asarray(o_size, dtype=np.int64)
+                out[f"unique_owners_{r}"] = np.asarray(o_ranks, dtype=np.int64)
+                out[f"ghosts_idx_{r}"] = cat(g_idx)
+                out[f"ghosts_size_{r}"] = np.asarray(g_size, dtype=np.int64)
+                out[f"unique_ghosts_{r}"] = np.asarray(g_ranks, dtype=np.int64)
+            tag = f"halo_plan_P{P}_{shape[0]}x{shape[1]}x{shape[2]}_grid{grid[0]}x{grid[1]}x{grid[2]}_{ghost_order}"
+            np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
+            print("wrote", tag)
 
 
 if __name__ == "__main__":

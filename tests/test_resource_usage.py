@@ -50,9 +50,9 @@ SHIPPED = [
     (r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>", 96, 5),
     (r"stiffness_plan_affine_kernel<double, 6, 5, true, true, 1>", 168, 3),
     # fused Westervelt cell pass
-    (r"westervelt_cell_kernel<double, 4, 10>", 168, 3),
-    (r"westervelt_cell_kernel<double, 6, 5>", 256, 2),
-    (r"westervelt_cell_kernel<float, 4, 10>", 96, 5),
+    (r"westervelt_cell_kernel<double, 4, 10, 1, 3>", 128, 4),
+    (r"westervelt_cell_kernel<double, 6, 5, 1, 4>", 168, 3),   # BASELINE config 5 degree
+    (r"westervelt_cell_kernel<float, 4, 10, 1, 3>", 96, 5),
     # plan-free column kernel
     (r"stiffness_col_kernel<double, 4, 10>", 128, 4),
 ]

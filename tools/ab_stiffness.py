@@ -30,6 +30,7 @@ def main():
     ap.add_argument("--rounds", type=int, default=7)
     ap.add_argument("--reps", type=int, default=10)
     ap.add_argument("--dtype", default="f64")
+    ap.add_argument("--isolated", action="store_true", help="one event pair per launch (launches cannot overlap at their tails)")
     ap.add_argument("--order", default="lex", choices=["lex", "random", "morton"], help="cell order of the dofmap")
     ap.add_argument("configs", nargs="*", default=["plan", "plan:0", "plan:1", "plan:2"])
     a = ap.parse_args()
@@ -85,18 +86,29 @@ def main():
             else:
                 lib.set_tuning(lib.TUNE_PLAN_VARIANT, k)
                 d_ = dm_raw if kind == "raw" else dm
-            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             fn(x, cc, y, G, d_)
-            e0.record()
-            for _ in range(a.reps):
-                fn(x, cc, y, G, d_)
-            e1.record()
-            torch.cuda.synchronize()
+            if a.isolated:
+                evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
+                for e0, e1 in evs:
+                    e0.record()
+                    fn(x, cc, y, G, d_)
+                    e1.record()
+                torch.cuda.synchronize()
+                tms = float(np.mean([e0.elapsed_time(e1) for e0, e1 in evs]))
+            else:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                for _ in range(a.reps):
+                    fn(x, cc, y, G, d_)
+                e1.record()
+                torch.cuda.synchronize()
+                tms = e0.elapsed_time(e1) / a.reps
             if rnd > 0:
-                times[name].append(e0.elapsed_time(e1) / a.reps)
+                times[name].append(tms)
     lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
     bpc = bench.stiffness_bytes_per_cell(a.degree, np.dtype(dt).itemsize)
-    print(f"P={a.degree} cells={a.cells}^3 dtype={a.dtype} order={a.order} dofs={mesh.ndofs} lib={lib.LIB_PATH}")
+    print(f"P={a.degree} cells={a.cells}^3 dtype={a.dtype} order={a.order} dofs={mesh.ndofs} lib={lib.LIB_PATH} "
+          f"timing={'isolated launches' if a.isolated else 'back-to-back launches'}")
     for name in a.configs:
         t = np.array(times[name])
         gbs = mesh.ncells * bpc / (np.median(t) * 1e-3) / 1e9
