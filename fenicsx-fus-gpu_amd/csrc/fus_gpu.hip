@@ -7,6 +7,8 @@
 #include <atomic>
 #include <cstdio>
 #include <cstring>
+#include <mutex>
+#include <unordered_map>
 
 #include "geometry.hpp"
 #include "halo.hpp"
@@ -36,6 +38,33 @@ inline int plan_allow_runs(int ndof_per_entity) {
   return mode == 2 ? 1 : (mode == 1 ? (ndof_per_entity <= 64) : 0);
 }
 std::atomic<int> g_plan_variant{-1};  // -1 = auto
+
+// Host mirror of the plans built through this library, keyed by workspace address: the apply entry
+// points check that a workspace was built, and for the (N, entities per batch, entity count) they are
+// called with, before any kernel indexes it (a mismatch would gather / scatter out of bounds), and
+// learn from it whether the plan carries a cell order.
+struct PlanInfo {
+  int N = 0, epb = 0;
+  int64_t nent = 0;
+  bool ordered = false;
+};
+std::mutex g_plans_mu;
+std::unordered_map<const void*, PlanInfo> g_plans;
+
+void plan_register(const void* ws, int N, int epb, int64_t nent, bool ordered) {
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  g_plans[ws] = PlanInfo{N, epb, nent, ordered};
+}
+// true if ``ws`` holds a plan for exactly this shape; ``ordered`` out
+bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered) {
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  auto it = g_plans.find(ws);
+  if (it == g_plans.end()) return false;
+  const PlanInfo& p = it->second;
+  if (p.N != N || p.epb != epb || p.nent != nent) return false;
+  *ordered = p.ordered;
+  return true;
+}
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
 
@@ -80,6 +109,11 @@ int stiffness_apply(const T* x, const T* cc, T* y, const T* G, const int32_t* do
   return hip_rc(e);
 }
 
+inline int cells_per_batch(int P) {
+  const int n2 = (P + 1) * (P + 1);
+  return 256 / n2 > 0 ? 256 / n2 : 1;
+}
+
 template <int P>
 int64_t plan_bytes_p(int64_t ncell) {
   return fus::plan_view(nullptr, P, fus::plan_cells_per_batch<P>(), ncell).bytes;
@@ -100,11 +134,11 @@ int64_t plan_bytes(int P, int64_t ncell) {
 // fp32 build with 5 waves per SIMD (only instantiated for float)
 template <typename T, int P>
 hipError_t launch_plan_f32_5w(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int64_t ncell,
-                              int remap, hipStream_t s) {
+                              int remap, hipStream_t s, bool ord) {
   if constexpr (sizeof(T) == 4 && P <= 4)
-    return fus::launch_stiffness_plan<T, P, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s);
+    return fus::launch_stiffness_plan<T, P, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s, ord);
   else
-    return fus::launch_stiffness_plan<T, P, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s);
+    return fus::launch_stiffness_plan<T, P, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord);
 }
 
 template <typename T>
@@ -115,6 +149,8 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   if (ncell == 0) return FUS_OK;
   if (!x || !cc || !y || !G || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  bool ord = false;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
@@ -134,10 +170,10 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
-      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
-      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s); break; \
+      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break;   \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break; \
+      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break; \
+      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break; \
     }                                                                                                     \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
@@ -155,6 +191,8 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   if (ncell == 0) return FUS_OK;
   if (!x || !cc || !y || !G || !wratio || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  bool ord = false;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
   // P <= 4: unpadded LDS + 5 waves per SIMD (+8 %, profiles/r01f_affine_fast_path.log); above, registers do
@@ -162,7 +200,7 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s); \
+    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -179,12 +217,14 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   if (ncell == 0) return FUS_OK;
   if (!x || !cc || !y || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  bool ord = false;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>()>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s); \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>()>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -201,12 +241,14 @@ int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c
   if (ncell == 0) return FUS_OK;
   if (!u || !v || !c2 || !c3 || !c4 || !c5 || !b || !m || !G || !detJ || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  bool ord = false;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_westervelt_cell<T, PP>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s); \
+    e = fus::launch_westervelt_cell<T, PP>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -246,7 +288,9 @@ int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const v
   if (nent < 0 || N < 2 || epb < 1 || (int64_t)N * epb > fus::kPlanMaxEntries) return FUS_ERR_INVALID_ARGUMENT;
   if (nent == 0) return FUS_OK;
   if (!x || !consts || !y || !detJ || !ws || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream)));
+  bool ord = false;
+  if (!plan_check(ws, N, epb, nent, &ord)) return FUS_ERR_PLAN_MISMATCH;
+  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord));
 }
 
 }  // namespace
@@ -262,6 +306,8 @@ const char* fus_error_string(int code) {
     case FUS_ERR_UNSUPPORTED_DEGREE: return "unsupported polynomial degree";
     case FUS_ERR_UNSUPPORTED_ENTITY: return "unsupported entity size";
     case FUS_ERR_NO_DEVICE: return "no HIP device";
+    case FUS_ERR_PLAN_MISMATCH:
+      return "workspace holds no plan built through this library for this (degree / entity size, entity count)";
     case FUS_ERR_COMM: return "communicator / RCCL failure (see fus_comm_last_error)";
     default:
       if (code <= FUS_ERR_HIP_BASE) return hipGetErrorString((hipError_t)(FUS_ERR_HIP_BASE - code));
@@ -321,23 +367,9 @@ int64_t fus_stiffness_plan_bytes(int P, int64_t ncell) {
 
 int fus_stiffness_plan_build(const int32_t* dofmap, int P, int64_t ncell, void* workspace, int64_t workspace_bytes,
                              void* stream) {
-  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
   if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
-  if (!workspace || misaligned(workspace, 256) || workspace_bytes < plan_bytes(P, ncell)) return FUS_ERR_INVALID_ARGUMENT;
-  if (ncell == 0) return FUS_OK;
-  if (!dofmap) return FUS_ERR_INVALID_ARGUMENT;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipErrorInvalidValue;
-  switch (P) {
-#define FUS_CASE(PP) \
-  case PP:           \
-    e = fus::launch_plan_build<PP>(dofmap, ncell, workspace, s, plan_allow_runs((PP + 1) * (PP + 1) * (PP + 1))); \
-    break;
-    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
-    FUS_CASE(10)
-#undef FUS_CASE
-  }
-  return hip_rc(e);
+  return fus_plan_build_ordered(dofmap, nullptr, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, workspace,
+                                workspace_bytes, stream);
 }
 
 int fus_stiffness_apply_planned_f64(const double* x, const double* cc, double* y, const double* G, const void* ws,
@@ -368,13 +400,22 @@ int64_t fus_plan_bytes(int N, int entities_per_batch, int64_t nent) {
 
 int fus_plan_build(const int32_t* dofmap, int N, int entities_per_batch, int64_t nent, void* workspace,
                    int64_t workspace_bytes, void* stream) {
+  return fus_plan_build_ordered(dofmap, nullptr, N, entities_per_batch, nent, workspace, workspace_bytes, stream);
+}
+
+int fus_plan_build_ordered(const int32_t* dofmap, const int32_t* entity_order, int N, int entities_per_batch,
+                           int64_t nent, void* workspace, int64_t workspace_bytes, void* stream) {
   const int64_t need = fus_plan_bytes(N, entities_per_batch, nent);
   if (need < 0) return (int)need;
   if (!workspace || misaligned(workspace, 256) || workspace_bytes < need) return FUS_ERR_INVALID_ARGUMENT;
-  if (nent == 0) return FUS_OK;
-  if (!dofmap) return FUS_ERR_INVALID_ARGUMENT;
-  return hip_rc(fus::launch_plan_build_generic(dofmap, N, entities_per_batch, nent, workspace,
-                                               static_cast<hipStream_t>(stream), plan_allow_runs(N)));
+  if (nent > 0 && !dofmap) return FUS_ERR_INVALID_ARGUMENT;
+  if (nent > 0) {
+    const hipError_t e = fus::launch_plan_build_generic(dofmap, N, entities_per_batch, nent, workspace,
+                                                        static_cast<hipStream_t>(stream), plan_allow_runs(N), entity_order);
+    if (e != hipSuccess) return hip_rc(e);
+  }
+  plan_register(workspace, N, entities_per_batch, nent, entity_order != nullptr);
+  return FUS_OK;
 }
 
 int fus_mass_apply_planned_f64(const double* x, const double* c, double* y, const double* detJ, const void* ws, int N,

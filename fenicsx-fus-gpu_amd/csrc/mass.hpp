@@ -51,7 +51,8 @@ template <typename T, int EPT>
 __global__ void __launch_bounds__(256)
     mass_plan_kernel(const T* __restrict__ x, const T* __restrict__ entity_constants, T* __restrict__ y,
                      const T* __restrict__ detJ, const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
-                     const uint16_t* __restrict__ slot, int N, int epb, int64_t nent, uint32_t inv_n) {
+                     const uint16_t* __restrict__ slot, int N, int epb, int64_t nent, uint32_t inv_n,
+                     const int32_t* __restrict__ order) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int M = N * epb;
   T* sx = reinterpret_cast<T*>(smem_raw);
@@ -78,7 +79,12 @@ __global__ void __launch_bounds__(256)
     const int ic = i < valid ? i : 0;
     sl[r] = slot[base + ic];
     const uint32_t e = __umulhi((uint32_t)ic, inv_n);  // ic / N
-    w[r] = detJ[base + ic] * entity_constants[ent0 + e];
+    if (order != nullptr) {  // entity at batch position e is order[ent0 + e]
+      const int64_t ent = order[ent0 + e];
+      w[r] = detJ[ent * N + (ic - (int)e * N)] * entity_constants[ent];
+    } else {
+      w[r] = detJ[base + ic] * entity_constants[ent0 + e];
+    }
   }
   batch_dofs_resolve<EPT, 256>(rt, nu_b, nr_b, tid, s_runs, mydof);
   T xv[EPT];
@@ -108,7 +114,7 @@ __global__ void __launch_bounds__(256)
 
 template <typename T>
 inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* detJ, const void* workspace, int N,
-                                   int epb, int64_t nent, hipStream_t stream) {
+                                   int epb, int64_t nent, hipStream_t stream, bool ordered = false) {
   if (nent <= 0) return hipSuccess;
   const int M = N * epb;
   if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
@@ -118,7 +124,7 @@ inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* d
   const dim3 grid((unsigned)v.nbatch), block(256);
 #define FUS_MASS_LAUNCH(E)                                                                                        \
   hipLaunchKernelGGL((mass_plan_kernel<T, E>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \
-                     N, epb, nent, inv_n)
+                     N, epb, nent, inv_n, ordered ? v.order : nullptr)
   const int ept = (M + 255) / 256;
   if (ept <= 1) FUS_MASS_LAUNCH(1);
   else if (ept <= 2) FUS_MASS_LAUNCH(2);

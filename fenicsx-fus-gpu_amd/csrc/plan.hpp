@@ -20,6 +20,9 @@
 //                                   a structured numbering gives ~n^2 long runs per batch, so the
 //                                   list shrinks from 4 nu bytes to 8 nr bytes (P = 4: 4100 -> 200)
 //   slot   uint16[nbatch][CPB*Nd]   slot of (cell, local dof) = position in udofs[b]
+//   order  int32 [nent]             optional cell order: batch b holds the entities order[b*CPB ..]
+//                                   (set-up-time locality reordering WITHOUT moving G / detJ / constants:
+//                                   the apply kernels index those arrays through it); unused otherwise
 // Nd = (P+1)^3; the last batch may be ragged (cells >= ncell are never touched).
 #pragma once
 
@@ -54,6 +57,7 @@ struct PlanView {
   int32_t* nu;
   int32_t* udofs;
   uint16_t* slot;
+  int32_t* order;
   int64_t bytes;
 };
 
@@ -70,6 +74,8 @@ inline PlanView plan_view_generic(void* workspace, int N, int epb, int64_t nent)
   off += align256(v.nbatch * v.entries * (int64_t)sizeof(int32_t));
   v.slot = reinterpret_cast<uint16_t*>(base + off);
   off += align256(v.nbatch * v.entries * (int64_t)sizeof(uint16_t));
+  v.order = reinterpret_cast<int32_t*>(base + off);
+  off += align256(nent * (int64_t)sizeof(int32_t));
   v.bytes = off;
   return v;
 }
@@ -84,7 +90,8 @@ inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
 template <int M2>
 __global__ void __launch_bounds__(256)
     plan_build_kernel(const int32_t* __restrict__ dofmap, int64_t nent, int N, int epb, int32_t* __restrict__ nu,
-                      int32_t* __restrict__ udofs, uint16_t* __restrict__ slot, int allow_runs) {
+                      int32_t* __restrict__ udofs, uint16_t* __restrict__ slot, int allow_runs,
+                      const int32_t* __restrict__ order) {
   constexpr int CH = M2 / 256;  // elements per thread in the scan phase
   __shared__ uint64_t keys[M2];
   __shared__ int cnt[256];
@@ -97,8 +104,20 @@ __global__ void __launch_bounds__(256)
   const int valid = (int)((left < epb ? left : epb) * N);
   const int32_t* dm = dofmap + ent0 * N;
 
-  for (int i = tid; i < M2; i += 256)
-    keys[i] = (i < valid) ? (((uint64_t)(uint32_t)dm[i] << 16) | (uint64_t)i) : ~0ull;
+  for (int i = tid; i < M2; i += 256) {
+    uint64_t k = ~0ull;
+    if (i < valid) {
+      int32_t d;
+      if (order) {  // entity at batch position e = i / N is order[ent0 + e]
+        const int e = i / N;
+        d = dofmap[(int64_t)order[ent0 + e] * N + (i - e * N)];
+      } else {
+        d = dm[i];
+      }
+      k = ((uint64_t)(uint32_t)d << 16) | (uint64_t)i;
+    }
+    keys[i] = k;
+  }
   __syncthreads();
 
   for (int k = 2; k <= M2; k <<= 1) {
@@ -182,31 +201,38 @@ __global__ void __launch_bounds__(256)
 constexpr int kPlanMaxEntries = 4096;  // per batch; slot ids are 16-bit, keys live in LDS
 
 inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int epb, int64_t nent, void* workspace,
-                                            hipStream_t stream, int allow_runs = 1) {
+                                            hipStream_t stream, int allow_runs = 1,
+                                            const int32_t* cell_order = nullptr) {
   if (nent <= 0) return hipSuccess;
   const int M = epb * N;
   if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
   PlanView v = plan_view_generic(workspace, N, epb, nent);
   if (v.nbatch > 0x7fffffffLL) return hipErrorInvalidValue;
-  int64_t hdr[6] = {kPlanMagic, N, epb, nent, v.nbatch, v.entries};
+  int64_t hdr[7] = {kPlanMagic, N, epb, nent, v.nbatch, v.entries, cell_order ? 1 : 0};
   hipError_t e = hipMemcpyAsync(workspace, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) return e;
+  const int32_t* order = nullptr;
+  if (cell_order) {  // keep a copy inside the workspace: the plan is self-contained
+    e = hipMemcpyAsync(v.order, cell_order, nent * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
+    if (e != hipSuccess) return e;
+    order = v.order;
+  }
   const dim3 grid((unsigned)v.nbatch), block(256);
   if (M <= 256)
     hipLaunchKernelGGL((plan_build_kernel<256>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
-                       allow_runs);
+                       allow_runs, order);
   else if (M <= 512)
     hipLaunchKernelGGL((plan_build_kernel<512>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
-                       allow_runs);
+                       allow_runs, order);
   else if (M <= 1024)
     hipLaunchKernelGGL((plan_build_kernel<1024>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
-                       allow_runs);
+                       allow_runs, order);
   else if (M <= 2048)
     hipLaunchKernelGGL((plan_build_kernel<2048>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
-                       allow_runs);
+                       allow_runs, order);
   else
     hipLaunchKernelGGL((plan_build_kernel<4096>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
-                       allow_runs);
+                       allow_runs, order);
   return hipGetLastError();
 }
 

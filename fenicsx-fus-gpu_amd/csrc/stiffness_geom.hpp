@@ -34,7 +34,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                                const T* __restrict__ x_g, const int32_t* __restrict__ x_dofs,
                                const T* __restrict__ pts, const T* __restrict__ wts,
                                const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
-                               const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell) {
+                               const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell,
+                               const int32_t* __restrict__ order) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
   constexpr int VPT = (CPB * 24 + BLOCK - 1) / BLOCK;  // vertex coordinates staged per thread (1 for P >= 4)
@@ -56,8 +57,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int t = tid - lc * n2;
   const int ty = t / n, tz = t - ty * n;
   const int64_t cell0 = (int64_t)batch * CPB;
-  const int64_t cell = cell0 + lc;
-  const bool active = (lc < CPB) && (cell < ncell);
+  const int64_t pos = cell0 + lc;  // position in the plan's cell order
+  const bool active = (lc < CPB) && (pos < ncell);
+  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = packed >> 16;
   const int32_t* ud = udofs + (int64_t)batch * M;
@@ -77,12 +79,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const int e = tid + r * BLOCK;
     const int c = e / 24, v = (e - c * 24) / 3;
     const bool ok = (e < CPB * 24) && (cell0 + c < ncell);
-    vid[r] = ok ? x_dofs[(cell0 + c) * 8 + v] : 0;
+    vid[r] = ok ? x_dofs[(order != nullptr ? (int64_t)order[cell0 + c] : cell0 + c) * 8 + v] : 0;
   }
   uint16_t sl[n];
   T coeff = T(0);
   if (active) {
-    const uint16_t* sp = slot + cell * Nd + t;
+    const uint16_t* sp = slot + pos * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
     coeff = cell_constants[cell];
@@ -184,13 +186,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 template <typename T, int P, bool ALIAS, bool PADLDS, int MINW>
 inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs,
                                              const T* pts, const T* wts, const void* workspace, const T* dphi,
-                                             int64_t ncell, hipStream_t stream) {
+                                             int64_t ncell, hipStream_t stream, bool ordered = false) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW>), dim3((unsigned)v.nbatch),
-                     dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell);
+                     dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
+                     ordered ? v.order : nullptr);
   return hipGetLastError();
 }
 

@@ -148,7 +148,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
                           const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
-                          const T* __restrict__ dphi, int64_t ncell, int xcd_remap) {
+                          const T* __restrict__ dphi, int64_t ncell, int xcd_remap,
+                          const int32_t* __restrict__ order) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
   static_assert(GPRE >= 1 && GPRE <= n, "GPRE: slabs of G held in registers");
@@ -167,8 +168,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int lc = tid / n2;
   const int t = tid - lc * n2;
   const int ty = t / n, tz = t - ty * n;
-  const int64_t cell = (int64_t)batch * CPB + lc;
-  const bool active = (lc < CPB) && (cell < ncell);
+  const int64_t pos = (int64_t)batch * CPB + lc;  // position in the plan's cell order
+  const bool active = (lc < CPB) && (pos < ncell);
+  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = packed >> 16;
   const int32_t* ud = udofs + (int64_t)batch * M;
@@ -183,7 +185,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   T coeff = T(0);
   const T* Gc = G + (cell * Nd + t) * 6;
   if (active) {
-    const uint16_t* sp = slot + cell * Nd + t;
+    const uint16_t* sp = slot + pos * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
 #pragma unroll
@@ -234,13 +236,15 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 
 template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, int GPRE = P + 1>
 inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
-                                        const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream) {
+                                        const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream,
+                                        bool ordered = false) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GPRE>), dim3((unsigned)v.nbatch),
-                     dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap);
+                     dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap,
+                     ordered ? v.order : nullptr);
   return hipGetLastError();
 }
 

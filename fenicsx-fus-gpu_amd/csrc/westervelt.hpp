@@ -32,7 +32,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                            const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
                            T* __restrict__ b, T* __restrict__ m, const T* __restrict__ G, const T* __restrict__ detJ,
                            const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
-                           const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell) {
+                           const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell,
+                           const int32_t* __restrict__ order) {
   constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
   constexpr int S = lds_cell_stride<T, P>();
   constexpr int BLOCK = col_block_threads<P, CPB>();
@@ -57,8 +58,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int lc = tid / n2;
   const int t = tid - lc * n2;
   const int ty = t / n, tz = t - ty * n;
-  const int64_t cell = (int64_t)batch * CPB + lc;
-  const bool active = (lc < CPB) && (cell < ncell);
+  const int64_t pos = (int64_t)batch * CPB + lc;  // position in the plan's cell order
+  const bool active = (lc < CPB) && (pos < ncell);
+  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = packed >> 16;
   const int32_t* ud = udofs + (int64_t)batch * M;
@@ -73,7 +75,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
   const T* Gc = G + (cell * Nd + t) * 6;
   if (active) {
-    const uint16_t* sp = slot + cell * Nd + t;
+    const uint16_t* sp = slot + pos * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
     const T* dc = detJ + cell * Nd + t;
@@ -195,14 +197,15 @@ __host__ __device__ constexpr int westervelt_g_ring() {
 template <typename T, int P>
 inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5,
                                          T* b, T* m, const T* G, const T* detJ, const void* workspace, const T* dphi,
-                                         int64_t ncell, hipStream_t stream) {
+                                         int64_t ncell, hipStream_t stream, bool ordered = false) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   constexpr int MINW = 1;
   hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, westervelt_g_ring<P>()>), dim3((unsigned)pv.nbatch),
-                     dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell);
+                     dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell,
+                     ordered ? pv.order : nullptr);
   return hipGetLastError();
 }
 

@@ -98,3 +98,33 @@ def test_c_abi_demo_plain_cpp_host():
         subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "C_ABI_DEMO_OK" in r.stdout, r.stdout + r.stderr
+
+
+def test_raw_golden_twin_matches_npz():
+    """tests/golden/ops_P4_2x2x2_pert_float64.bin (read by examples/c_abi_golden.cpp) is the same data as
+    the reference-generated .npz."""
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    import export_raw
+
+    d = np.load(os.path.join(ROOT, "tests", "golden", export_raw.CASE + ".npz"))
+    with open(os.path.join(ROOT, "tests", "golden", export_raw.CASE + ".bin"), "rb") as f:
+        assert f.read() == export_raw.encode(d)
+
+
+@pytest.mark.gpu
+def test_c_abi_golden_plain_cpp_host():
+    """examples/c_abi_golden.cpp: a C++ host with no Python/torch compares stiffness (three entry points),
+    cell / facet mass and the device precompute with the REFERENCE'S outputs (golden twin), and runs a
+    fus_halo_* exchange over the RCCL transport in a 1-rank world."""
+    import subprocess
+
+    exe = os.path.join(ROOT, "examples", "c_abi_golden")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "ops_P4_2x2x2_pert_float64.bin")],
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0 and "C_ABI_GOLDEN_OK" in r.stdout, r.stdout + r.stderr

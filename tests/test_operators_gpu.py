@@ -490,3 +490,98 @@ def test_in_kernel_geometry_full_size_properties(gpu):
     ops.stiffness_operator(P, D.flatten(), np.float64)(u, cc, Ku2, G, dm)
     err = float((Ku - Ku2).norm() / Ku2.norm())
     assert err < 1e-12, err
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [1, 2, 4, 6])
+def test_random_cell_order_uses_locality_plan(gpu, oracle_c, P, dtype):
+    """A dofmap whose rows are in random order: the plan cache builds the batches in min-dof order (an
+    index indirection inside the plan -- G, detJ and the constants are NOT permuted) for every planned
+    kernel: stiffness, in-kernel geometry, affine, cell mass, fused Westervelt pass."""
+    dev, ops = gpu
+    gll = pkg("gll")
+    pb = build_problem(P, (4, 3, 5) if P <= 4 else (3, 2, 3), dtype=dtype, perturb=0.2, seed=21)
+    mesh = pb["mesh"]
+    perm = np.random.default_rng(3).permutation(mesh.ncells)
+    dm, G, detJ, cc, xd = (np.ascontiguousarray(a[perm]) for a in (mesh.dofmap, pb["G"], pb["detJ"], pb["cc"], mesh.x_dofs))
+    x_d, cc_d, dm_d, G_d, dJ_d = (dev.to_device(a) for a in (pb["x"], cc, dm, G, detJ))
+    ops._PLANS.clear()
+    # stiffness
+    y_ref = np.zeros(mesh.ndofs, dtype=dtype)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], cc, y_ref, G, dm)
+    y = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    ops.stiffness_operator(P, pb["D"].flatten(), dtype)(x_d, cc_d, y, G_d, dm_d)
+    assert ops._PLANS.last_order is not None, "the random order must have triggered the locality plan"
+    _check(y.copy_to_host(), y_ref, dtype, "stiffness, ordered plan")
+    # in-kernel geometry
+    y = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    ops.stiffness_operator(P, pb["D"].flatten(), dtype, geometry=(xd, mesh.x_g, pb["pts"], pb["wts"]))(x_d, cc_d, y, None, dm_d)
+    _check(y.copy_to_host(), y_ref, dtype, "in-kernel geometry, ordered plan")
+    # cell mass through the same plan
+    y_ref = np.zeros(mesh.ndofs, dtype=dtype)
+    oracle_c.mass_apply(pb["x"], cc, y_ref, detJ, dm)
+    y = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    old_min, ops._MASS_PLAN_MIN_ENTRIES = ops._MASS_PLAN_MIN_ENTRIES, 1
+    try:
+        ops.mass_operator((P + 1) ** 3, dtype)(x_d, cc_d, y, dJ_d, dm_d)
+    finally:
+        ops._MASS_PLAN_MIN_ENTRIES = old_min
+    _check(y.copy_to_host(), y_ref, dtype, "mass, ordered plan")
+    # fused Westervelt pass: b += K(c3) u + K(c4) v + M(c5) v^2 ; m += M(c2) u
+    rng = np.random.default_rng(8)
+    v = rng.standard_normal(mesh.ndofs).astype(dtype)
+    c2, c3, c4, c5 = ((0.5 + rng.random(mesh.ncells)).astype(dtype) for _ in range(4))
+    b_ref, m_ref = np.zeros(mesh.ndofs, dtype=dtype), np.zeros(mesh.ndofs, dtype=dtype)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], c3, b_ref, G, dm)
+    oracle_c.stiffness_apply(P, pb["D"], v, c4, b_ref, G, dm)
+    oracle_c.mass_apply((v * v).astype(dtype), c5, b_ref, detJ, dm)
+    oracle_c.mass_apply(pb["x"], c2, m_ref, detJ, dm)
+    b, m = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype)), dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    ops.westervelt_cell_operator(P, pb["D"].flatten(), dtype)(x_d, dev.to_device(v), dev.to_device(c2), dev.to_device(c3),
+                                                              dev.to_device(c4), dev.to_device(c5), b, m, G_d, dJ_d, dm_d)
+    _check(b.copy_to_host(), b_ref, dtype, "Westervelt b, ordered plan")
+    _check(m.copy_to_host(), m_ref, dtype, "Westervelt m, ordered plan")
+    ops._PLANS.clear()
+
+
+def test_affine_with_random_cell_order(gpu, oracle_c):
+    dev, ops = gpu
+    gll = pkg("gll")
+    P = 3
+    pb = build_problem(P, (4, 3, 5))
+    mesh = pb["mesh"]
+    perm = np.random.default_rng(5).permutation(mesh.ncells)
+    dm, G, cc = (np.ascontiguousarray(a[perm]) for a in (mesh.dofmap, pb["G"], pb["cc"]))
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], cc, y_ref, G, dm)
+    y = dev.to_device(np.zeros(mesh.ndofs))
+    ops._PLANS.clear()
+    op = ops.stiffness_operator(P, pb["D"].flatten(), np.float64, affine_weights=gll.tensor_weights_3d(pb["wts"]))
+    op(dev.to_device(pb["x"]), dev.to_device(cc), y, dev.to_device(G), dev.to_device(dm))
+    assert ops._PLANS.last_order is not None
+    _check(y.copy_to_host(), y_ref, np.float64, "affine, ordered plan")
+
+
+def test_planned_apply_rejects_foreign_workspace(gpu):
+    """A workspace that was not built for this (degree, cell count) -- or not built at all -- is refused
+    with FUS_ERR_PLAN_MISMATCH before any kernel indexes it."""
+    import torch
+
+    dev, ops = gpu
+    lib = pkg("_lib").load()
+    pb = build_problem(2, (3, 3, 3))
+    mesh = pb["mesh"]
+    d = torch.device("cuda", 0)
+    x, cc, G, dm = (torch.from_numpy(a).to(d) for a in (pb["x"], pb["cc"], pb["G"], mesh.dofmap))
+    y = torch.zeros_like(x)
+    D = torch.from_numpy(pb["D"]).to(d)
+    nbytes = lib.fus_stiffness_plan_bytes(2, mesh.ncells)
+    ws = torch.zeros(int(nbytes) + 512, dtype=torch.uint8, device=d)
+    base = ws.data_ptr() + (-ws.data_ptr() % 256)
+    args = (x.data_ptr(), cc.data_ptr(), y.data_ptr(), G.data_ptr())
+    assert lib.fus_stiffness_apply_planned_f64(*args, base, D.data_ptr(), 2, mesh.ncells, None) == -6  # never built
+    assert lib.fus_stiffness_plan_build(dm.data_ptr(), 2, mesh.ncells, base, int(nbytes), None) == 0
+    assert lib.fus_stiffness_apply_planned_f64(*args, base, D.data_ptr(), 2, mesh.ncells, None) == 0
+    assert lib.fus_stiffness_apply_planned_f64(*args, base, D.data_ptr(), 2, mesh.ncells - 1, None) == -6  # other cell count
+    assert lib.fus_stiffness_apply_planned_f64(*args, base, D.data_ptr(), 3, mesh.ncells, None) == -6  # other degree
+    torch.cuda.synchronize()
