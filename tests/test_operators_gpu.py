@@ -500,7 +500,8 @@ def test_random_cell_order_uses_locality_plan(gpu, oracle_c, P, dtype):
     kernel: stiffness, in-kernel geometry, affine, cell mass, fused Westervelt pass."""
     dev, ops = gpu
     gll = pkg("gll")
-    pb = build_problem(P, (4, 3, 5) if P <= 4 else (3, 2, 3), dtype=dtype, perturb=0.2, seed=21)
+    shape = {1: (8, 6, 5), 2: (5, 4, 5), 4: (4, 3, 5), 6: (3, 2, 3)}[P]  # more than two batches of cells
+    pb = build_problem(P, shape, dtype=dtype, perturb=0.2, seed=21)
     mesh = pb["mesh"]
     perm = np.random.default_rng(3).permutation(mesh.ncells)
     dm, G, detJ, cc, xd = (np.ascontiguousarray(a[perm]) for a in (mesh.dofmap, pb["G"], pb["detJ"], pb["cc"], mesh.x_dofs))
