@@ -60,6 +60,30 @@ def log(msg):
     print(f"[bench] {msg}", file=sys.stderr, flush=True)
 
 
+_JSON_FD = None
+
+
+def protect_stdout():
+    """The contract is ONE JSON line on stdout.  Native libraries loaded below write there too (RCCL
+    prints a version banner on stdout when a communicator is created with ncclCommInitRank), so file
+    descriptor 1 is pointed at stderr for the life of the process and the JSON line is written to a
+    private duplicate of the original stdout."""
+    global _JSON_FD
+    if _JSON_FD is None:
+        sys.stdout.flush()
+        _JSON_FD = os.dup(1)
+        os.dup2(2, 1)
+
+
+def emit(obj):
+    line = (json.dumps(obj) + "\n").encode()
+    if _JSON_FD is None:
+        sys.stdout.write(line.decode())
+        sys.stdout.flush()
+    else:
+        os.write(_JSON_FD, line)
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -204,14 +228,14 @@ def dry_run(args, rank, world):
     ok = torch.tensor([float(torch.equal(x, lex))])  # every ghost now holds its owner's value
     dist.all_reduce(ok, op=dist.ReduceOp.MIN)
     if rank == 0:
-        print(json.dumps({
+        emit({
             "metric": "stiffness_apply_dof_per_s", "value": None, "unit": "DOF/s", "n_gpus": world, "steps": args.steps,
             "warmup": args.warmup, "ms_per_step": float(el.item()) / args.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None, "dtype": "f64", "data": "synthetic", "dry_run": True,
             "valid": False, "halo_ok": bool(ok.item() == 1.0), "ranks": dist.get_world_size(), "backend": "gloo",
             "config": {"workload": f"DRY RUN (CPU, gloo): halo exchange only, P={P}, {cells}^3 cells per rank",
                        "partition": f"{grid[0]}x{grid[1]}x{grid[2]} blocks", "global_dofs": mesh.ndofs_global},
-            "roofline": None, "cpu_baseline": None}), flush=True)
+            "roofline": None, "cpu_baseline": None})
     dist.destroy_process_group()
     return 0 if ok.item() == 1.0 else 1
 
@@ -300,9 +324,15 @@ def bench_rk4(args, rank, world, device):
     grid = boxmesh.default_grid(world)
     gcells = tuple(args.cells * g for g in grid)
     mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, length=tuple(L * g for g in grid), dtype=dt_np)
-    h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
-    dts, tf, nstep = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
-    comm = scat.TorchComm() if world > 1 else None
+    h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L * grid[0])
+    if world > 1:  # comm.Allreduce(hmin, mesh_size, op=MPI.MIN), cuda/demo_linear_box.py:108
+        hm = torch.tensor([h], dtype=torch.float64, device=device)
+        dist.all_reduce(hm, op=dist.ReduceOp.MIN)
+        h = float(hm.item())
+    dts, tf, nstep = ls.snap_time_step(h, P, 1500.0, 0.5e6, L * grid[0])  # the wave crosses the whole (partitioned) box
+    if args.warmup + args.steps > nstep:
+        raise SystemExit(f"--warmup + --steps = {args.warmup + args.steps} exceeds the {nstep} steps to the final time")
+    comm = (scat.NativeComm() if args.halo == "native" else scat.TorchComm()) if world > 1 else None
     if args.mode == "westervelt":  # BASELINE config 5 shape: Westervelt, bowl-warped trilinear cells
         nls = fusgpu_loader.submodule("nonlinear_solver")
         Lx = L * grid[0]
@@ -314,7 +344,8 @@ def bench_rk4(args, rank, world, device):
             return out
 
         mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, length=tuple(L * g for g in grid), dtype=dt_np, warp=bowl)
-        solver = nls.WesterveltSpectral3D(mesh, dt_np, speed_of_sound=1500.0, source_frequency=0.5e6, comm=comm, fused=True)
+        solver = nls.WesterveltSpectral3D(mesh, dt_np, speed_of_sound=1500.0, source_frequency=0.5e6, comm=comm, fused=True,
+                                          in_kernel_geometry=args.in_kernel_geometry)
         solver.affine = False
     else:
         solver = ls.LinearSpectral3D(mesh, dt_np, comm=comm, fused=True)
@@ -324,7 +355,8 @@ def bench_rk4(args, rank, world, device):
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    solver.rk4(args.warmup * dts, tf, dts, max_steps=args.steps)
+    _, steps_done = solver.rk4(args.warmup * dts, tf, dts, max_steps=args.steps)
+    assert steps_done == args.steps, (steps_done, args.steps)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -344,11 +376,12 @@ def bench_rk4(args, rank, world, device):
                                f"P={P}, {gcells[0]}x{gcells[1]}x{gcells[2]} cells, {mesh.ndofs_global} dofs",
                    "steps_to_final_time": nstep, "dt": dts,
                    "geometry": "affine box: constant-G fast path (opt-in, checked at set-up)" if solver.affine
-                   else "general per-quadrature-point G"},
+                   else ("G and detJ formed in the cell kernel from the vertices (opt-in)"
+                         if getattr(solver, "in_kernel_geometry", False) else "general per-quadrature-point G")},
         "roofline": None, "cpu_baseline": None,
     }
     if rank == 0:
-        print(json.dumps(out), flush=True)
+        emit(out)
     if world > 1:
         dist.destroy_process_group()
 
@@ -372,6 +405,8 @@ def main():
     ap.add_argument("--dry-run", action="store_true",
                     help="CPU rehearsal of the N-rank path (gloo): launcher, partition, halo plan and exchange; no "
                          "GPU, no operator, the printed line is marked invalid")
+    ap.add_argument("--in-kernel-geometry", action="store_true",
+                    help="--mode westervelt: the fused cell pass forms G and detJ from the cell vertices")
     ap.add_argument("--halo", default=os.environ.get("FUS_HALO", "native"), choices=["native", "torch"],
                     help="N > 1 transport: native = grouped ncclSend/ncclRecv issued by libfusgpu.so on its own "
                          "stream (default); torch = torch.distributed all_to_all_single")
@@ -388,6 +423,7 @@ def main():
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
+    protect_stdout()
     if args.dry_run:
         raise SystemExit(dry_run(args, rank, world))
 
@@ -652,7 +688,7 @@ def main():
                 out["cpu_baseline"] = None
         else:
             out["cpu_baseline"] = None
-        print(json.dumps(out), flush=True)
+        emit(out)
     if use_dist:
         dist.destroy_process_group()
 

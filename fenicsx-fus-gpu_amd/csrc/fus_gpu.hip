@@ -22,6 +22,7 @@
 #include "stiffness_plan.hpp"
 #include "vecops.hpp"
 #include "westervelt.hpp"
+#include "westervelt_geom.hpp"
 
 namespace {
 
@@ -224,7 +225,7 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>()>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -249,6 +250,32 @@ int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c
 #define FUS_CASE(PP) \
   case PP:           \
     e = fus::launch_westervelt_cell<T, PP>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord); \
+    break;
+    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
+    FUS_CASE(10)
+#undef FUS_CASE
+  }
+  return hip_rc(e);
+}
+
+template <typename T>
+int westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5, T* b, T* m,
+                         const T* x_g, const int32_t* x_dofs, const T* pts, const T* wts, const void* ws, const T* dphi,
+                         int P, int64_t ncell, void* stream) {
+  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
+  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
+  if (ncell == 0) return FUS_OK;
+  if (!u || !v || !c2 || !c3 || !c4 || !c5 || !b || !m || !x_g || !x_dofs || !pts || !wts || !ws || !dphi)
+    return FUS_ERR_INVALID_ARGUMENT;
+  if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
+  bool ord = false;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
+  hipStream_t s = static_cast<hipStream_t>(stream);
+  hipError_t e = hipErrorInvalidValue;
+  switch (P) {
+#define FUS_CASE(PP) \
+  case PP:           \
+    e = fus::launch_westervelt_cell_geom<T, PP>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -526,6 +553,16 @@ FUS_GEOMK(float, f32)
   }
 FUS_WEST(double, f64)
 FUS_WEST(float, f32)
+#define FUS_WESTG(T, SUF)                                                                                          \
+  int fus_westervelt_cell_apply_planned_geom_##SUF(const T* u, const T* v, const T* c2, const T* c3, const T* c4,  \
+                                                   const T* c5, T* b, T* m, const T* x_g, const int32_t* x_dofs,   \
+                                                   const T* pts, const T* wts, const void* ws, const T* dphi,      \
+                                                   int P, int64_t ncell, void* s) {                                \
+    return westervelt_cell_geom<T>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, P, ncell, s);      \
+  }
+FUS_WESTG(double, f64)
+FUS_WESTG(float, f32)
+#undef FUS_WESTG
 #undef FUS_WEST
 
 #define FUS_RK4(T, SUF)                                                                                        \

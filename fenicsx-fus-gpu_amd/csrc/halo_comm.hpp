@@ -261,6 +261,7 @@ inline hipError_t halo_wait_readers_local(Halo* h, const Side& sside) {
 // dir 1: reverse (ghosts -> owners, add)         cuda/scatterer.py:104-188
 inline int halo_begin(Halo* h, void* buffer, hipStream_t stream, int dir) {
   Comm* c = h->comm;
+  if (h->owners.total == 0 && h->ghosts.total == 0) return 0;  // no neighbours: nothing to order, nothing to move
   char* vec = static_cast<char*>(buffer);
   char* ghost_block = vec + h->nlocal * h->eb;
   const Side& sside = dir == 0 ? h->ghosts : h->owners;
@@ -308,6 +309,7 @@ inline int halo_begin(Halo* h, void* buffer, hipStream_t stream, int dir) {
 
 inline int halo_end(Halo* h, void* buffer, hipStream_t stream, int dir) {
   Comm* c = h->comm;
+  if (h->owners.total == 0 && h->ghosts.total == 0) return 0;
   char* vec = static_cast<char*>(buffer);
   if (c->kind == Comm::LOCAL) {
     char* ghost_block = vec + h->nlocal * h->eb;

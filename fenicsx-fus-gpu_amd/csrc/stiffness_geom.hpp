@@ -28,7 +28,109 @@ __host__ __device__ constexpr int geom_min_waves() {
   return 1;
 }
 
-template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW>
+// Geometric factor of the column at quadrature plane qx, scaled by s0 = cell constant * w_y * w_z:
+// rows of J_ (J0 constant, J1 / J2 linear in xi_x), adj(J_), det, G = w |det| adj^T adj / det^2.
+template <typename T>
+__device__ __forceinline__ void column_g_at(T ex, T wx_s0, const T (&J0)[3], const T (&Ja)[3], const T (&Jba)[3],
+                                            const T (&Jc)[3], const T (&Jdc)[3], T (&gq)[6]) {
+  T J1[3], J2[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    J1[d] = Ja[d] + ex * Jba[d];
+    J2[d] = Jc[d] + ex * Jdc[d];
+  }
+  // adj(J_): A[d][a], inv(J_) = A / det  (same expressions as geometry_kernel, geometry.hpp)
+  T A[3][3];
+  A[0][0] = J1[1] * J2[2] - J1[2] * J2[1];
+  A[0][1] = J0[2] * J2[1] - J0[1] * J2[2];
+  A[0][2] = J0[1] * J1[2] - J0[2] * J1[1];
+  A[1][0] = J1[2] * J2[0] - J1[0] * J2[2];
+  A[1][1] = J0[0] * J2[2] - J0[2] * J2[0];
+  A[1][2] = J0[2] * J1[0] - J0[0] * J1[2];
+  A[2][0] = J1[0] * J2[1] - J1[1] * J2[0];
+  A[2][1] = J0[1] * J2[0] - J0[0] * J2[1];
+  A[2][2] = J0[0] * J1[1] - J0[1] * J1[0];
+  const T det = J0[0] * A[0][0] + J0[1] * A[1][0] + J0[2] * A[2][0];
+  const T s = wx_s0 / (det < T(0) ? -det : det);  // c w_q |det| / det^2 = c w_q / |det|
+  gq[0] = s * (A[0][0] * A[0][0] + A[1][0] * A[1][0] + A[2][0] * A[2][0]);
+  gq[1] = s * (A[0][0] * A[0][1] + A[1][0] * A[1][1] + A[2][0] * A[2][1]);
+  gq[2] = s * (A[0][0] * A[0][2] + A[1][0] * A[1][2] + A[2][0] * A[2][2]);
+  gq[3] = s * (A[0][1] * A[0][1] + A[1][1] * A[1][1] + A[2][1] * A[2][1]);
+  gq[4] = s * (A[0][1] * A[0][2] + A[1][1] * A[1][2] + A[2][1] * A[2][2]);
+  gq[5] = s * (A[0][2] * A[0][2] + A[1][2] * A[1][2] + A[2][2] * A[2][2]);
+}
+
+// Rows of J_ along the column (xi_y, xi_z) = (ey, ez) of a trilinear cell with vertex coordinates
+// X[(vx + 2 vy + 4 vz) * 3 + d]:  J_[0] = J0,  J_[1] = Ja + xi_x Jba,  J_[2] = Jc + xi_x Jdc.
+template <typename T>
+__device__ __forceinline__ void column_jacobian_rows(const T* __restrict__ X, T ey, T ez, T (&J0)[3], T (&Ja)[3],
+                                                     T (&Jba)[3], T (&Jc)[3], T (&Jdc)[3]) {
+  const T fy0 = T(1) - ey, fz0 = T(1) - ez;
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    const T x000 = X[0 * 3 + d], x100 = X[1 * 3 + d], x010 = X[2 * 3 + d], x110 = X[3 * 3 + d];
+    const T x001 = X[4 * 3 + d], x101 = X[5 * 3 + d], x011 = X[6 * 3 + d], x111 = X[7 * 3 + d];
+    // d/dxi_x: bilinear in (xi_y, xi_z) of the four x-edges
+    J0[d] = fz0 * (fy0 * (x100 - x000) + ey * (x110 - x010)) + ez * (fy0 * (x101 - x001) + ey * (x111 - x011));
+    // d/dxi_y at xi_x = 0 (A) and 1 (B): linear in xi_z of the y-edges
+    const T A = fz0 * (x010 - x000) + ez * (x011 - x001);
+    const T B = fz0 * (x110 - x100) + ez * (x111 - x101);
+    // d/dxi_z at xi_x = 0 (C) and 1 (D): linear in xi_y of the z-edges
+    const T C = fy0 * (x001 - x000) + ey * (x011 - x010);
+    const T D = fy0 * (x101 - x100) + ey * (x111 - x110);
+    Ja[d] = A;
+    Jba[d] = B - A;
+    Jc[d] = C;
+    Jdc[d] = D - C;
+  }
+}
+
+// |det J_| at plane xi_x = ex of the column (the scaled Jacobian determinant is w_q times this:
+// numba-cpu/precompute.py:76-112).
+template <typename T>
+__device__ __forceinline__ T column_absdet_at(T ex, const T (&J0)[3], const T (&Ja)[3], const T (&Jba)[3],
+                                              const T (&Jc)[3], const T (&Jdc)[3]) {
+  T J1[3], J2[3];
+#pragma unroll
+  for (int d = 0; d < 3; ++d) {
+    J1[d] = Ja[d] + ex * Jba[d];
+    J2[d] = Jc[d] + ex * Jdc[d];
+  }
+  const T det = J0[0] * (J1[1] * J2[2] - J1[2] * J2[1]) + J0[1] * (J1[2] * J2[0] - J1[0] * J2[2]) +
+                J0[2] * (J1[0] * J2[1] - J1[1] * J2[0]);
+  return det < T(0) ? -det : det;
+}
+
+// Stage the 24 vertex coordinates of each cell of the batch in LDS (sX[cell in batch][vertex][axis]):
+// issue the vertex-id loads ...
+template <int VPT, int BLOCK, int CPB>
+__device__ __forceinline__ void stage_vertex_ids(const int32_t* __restrict__ x_dofs, const int32_t* __restrict__ order,
+                                                 int64_t cell0, int64_t ncell, int tid, int32_t (&vid)[VPT]) {
+#pragma unroll
+  for (int r = 0; r < VPT; ++r) {
+    const int e = tid + r * BLOCK;  // entry e = (cell in batch) * 24 + vertex * 3 + axis
+    const int c = e / 24, v = (e - c * 24) / 3;
+    const bool ok = (e < CPB * 24) && (cell0 + c < ncell);
+    vid[r] = ok ? x_dofs[(order != nullptr ? (int64_t)order[cell0 + c] : cell0 + c) * 8 + v] : 0;
+  }
+}
+// ... and, once they have arrived, the coordinates themselves.
+template <typename T, int VPT, int BLOCK, int CPB>
+__device__ __forceinline__ void stage_vertex_coords(const T* __restrict__ x_g, const int32_t (&vid)[VPT], int tid,
+                                                    T* __restrict__ sX) {
+#pragma unroll
+  for (int r = 0; r < VPT; ++r) {
+    const int e = tid + r * BLOCK;
+    if (e < CPB * 24) sX[e] = x_g[(int64_t)vid[r] * 3 + e % 3];
+  }
+}
+
+// PREG: form the n x 6 factors of the column BEFORE the contraction phases (between the two barriers
+// of the gather, while the u values are not yet in registers): the main loop then has the register
+// profile of the general kernel (P = 4 fp64: 4 workgroups per CU) and the geometry arithmetic runs in
+// the shadow of the gather.  Without it the factors are formed plane by plane inside the loop (fewest
+// registers: the build for P >= 6).
+template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, bool PREG>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_geom_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                                const T* __restrict__ x_g, const int32_t* __restrict__ x_dofs,
@@ -72,15 +174,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 
   int32_t mydof[SPT];
   const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
-  // vertex indices of the batch's cells: entry e = (cell in batch) * 24 + vertex * 3 + axis
   int32_t vid[VPT];
-#pragma unroll
-  for (int r = 0; r < VPT; ++r) {
-    const int e = tid + r * BLOCK;
-    const int c = e / 24, v = (e - c * 24) / 3;
-    const bool ok = (e < CPB * 24) && (cell0 + c < ncell);
-    vid[r] = ok ? x_dofs[(order != nullptr ? (int64_t)order[cell0 + c] : cell0 + c) * 8 + v] : 0;
-  }
+  stage_vertex_ids<VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
   uint16_t sl[n];
   T coeff = T(0);
   if (active) {
@@ -90,43 +185,47 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     coeff = cell_constants[cell];
   }
   batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
+  stage_vertex_coords<T, VPT, BLOCK, CPB>(x_g, vid, tid, sX);
+
+  // ---- gather x (as plan_gather_x) with the column geometry formed between its two barriers
+  {
+    T xv[SPT];
 #pragma unroll
-  for (int r = 0; r < VPT; ++r) {
-    const int e = tid + r * BLOCK;
-    const int d = e % 3;
-    if (e < CPB * 24) sX[e] = x_g[(int64_t)vid[r] * 3 + d];
+    for (int r = 0; r < SPT; ++r) xv[r] = x[mydof[r]];
+#pragma unroll
+    for (int r = 0; r < SPT; ++r) {
+      const int s = tid + r * BLOCK;
+      if (s < nu_b) sx[s] = xv[r];
+    }
+  }
+  __syncthreads();  // x values and vertex coordinates are in LDS
+
+  T J0[3], Ja[3], Jba[3], Jc[3], Jdc[3];
+  T s0 = T(0);
+  T g[PREG ? n : 1][6];
+  if (active) {
+    column_jacobian_rows<T>(sX + lc * 24, sP[ty], sP[tz], J0, Ja, Jba, Jc, Jdc);
+    s0 = coeff * sW[ty] * sW[tz];
+    if constexpr (PREG) {
+#pragma unroll
+      for (int qx = 0; qx < n; ++qx) column_g_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, g[qx]);
+    }
   }
 
   T u[n];
-  plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sl, sx, su + lc * S + t, u);
+  if (active) {
+    T* cu = su + lc * S + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) {
+      u[ix] = sx[sl[ix]];
+      cu[ix * n2] = u[ix];
+    }
+  }
+  __syncthreads();
   if constexpr (!ALIAS) plan_zero<T, SPT, BLOCK>(sy, nu_b, tid);
 
   T fx[n];
   if (active) {
-    // ---- column geometry: rows of J_ as functions of xi_x --------------------------------------
-    const T* X = sX + lc * 24;  // X[(vx + 2 vy + 4 vz) * 3 + d]
-    const T ey = sP[ty], ez = sP[tz];
-    const T fy0 = T(1) - ey, fz0 = T(1) - ez;
-    T J0[3], Ja[3], Jba[3], Jc[3], Jdc[3];
-#pragma unroll
-    for (int d = 0; d < 3; ++d) {
-      const T x000 = X[0 * 3 + d], x100 = X[1 * 3 + d], x010 = X[2 * 3 + d], x110 = X[3 * 3 + d];
-      const T x001 = X[4 * 3 + d], x101 = X[5 * 3 + d], x011 = X[6 * 3 + d], x111 = X[7 * 3 + d];
-      // d/dxi_x: bilinear in (xi_y, xi_z) of the four x-edges
-      J0[d] = fz0 * (fy0 * (x100 - x000) + ey * (x110 - x010)) + ez * (fy0 * (x101 - x001) + ey * (x111 - x011));
-      // d/dxi_y at xi_x = 0 (A) and 1 (B): linear in xi_z of the y-edges
-      const T A = fz0 * (x010 - x000) + ez * (x011 - x001);
-      const T B = fz0 * (x110 - x100) + ez * (x111 - x101);
-      // d/dxi_z at xi_x = 0 (C) and 1 (D): linear in xi_y of the z-edges
-      const T C = fy0 * (x001 - x000) + ey * (x011 - x010);
-      const T D = fy0 * (x101 - x100) + ey * (x111 - x110);
-      Ja[d] = A;
-      Jba[d] = B - A;
-      Jc[d] = C;
-      Jdc[d] = D - C;
-    }
-    const T cw = coeff * sW[ty] * sW[tz];
-
     T dy[n], dz[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) {
@@ -141,36 +240,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int qx = 0; qx < n; ++qx) {
       T vx, vy, vz;
       plan_grad_at<T, n, n2>(qx, dphi, u, dy, dz, cu_y, cu_z, vx, vy, vz);
-      const T ex = pts[qx];  // compile-time index: scalar load
-      T J1[3], J2[3];
-#pragma unroll
-      for (int d = 0; d < 3; ++d) {
-        J1[d] = Ja[d] + ex * Jba[d];
-        J2[d] = Jc[d] + ex * Jdc[d];
-      }
-      // adj(J_): A[d][a], inv(J_) = A / det  (same expressions as geometry_kernel, geometry.hpp)
-      T A[3][3];
-      A[0][0] = J1[1] * J2[2] - J1[2] * J2[1];
-      A[0][1] = J0[2] * J2[1] - J0[1] * J2[2];
-      A[0][2] = J0[1] * J1[2] - J0[2] * J1[1];
-      A[1][0] = J1[2] * J2[0] - J1[0] * J2[2];
-      A[1][1] = J0[0] * J2[2] - J0[2] * J2[0];
-      A[1][2] = J0[2] * J1[0] - J0[0] * J1[2];
-      A[2][0] = J1[0] * J2[1] - J1[1] * J2[0];
-      A[2][1] = J0[1] * J2[0] - J0[0] * J2[1];
-      A[2][2] = J0[0] * J1[1] - J0[1] * J1[0];
-      const T det = J0[0] * A[0][0] + J0[1] * A[1][0] + J0[2] * A[2][0];
-      // coeff * w_q |det| / det^2 = coeff * w_q / |det|
-      const T s = cw * wts[qx] / (det < T(0) ? -det : det);
-      const T g00 = A[0][0] * A[0][0] + A[1][0] * A[1][0] + A[2][0] * A[2][0];
-      const T g01 = A[0][0] * A[0][1] + A[1][0] * A[1][1] + A[2][0] * A[2][1];
-      const T g02 = A[0][0] * A[0][2] + A[1][0] * A[1][2] + A[2][0] * A[2][2];
-      const T g11 = A[0][1] * A[0][1] + A[1][1] * A[1][1] + A[2][1] * A[2][1];
-      const T g12 = A[0][1] * A[0][2] + A[1][1] * A[1][2] + A[2][1] * A[2][2];
-      const T g22 = A[0][2] * A[0][2] + A[1][2] * A[1][2] + A[2][2] * A[2][2];
-      fx[qx] = s * (g00 * vx + g01 * vy + g02 * vz);
-      cfy[qx * n2] = s * (g01 * vx + g11 * vy + g12 * vz);
-      cfz[qx * n2] = s * (g02 * vx + g12 * vy + g22 * vz);
+      T gl[6];
+      if constexpr (!PREG) column_g_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, gl);  // compile-time index: scalar loads
+      const T* gq = PREG ? g[PREG ? qx : 0] : gl;
+      fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
+      cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
+      cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
     }
   }
   __syncthreads();
@@ -183,7 +258,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   plan_flush<T, SPT, BLOCK>(y, mydof, nu_b, tid, sy);
 }
 
-template <typename T, int P, bool ALIAS, bool PADLDS, int MINW>
+template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, bool PREG>
 inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs,
                                              const T* pts, const T* wts, const void* workspace, const T* dphi,
                                              int64_t ncell, hipStream_t stream, bool ordered = false) {
@@ -191,7 +266,7 @@ inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, cons
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
-  hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW>), dim3((unsigned)v.nbatch),
+  hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
                      ordered ? v.order : nullptr);
   return hipGetLastError();

@@ -213,30 +213,41 @@ inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, co
 // lumped mass changes every stage, so kv = b / m and m is reset to its steady part m0.
 template <typename T>
 __global__ void __launch_bounds__(256)
-    rk4_stage_nl_kernel(T bw, T aw, int new_step, const T* __restrict__ m0, T* __restrict__ m, T* __restrict__ b,
+    rk4_stage_nl_kernel(T bw, T aw, int kind, const T* __restrict__ m0, T* __restrict__ m, T* __restrict__ b,
                         T* __restrict__ u, T* __restrict__ v, T* __restrict__ u0, T* __restrict__ v0,
                         T* __restrict__ ku, T* __restrict__ un, int64_t nlocal, int64_t ntotal) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntotal; i += stride) {
     if (i < nlocal) {
       const T kv = b[i] / m[i];
-      const T kui = ku[i];
-      const T ui = u[i] + bw * kui;
-      const T vi = v[i] + bw * kv;
-      u[i] = ui;
-      v[i] = vi;
-      T u0i, v0i;
-      if (new_step) {
-        u0i = ui;
-        v0i = vi;
-        u0[i] = ui;
-        v0[i] = vi;
+      if (kind == 2) {  // FIRST (see rk4_stage_kernel, rk4.hpp)
+        const T u0i = u0[i], v0i = v0[i];
+        u[i] = u0i + bw * v0i;
+        v[i] = v0i + bw * kv;
+        un[i] = u0i + aw * v0i;
+        ku[i] = v0i + aw * kv;
+      } else if (kind == 3) {  // LAST
+        u0[i] = u[i] + bw * ku[i];
+        v0[i] = v[i] + bw * kv;
       } else {
-        u0i = u0[i];
-        v0i = v0[i];
+        const T kui = ku[i];
+        const T ui = u[i] + bw * kui;
+        const T vi = v[i] + bw * kv;
+        u[i] = ui;
+        v[i] = vi;
+        T u0i, v0i;
+        if (kind == 1) {
+          u0i = ui;
+          v0i = vi;
+          u0[i] = ui;
+          v0[i] = vi;
+        } else {
+          u0i = u0[i];
+          v0i = v0[i];
+        }
+        un[i] = u0i + aw * kui;
+        ku[i] = v0i + aw * kv;
       }
-      un[i] = u0i + aw * kui;
-      ku[i] = v0i + aw * kv;
     }
     // owned: restart from the steady part (already reverse-scattered); ghosts: restart from zero --
     // they collect this rank's partial sums of the next stage, which the reverse scatter ADDS to the

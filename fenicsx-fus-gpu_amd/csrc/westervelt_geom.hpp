@@ -1,0 +1,193 @@
+// Fused Westervelt cell pass with the geometry formed in the kernel (SURVEY 8f ranks 3 + 4 combined):
+// as westervelt_cell_kernel (westervelt.hpp), but neither G (48 n^3 bytes per cell) nor detJ (8 n^3) is
+// read -- both come from the 8 vertices of the (trilinear) cell, with the formulas of
+// numba-cpu/precompute.py:76-163 specialised as in stiffness_geom.hpp.  BASELINE config 5 (P = 6, bowl
+// mesh): 31.9 -> 12.7 kB per cell.  Own bytes contract, own bench line; never the headline.
+#pragma once
+
+#include "stiffness_geom.hpp"
+#include "westervelt.hpp"
+
+namespace fus {
+
+template <typename T, int P, int CPB, int MINW>
+__global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
+    westervelt_cell_geom_kernel(const T* __restrict__ u_in, const T* __restrict__ v_in, const T* __restrict__ c2,
+                                const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
+                                T* __restrict__ b, T* __restrict__ m, const T* __restrict__ x_g,
+                                const int32_t* __restrict__ x_dofs, const T* __restrict__ pts,
+                                const T* __restrict__ wts, const int32_t* __restrict__ nu,
+                                const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
+                                const T* __restrict__ dphi, int64_t ncell, const int32_t* __restrict__ order) {
+  constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
+  constexpr int S = lds_cell_stride<T, P>();
+  constexpr int BLOCK = col_block_threads<P, CPB>();
+  constexpr int M = CPB * Nd;
+  constexpr int SPT = (M + BLOCK - 1) / BLOCK;
+  constexpr int VPT = (CPB * 24 + BLOCK - 1) / BLOCK;
+
+  __shared__ T sD[n2];
+  __shared__ T sP[n], sW[n];
+  __shared__ T sX[CPB * 24];
+  __shared__ T su[CPB * S];
+  __shared__ T sfy[CPB * S];
+  __shared__ T sfz[CPB * S];
+  __shared__ int s_runs[2 * kPlanMaxRuns];
+  T* const sxu = sfy;
+  T* const sxv = sfz;
+  T* const sm = sfy;
+  T* const sb = su;
+
+  const int tid = threadIdx.x;
+  const unsigned batch = blockIdx.x;
+  const int lc = tid / n2;
+  const int t = tid - lc * n2;
+  const int ty = t / n, tz = t - ty * n;
+  const int64_t cell0 = (int64_t)batch * CPB;
+  const int64_t pos = cell0 + lc;
+  const bool active = (lc < CPB) && (pos < ncell);
+  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
+  const int32_t* ud = udofs + (int64_t)batch * M;
+
+  if (tid < n2) sD[tid] = dphi[tid];
+  if (tid < n) {
+    sP[tid] = pts[tid];
+    sW[tid] = wts[tid];
+  }
+
+  int32_t mydof[SPT];
+  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
+  int32_t vid[VPT];
+  stage_vertex_ids<VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
+  uint16_t sl[n];
+  T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
+  if (active) {
+    const uint16_t* sp = slot + pos * Nd + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+    k2 = c2[cell];
+    k3 = c3[cell];
+    k4 = c4[cell];
+    k5 = c5[cell];
+  }
+  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
+  stage_vertex_coords<T, VPT, BLOCK, CPB>(x_g, vid, tid, sX);
+  {
+    T xu[SPT], xv[SPT];
+#pragma unroll
+    for (int r = 0; r < SPT; ++r) {
+      xu[r] = u_in[mydof[r]];
+      xv[r] = v_in[mydof[r]];
+    }
+#pragma unroll
+    for (int r = 0; r < SPT; ++r) {
+      const int s = tid + r * BLOCK;
+      if (s < nu_b) {
+        sxu[s] = xu[r];
+        sxv[s] = xv[r];
+      }
+    }
+  }
+  __syncthreads();  // B1: u / v values and vertex coordinates are in LDS
+
+  T J0[3], Ja[3], Jba[3], Jc[3], Jdc[3];
+  T wyz = T(0);
+  T w[n];       // combined stiffness input  c3 u + c4 v
+  T bextra[n];  // detJ c5 v^2
+  T madd[n];    // detJ c2 u
+  if (active) {
+    column_jacobian_rows<T>(sX + lc * 24, sP[ty], sP[tz], J0, Ja, Jba, Jc, Jdc);
+    wyz = sW[ty] * sW[tz];
+    T* cu = su + lc * S + t;
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) {
+      const T uu = sxu[sl[ix]], vv = sxv[sl[ix]];
+      const T dj = column_absdet_at<T>(pts[ix], J0, Ja, Jba, Jc, Jdc) * (wts[ix] * wyz);  // scaled Jacobian determinant
+      w[ix] = k3 * uu + k4 * vv;
+      bextra[ix] = dj * k5 * vv * vv;
+      madd[ix] = dj * k2 * uu;
+      cu[ix * n2] = w[ix];
+    }
+  }
+  __syncthreads();  // B2
+  plan_zero<T, SPT, BLOCK>(sm, nu_b, tid);
+  __syncthreads();
+  if (active) {
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], madd[ix]);
+  }
+  __syncthreads();
+  plan_flush<T, SPT, BLOCK>(m, mydof, nu_b, tid, sm);
+  __syncthreads();
+
+  T fx[n];
+  if (active) {
+    T dy[n], dz[n];
+#pragma unroll
+    for (int i = 0; i < n; ++i) {
+      dy[i] = sD[ty * n + i];
+      dz[i] = sD[tz * n + i];
+    }
+    const T* cu_y = su + lc * S + tz;
+    const T* cu_z = su + lc * S + ty * n;
+    T* cfy = sfy + lc * S + t;
+    T* cfz = sfz + lc * S + t;
+#pragma unroll
+    for (int qx = 0; qx < n; ++qx) {
+      T vx, vy, vz;
+      plan_grad_at<T, n, n2>(qx, dphi, w, dy, dz, cu_y, cu_z, vx, vy, vz);
+      T gq[6];
+      column_g_at<T>(pts[qx], wts[qx] * wyz, J0, Ja, Jba, Jc, Jdc, gq);
+      fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
+      cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
+      cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
+    }
+  }
+  __syncthreads();  // B3
+  plan_zero<T, SPT, BLOCK>(sb, nu_b, tid);
+  __syncthreads();
+
+  if (active) {
+    T dyT[n], dzT[n];
+#pragma unroll
+    for (int q = 0; q < n; ++q) {
+      dyT[q] = sD[q * n + ty];
+      dzT[q] = sD[q * n + tz];
+    }
+    const T* cf_y = sfy + lc * S + tz;
+    const T* cf_z = sfz + lc * S + ty * n;
+#pragma unroll
+    for (int jx = 0; jx < n; ++jx) {
+      T acc = bextra[jx];
+#pragma unroll
+      for (int qx = 0; qx < n; ++qx) acc += dphi[qx * n + jx] * fx[qx];
+#pragma unroll
+      for (int q = 0; q < n; ++q) {
+        acc += dyT[q] * cf_y[jx * n2 + q * n];
+        acc += dzT[q] * cf_z[jx * n2 + q];
+      }
+      lds_atomic_add(&sb[sl[jx]], acc);
+    }
+  }
+  __syncthreads();  // B4
+  plan_flush<T, SPT, BLOCK>(b, mydof, nu_b, tid, sb);
+}
+
+template <typename T, int P>
+inline hipError_t launch_westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const T* c4,
+                                              const T* c5, T* b, T* m, const T* x_g, const int32_t* x_dofs,
+                                              const T* pts, const T* wts, const void* workspace, const T* dphi,
+                                              int64_t ncell, hipStream_t stream, bool ordered = false) {
+  constexpr int CPB = plan_cells_per_batch<P>();
+  if (ncell <= 0) return hipSuccess;
+  PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
+  constexpr int threads = col_block_threads<P, CPB>();
+  hipLaunchKernelGGL((westervelt_cell_geom_kernel<T, P, CPB, 1>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u,
+                     v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, pv.nu, pv.udofs, pv.slot, dphi, ncell,
+                     ordered ? pv.order : nullptr);
+  return hipGetLastError();
+}
+
+}  // namespace fus

@@ -26,7 +26,8 @@ sys.path.insert(0, ROOT)
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--degree", type=int, default=4)
-    ap.add_argument("--cells", type=int, default=None, help="cells per direction per rank block (default: 2 per wavelength, as the reference)")
+    ap.add_argument("--cells", type=int, default=None, help="cells per direction of the WHOLE box, split over the ranks' blocks -- the reference's fixed-size "
+                         "box, strong scaling (default: 2 per wavelength, as the reference)")
     ap.add_argument("--reference-sequence", action="store_true", help="the reference's unfused launch sequence")
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--out", default=None)
@@ -43,7 +44,7 @@ def main():
     comm = None
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
-        comm = scat.TorchComm()
+        comm = scat.NativeComm()  # exchange issued by libfusgpu.so (RCCL); torch.distributed only bootstraps it
 
     # cuda/demo_linear_box.py:53-80
     float_type = np.float64

@@ -31,7 +31,8 @@ def compute_diffusivity_of_sound(frequency, speed, attenuationdB):
 class WesterveltSpectral3D:
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
                  source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
-                 attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False):
+                 attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False,
+                 in_kernel_geometry=False):
         self.mesh, self.P = mesh, mesh.P
         ft = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(ft)
@@ -92,6 +93,15 @@ class WesterveltSpectral3D:
             self.halo.rev(self.m0)
 
         self.cell_fused = ops.westervelt_cell_operator(P, D.flatten(), ft)
+        # opt-in (fused mode): G and detJ formed in the cell kernel from the vertices -- the cells of
+        # the reference's meshes are trilinear (P1 geometry, cuda/demo_nonlinear_bowl.py:317)
+        self.in_kernel_geometry = bool(in_kernel_geometry)
+        if self.in_kernel_geometry:
+            from .gll import tabulate_1d
+
+            pts, wts, _ = tabulate_1d(P, ft)
+            self.x_dofs = torch.from_numpy(np.ascontiguousarray(mesh.x_dofs)).to(dev)
+            self.cell_fused_geom = ops.westervelt_cell_operator(P, D.flatten(), ft, geometry=(mesh.x_g, pts, wts))
         self.fc_src = torch.zeros_like(self.fc1_1)  # per-stage source-facet constants (fused mode)
 
     def init(self):
@@ -108,25 +118,32 @@ class WesterveltSpectral3D:
             "fus_rk4_stage_nl",
         )
 
-    def _operator_fused(self, ts):
+    def _operator_fused(self, ts, u_n=None, v_n=None):
+        u_n = self.un if u_n is None else u_n
+        v_n = self.ku if v_n is None else v_n  # ku == v_n
         gv, dgv = self.source_values(ts)
         if self.fc_src.numel():
             ops.scale(gv, self.fc1_1, self.fc_src)        # M_f1(fc1_1) g + M_f1(fc2_1) dg
             ops.axpy[1, 1](dgv, self.fc2_1, self.fc_src)  #   = M_f1(fc1_1 g + fc2_1 dg) 1
 
         def cells(c2, c3, c4, c5, G_, dJ_, dm_):
-            self.cell_fused(self.un, self.ku, c2, c3, c4, c5, self.b, self.m, G_, dJ_, dm_)  # ku == v_n
+            self.cell_fused(u_n, v_n, c2, c3, c4, c5, self.b, self.m, G_, dJ_, dm_)
 
         def facets():
             self.mass_facet(self.g, self.fc_src, self.b, self.dF1, self.fdm1)  # g == 1
-            self.mass_facet(self.ku, self.fc2_2, self.b, self.dF2, self.fdm2)
+            self.mass_facet(v_n, self.fc2_2, self.b, self.dF2, self.fdm2)
 
         percell = (self.cc2, self.cc3, self.cc4, self.cc5, self.G, self.detJ, self.dofmap)
+        if self.in_kernel_geometry:
+            def cells(c2, c3, c4, c5, xd_, dm_):  # noqa: F811
+                self.cell_fused_geom(u_n, v_n, c2, c3, c4, c5, self.b, self.m, xd_, dm_)
+
+            percell = (self.cc2, self.cc3, self.cc4, self.cc5, self.x_dofs, self.dofmap)
         if self.halo is None:
             cells(*percell)
             facets()
         else:
-            self.halo.run(cells, percell, [(self.fwd_u, self.un), (self.fwd_v, self.ku)],
+            self.halo.run(cells, percell, [(self.fwd_u, u_n), (self.fwd_v, v_n)],
                           [(self.halo.rev, self.b), (self.rev_m, self.m)], facets)
 
     def source_values(self, t):
@@ -186,15 +203,20 @@ class WesterveltSpectral3D:
             ops.fill(1.0, self.g)  # source enters through scaled facet constants
             ops.fill(0.0, self.b)
             ops.copy(self.m0, self.m)
-            self._stage_vector_kernel(0.0, 0.0, 1)  # u0 = u, v0 = v, un = u, ku = v, b = 0, m = m0
+            ops.fill(0.0, self.m[self.nlocal:])  # ghost entries collect partial sums
+            ops.copy(self.u, self.u0)  # between steps the solution lives in (u0, v0): stage kinds 2, 0, 0, 3
+            ops.copy(self.v, self.v0)
         while t < tf and (max_steps is None or step < max_steps):
             dt = min(dt, tf - t)
             if self.fused:
                 for i in range(4):
                     tn = t + C_RUNGE[i] * dt
-                    self._operator_fused(tn if self.source_time == "tn" else t)
+                    if i == 0:
+                        self._operator_fused(tn if self.source_time == "tn" else t, self.u0, self.v0)
+                    else:
+                        self._operator_fused(tn if self.source_time == "tn" else t)
                     last = i == 3
-                    self._stage_vector_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 1 if last else 0)
+                    self._stage_vector_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if i == 0 else 0))
             else:
                 ops.copy(self.u, self.u0)
                 ops.copy(self.v, self.v0)
@@ -202,6 +224,9 @@ class WesterveltSpectral3D:
                     self._stage(i, t, dt)
             t += dt
             step += 1
+        if self.fused:
+            ops.copy(self.u0, self.u)
+            ops.copy(self.v0, self.v)
         return t, step
 
     def u_sol(self):

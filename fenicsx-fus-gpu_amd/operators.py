@@ -365,7 +365,52 @@ class _WesterveltCellOperator:
         )
 
 
-def westervelt_cell_operator(P, dphi, float_type):
+class _WesterveltCellGeomOperator:
+    """The fused Westervelt cell pass with G and detJ formed in the kernel from the cell vertices
+    (csrc/westervelt_geom.hpp): ``op(u, v, c2, c3, c4, c5, b, m, x_dofs, dofmap)``.  ``x_dofs`` (int32
+    [ncell, 8], dofmap cell order) is a call argument so that cell sub-ranges can be passed as views;
+    ``x_g``, ``pts``, ``wts`` are fixed at construction."""
+
+    def __init__(self, P, dphi, float_type, x_g, pts, wts):
+        self._st = _StiffnessOperator(P, float_type, dphi)
+        self.P, self.n, self.dtype = self._st.P, self._st.n, self._st.dtype
+        dev = torch.device("cuda", torch.cuda.current_device())
+        conv = lambda a: (a if isinstance(a, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(np.asarray(a)))).to(  # noqa: E731
+            device=dev, dtype=self.dtype).contiguous()
+        self.x_g, self.pts, self.wts = conv(x_g), conv(pts).reshape(-1), conv(wts).reshape(-1)
+        if self.x_g.dim() != 2 or self.x_g.shape[1] != 3 or self.pts.numel() != self.n or self.wts.numel() != self.n:
+            raise ValueError("x_g must be [nvert, 3]; pts / wts the 1-D GLL points / weights")
+        self._fn = getattr(_lib.load(), f"fus_westervelt_cell_apply_planned_geom_{_lib.suffix(self.dtype)}")
+
+    def __call__(self, u, v, c2, c3, c4, c5, b, m, x_dofs, dofmap):
+        dt = self.dtype
+        for name, t in (("u", u), ("v", v), ("c2", c2), ("c3", c3), ("c4", c4), ("c5", c5), ("b", b), ("m", m)):
+            _req(t, dt, name)
+        _req(dofmap, torch.int32, "dofmap")
+        _req(x_dofs, torch.int32, "x_dofs")
+        nd = self.n**3
+        ncell = dofmap.shape[0]
+        if dofmap.dim() != 2 or dofmap.shape[1] != nd or tuple(x_dofs.shape) != (ncell, 8):
+            raise ValueError(f"dofmap [ncell, {nd}] and x_dofs [ncell, 8] expected")
+        for name, t in (("c2", c2), ("c3", c3), ("c4", c4), ("c5", c5)):
+            if t.numel() != ncell:
+                raise ValueError(f"{name} must have one value per cell")
+        if ncell == 0:
+            return
+        ws, _ = _PLANS.get(dofmap)
+        _lib.check(
+            self._fn(u.data_ptr(), v.data_ptr(), c2.data_ptr(), c3.data_ptr(), c4.data_ptr(), c5.data_ptr(),
+                     b.data_ptr(), m.data_ptr(), self.x_g.data_ptr(), x_dofs.data_ptr(), self.pts.data_ptr(),
+                     self.wts.data_ptr(), ws.data_ptr(), self._st._dphi.data_ptr(), self.P, int(ncell), _lib.stream_ptr()),
+            "fus_westervelt_cell_apply_planned_geom",
+        )
+
+
+def westervelt_cell_operator(P, dphi, float_type, geometry=None):
+    """``geometry=(x_g, pts, wts)``: the variant that forms G and detJ in the kernel (its call takes
+    ``x_dofs`` in place of ``G, detJ``)."""
+    if geometry is not None:
+        return _WesterveltCellGeomOperator(P, dphi, float_type, *geometry)
     return _WesterveltCellOperator(P, dphi, float_type)
 
 

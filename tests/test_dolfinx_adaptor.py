@@ -1,0 +1,131 @@
+"""dolfinx adaptor on mock inputs shaped like what a dolfinx driver holds: the
+function-space dofmap in the STANDARD basix local order with a ``dof_ordering`` permutation
+(cuda/demo_linear_box.py:167-176), cells in arbitrary order, ghosts in arbitrary (not owner-grouped)
+order.  dolfinx itself exists nowhere in this pipeline; BoxMesh supplies the ground truth the mock is
+scrambled from.  CPU: adaptor invariants + partitioned apply == serial apply with the oracle as the
+operator; GPU: the same through HaloApply, the HIP kernels and the native halo exchange."""
+import itertools
+
+import numpy as np
+import pytest
+
+from conftest import build_problem, pkg, rel_l2, ref_field
+from halo_cpu import global_cell_constants
+
+_world_ids = itertools.count(5000)
+
+
+def mock_dolfinx_rank(P, cells, grid, rank, seed):
+    """One rank's data as a dolfinx driver would see it, scrambled from BoxMesh."""
+    boxmesh, gll, pre = pkg("boxmesh"), pkg("gll"), pkg("precompute")
+    mesh = boxmesh.BoxMesh(P, cells, grid=grid, rank=rank, perturb=0.16, seed=3, ghost_order=seed)
+    rng = np.random.default_rng(100 * seed + rank)
+    n = P + 1
+    cperm = rng.permutation(mesh.ncells)                     # cells in arbitrary order
+    sigma = np.random.default_rng(seed).permutation(n**3)    # the element's dof_ordering (same on all ranks)
+    dofmap_std = mesh.dofmap[cperm][:, sigma]                # V.dofmap.list on the standard element
+    pts, wts, D = gll.tabulate_1d(P)
+    G = np.zeros((mesh.ncells, n**3, 6))
+    pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), mesh.ncells, pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts)),
+                                          gll.tensor_weights_3d(wts))
+    return dict(mesh=mesh, dofmap_std=dofmap_std, dof_ordering=sigma, G=G[cperm], cc=global_cell_constants(mesh)[cperm],
+                x_dofs=mesh.x_dofs[cperm], D=D)
+
+
+def test_tensor_product_dofmap_round_trip():
+    ad = pkg("dolfinx_adaptor")
+    r = mock_dolfinx_rank(3, (2, 2, 2), (1, 1, 1), 0, 7)
+    tp = ad.tensor_product_dofmap(r["dofmap_std"], r["dof_ordering"])
+    assert tp.dtype == np.int32 and tp.flags.c_contiguous
+    # same cells (as sets of rows) as the ground-truth tensor-product dofmap
+    assert sorted(map(tuple, tp)) == sorted(map(tuple, r["mesh"].dofmap))
+    assert np.array_equal(ad.tensor_product_dofmap(r["mesh"].dofmap, None), r["mesh"].dofmap)
+    with pytest.raises(ValueError):
+        ad.tensor_product_dofmap(r["dofmap_std"], np.zeros(64, dtype=int))
+
+
+@pytest.mark.parametrize("P,cells,grid", [(2, (4, 4, 2), (2, 2, 1)), (3, (4, 2, 2), (2, 1, 1)), (2, (4, 4, 4), (2, 2, 2))])
+def test_partitioned_apply_through_adaptor_cpu(oracle_c, P, cells, grid):
+    from oracle import oracle_np
+
+    ad, utils = pkg("dolfinx_adaptor"), pkg("utils")
+    R = int(np.prod(grid))
+    ranks = [mock_dolfinx_rank(P, cells, grid, r, 11) for r in range(R)]
+    rms = []
+    for rk in ranks:
+        tp = ad.tensor_product_dofmap(rk["dofmap_std"], rk["dof_ordering"])
+        rm, (G, cc, xd) = ad.partition_for_overlap(tp, rk["mesh"].index_map, (rk["G"], rk["cc"], rk["x_dofs"]))
+        nb = rm.num_boundary_cells
+        assert (rm.dofmap[:nb] >= rm.nlocal).any(axis=1).all() and not (rm.dofmap[nb:] >= rm.nlocal).any()
+        assert rm.ncells == rk["mesh"].ncells and rm.ndofs == rk["mesh"].ndofs
+        rms.append((rm, G, cc))
+    od, gd = utils.compute_scatterer_data_all([rm.index_map for rm, _, _ in rms])
+    nl = [rm.nlocal for rm, _, _ in rms]
+    xs = []
+    for rk, (rm, _, _) in zip(ranks, rms):
+        x = ref_field(rk["mesh"].dof_coordinates())
+        x[rm.nlocal:] = -777.0
+        xs.append(x)
+    oracle_np.scatter_forward_all(xs, od, gd, nl)
+    ys = []
+    for rk, (rm, G, cc), x in zip(ranks, rms, xs):
+        y = np.zeros(rm.ndofs)
+        oracle_c.stiffness_apply(P, rk["D"], x, cc, y, G, rm.dofmap)
+        ys.append(y)
+    oracle_np.scatter_reverse_all(ys, od, gd, nl)
+    pb = build_problem(P, cells, perturb=0.16, seed=3)
+    ms = pb["mesh"]
+    y_ser = np.zeros(ms.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], global_cell_constants(ms), y_ser, pb["G"], ms.dofmap)
+    for rk, y in zip(ranks, ys):
+        m = rk["mesh"]
+        lex = m.global_lexicographic_ids()
+        assert rel_l2(y[: m.nlocal], y_ser[lex[: m.nlocal]]) < 1e-13
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("P,cells,grid", [(4, (4, 4, 2), (2, 2, 1)), (2, (4, 4, 4), (2, 2, 2))])
+def test_partitioned_apply_through_adaptor_gpu(oracle_c, P, cells, grid):
+    """The same through HaloApply: HIP stiffness kernel on the three cell sub-ranges (each with its own
+    locality-ordered plan: the mock's cells are in random order), native halo exchange (in-process
+    transport), ghosts not owner-grouped."""
+    import torch
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ad, utils, scat, ops = pkg("dolfinx_adaptor"), pkg("utils"), pkg("scatterer"), pkg("operators")
+    R = int(np.prod(grid))
+    wid = next(_world_ids)
+    ranks = [mock_dolfinx_rank(P, cells, grid, r, 11) for r in range(R)]
+    parts = []
+    for rk in ranks:
+        tp = ad.tensor_product_dofmap(rk["dofmap_std"], rk["dof_ordering"])
+        parts.append(ad.partition_for_overlap(tp, rk["mesh"].index_map, (rk["G"], rk["cc"])))
+    od, gd = utils.compute_scatterer_data_all([rm.index_map for rm, _ in parts])
+    op = ops.stiffness_operator(P, ranks[0]["D"].flatten(), np.float64)
+    state = []
+    for r, (rk, (rm, (G, cc))) in enumerate(zip(ranks, parts)):
+        x = ref_field(rk["mesh"].dof_coordinates())
+        x[rm.nlocal:] = -777.0
+        halo = scat.HaloApply(rm, op, scat.NativeComm(local=(wid, R, r)), np.float64, plan=(od[r], gd[r]))
+        state.append(dict(halo=halo, x=torch.from_numpy(x).to(dev), y=torch.zeros(rm.ndofs, dtype=torch.float64, device=dev),
+                          cc=torch.from_numpy(cc).to(dev), G=torch.from_numpy(G).to(dev), dm=torch.from_numpy(rm.dofmap).to(dev)))
+    live = [s["halo"].apply_schedule(s["x"], s["cc"], s["y"], s["G"], s["dm"]) for s in state]
+    while live:
+        nxt = []
+        for g in live:
+            try:
+                next(g)
+                nxt.append(g)
+            except StopIteration:
+                pass
+        live = nxt
+    torch.cuda.synchronize()
+    pb = build_problem(P, cells, perturb=0.16, seed=3)
+    ms = pb["mesh"]
+    y_ser = np.zeros(ms.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], global_cell_constants(ms), y_ser, pb["G"], ms.dofmap)
+    for rk, s in zip(ranks, state):
+        m = rk["mesh"]
+        lex = m.global_lexicographic_ids()
+        assert rel_l2(s["y"].cpu().numpy()[: m.nlocal], y_ser[lex[: m.nlocal]]) < 1e-12

@@ -586,3 +586,28 @@ def test_planned_apply_rejects_foreign_workspace(gpu):
     assert lib.fus_stiffness_apply_planned_f64(*args, base, D.data_ptr(), 2, mesh.ncells - 1, None) == -6  # other cell count
     assert lib.fus_stiffness_apply_planned_f64(*args, base, D.data_ptr(), 3, mesh.ncells, None) == -6  # other degree
     torch.cuda.synchronize()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 6, 8])
+def test_westervelt_cell_pass_in_kernel_geometry(gpu, oracle_c, P, dtype):
+    """b += K(c3) u + K(c4) v + M(c5) v^2, m += M(c2) u with G and detJ formed in the kernel, against
+    the four reference-style applies of the oracle on the precomputed G / detJ of the same vertices."""
+    dev, ops = gpu
+    pb = build_problem(P, (3, 2, 3) if P <= 6 else (2, 1, 2), dtype=dtype, perturb=0.25, seed=40 + P)
+    mesh = pb["mesh"]
+    rng = np.random.default_rng(P)
+    v = rng.standard_normal(mesh.ndofs).astype(dtype)
+    c2, c3, c4, c5 = ((0.5 + rng.random(mesh.ncells)).astype(dtype) for _ in range(4))
+    b0, m0 = rng.standard_normal(mesh.ndofs).astype(dtype), rng.standard_normal(mesh.ndofs).astype(dtype)
+    b_ref, m_ref = b0.copy(), m0.copy()
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], c3, b_ref, pb["G"], mesh.dofmap)
+    oracle_c.stiffness_apply(P, pb["D"], v, c4, b_ref, pb["G"], mesh.dofmap)
+    oracle_c.mass_apply((v * v).astype(dtype), c5, b_ref, pb["detJ"], mesh.dofmap)
+    oracle_c.mass_apply(pb["x"], c2, m_ref, pb["detJ"], mesh.dofmap)
+    b, m = dev.to_device(b0), dev.to_device(m0)
+    op = ops.westervelt_cell_operator(P, pb["D"].flatten(), dtype, geometry=(mesh.x_g, pb["pts"], pb["wts"]))
+    op(dev.to_device(pb["x"]), dev.to_device(v), dev.to_device(c2), dev.to_device(c3), dev.to_device(c4), dev.to_device(c5),
+       b, m, dev.to_device(mesh.x_dofs), dev.to_device(mesh.dofmap))
+    _check(b.copy_to_host(), b_ref, dtype, f"Westervelt b, in-kernel geometry P={P}")
+    _check(m.copy_to_host(), m_ref, dtype, f"Westervelt m, in-kernel geometry P={P}")

@@ -43,9 +43,10 @@ SHIPPED = [
     (r"stiffness_plan_kernel<float, 4, 10, false, true, 5, 5>", 96, 5),
     (r"stiffness_plan_kernel<float, 6, 5, true, true, 1, 4>", 96, 5),
     # in-kernel geometry
-    (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, \d>", 168, 3),
-    (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, \d>", 168, 3),
-    (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, \d>", 96, 5),
+    (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true>", 128, 4),
+    (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, 1, false>", 168, 3),
+    (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, 1, true>", 96, 5),
+    (r"westervelt_cell_geom_kernel<double, 6, 5, 1>", 168, 3),
     # affine fast path
     (r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>", 96, 5),
     (r"stiffness_plan_affine_kernel<double, 6, 5, true, true, 1>", 168, 3),

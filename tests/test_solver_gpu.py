@@ -59,10 +59,11 @@ def _bowl_warp(xg):
     return out
 
 
-@pytest.mark.parametrize("fused", [False, True], ids=["reference-sequence", "fused"])
+@pytest.mark.parametrize("fused", [False, True, "geom"], ids=["reference-sequence", "fused", "fused-in-kernel-geometry"])
 @pytest.mark.parametrize("P,cells", [(6, (3, 2, 2)), (4, (4, 3, 3)), (2, (7, 5, 6))], ids=["P6", "P4", "P2"])
 def test_westervelt_bowl_pressure_field(oracle_c, P, cells, fused):
-    """BASELINE config 5 shape (Westervelt, curved trilinear cells, P = 6) at test size."""
+    """BASELINE config 5 shape (Westervelt, curved trilinear cells, P = 6) at test size; "geom": the fused
+    cell pass forms G and detJ from the cell vertices instead of reading the precomputed arrays."""
     import torch
 
     torch.cuda.set_device(0)
@@ -72,7 +73,7 @@ def test_westervelt_bowl_pressure_field(oracle_c, P, cells, fused):
     h = ls.time_step_parameters(mesh, P, 1480.0, 1.1e6, L)
     dt, tf, _ = ls.snap_time_step(h, P, 1480.0, 1.1e6, L)
     nsteps = 10
-    s = nls.WesterveltSpectral3D(mesh, np.float64, fused=fused)
+    s = nls.WesterveltSpectral3D(mesh, np.float64, fused=bool(fused), in_kernel_geometry=(fused == "geom"))
     s.init()
     s.rk4(0.0, tf, dt, max_steps=nsteps)
     u_ref, v_ref = rk4_oracle.solve_westervelt(mesh, nsteps, dt, oracle_c=oracle_c)

@@ -47,10 +47,30 @@ def issue(fn, K=200):
     return (t1 - t0) / K * 1e6, (t2 - t0) / K * 1e6
 
 
+# a halo plan of config-4 size (3 faces + 3 edges + 1 corner of a 2x2x2 block partition: 141 919 ghost
+# dofs) in a 1-rank world whose rank is its own neighbour, through both transports
+rng = np.random.default_rng(0)
+ng = 3 * 47089 + 3 * 217 + 1
+N = mesh.ndofs - ng
+od = [np.arange(ng, dtype=np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+gd = [rng.choice(N, size=ng, replace=False).astype(np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+od_perm = [rng.permutation(ng).astype(np.int64)] + od[1:]
+ncomm = scat.NativeComm()
+nat_fwd, nat_rev = scat.scatter_forward(ncomm, od, gd, N, np.float64), scat.scatter_reverse(ncomm, od, gd, N, np.float64)
+nat_fwd_p, nat_rev_p = scat.scatter_forward(ncomm, od_perm, gd, N, np.float64), scat.scatter_reverse(ncomm, od_perm, gd, N, np.float64)
+tcomm = scat.TorchComm()
+t_fwd, t_rev = scat.scatter_forward(tcomm, od, gd, N, np.float64), scat.scatter_reverse(tcomm, od, gd, N, np.float64)
+t_fwd_p, t_rev_p = scat.scatter_forward(tcomm, od_perm, gd, N, np.float64), scat.scatter_reverse(tcomm, od_perm, gd, N, np.float64)
+print(f"halo plan: {ng} ghost dofs ({ng * 8 / 1e6:.2f} MB per direction), 1-rank world, rank 0 <-> rank 0")
+
 for name, fn in (("single launch op(...)", lambda: op(x, cc, y, G, dm)),
+                 ("native halo fwd+rev, direct (fus_halo_*: 1 pack, 2 RCCL groups, 1 unpack)", lambda: (nat_fwd(y), nat_rev(y))),
+                 ("torch  halo fwd+rev, direct (all_to_all_single + Python launches)", lambda: (t_fwd(y), t_rev(y))),
+                 ("native halo fwd+rev, permuted ghosts (2 pack, 2 groups, 2 unpack)", lambda: (nat_fwd_p(y), nat_rev_p(y))),
+                 ("torch  halo fwd+rev, permuted ghosts", lambda: (t_fwd_p(y), t_rev_p(y))),
                  ("HaloApply.apply (1 rank: 3 launches, no exchange)", lambda: halo.apply(x, cc, y, G, dm)),
                  ("all_to_all_single to self, async + wait (377 kB x3)", lambda: dist.all_to_all_single(recv, send, [send.numel()], [send.numel()], async_op=True).wait()),
                  ("fill kernel via ctypes", lambda: ops.fill(0.0, recv))):
     h, tot = issue(fn)
-    print(f"{name:58s} host issue {h:7.1f} us/step   wall {tot:7.1f} us/step")
+    print(f"{name:78s} host issue {h:7.1f} us/step   wall {tot:7.1f} us/step")
 dist.destroy_process_group()
