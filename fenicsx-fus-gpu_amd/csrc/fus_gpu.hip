@@ -244,7 +244,9 @@ int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c
   if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
   if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
   if (ncell == 0) return FUS_OK;
-  if (!u || !v || !c2 || !c3 || !c4 || !c5 || !b || !m || !G || !detJ || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  const bool mass = c2 || c5 || m || detJ;  // all four or none: none = the stiffness part alone
+  if (!u || !v || !c3 || !c4 || !b || !G || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  if (mass && (!c2 || !c5 || !m || !detJ)) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   bool ord = false;
   if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
@@ -253,7 +255,8 @@ int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_westervelt_cell<T, PP>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord); \
+    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord) \
+             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -269,8 +272,9 @@ int westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const
   if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
   if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
   if (ncell == 0) return FUS_OK;
-  if (!u || !v || !c2 || !c3 || !c4 || !c5 || !b || !m || !x_g || !x_dofs || !pts || !wts || !ws || !dphi)
-    return FUS_ERR_INVALID_ARGUMENT;
+  const bool mass = c2 || c5 || m;
+  if (!u || !v || !c3 || !c4 || !b || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
+  if (mass && (!c2 || !c5 || !m)) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   bool ord = false;
   if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
@@ -279,7 +283,8 @@ int westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_westervelt_cell_geom<T, PP>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
+    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord) \
+             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -557,6 +562,18 @@ FUS_GEOMK(float, f32)
   }
 FUS_WEST(double, f64)
 FUS_WEST(float, f32)
+#define FUS_NL2(T, SUF)                                                                                            \
+  int fus_rk4_stage_nl2_##SUF(T bw, T aw, int new_step, const T* m0, const T* w2, const T* w5, T* b, T* u, T* v,   \
+                              T* u0, T* v0, T* ku, T* un, int64_t nlocal, int64_t ntotal, void* s) {               \
+    if (nlocal < 0 || ntotal < nlocal) return FUS_ERR_INVALID_ARGUMENT;                                            \
+    if (ntotal == 0) return FUS_OK;                                                                                \
+    if (!m0 || !w2 || !w5 || !b || !u || !v || !u0 || !v0 || !ku || !un) return FUS_ERR_INVALID_ARGUMENT;          \
+    return hip_rc(fus::launch_rk4_stage_nl2<T>(bw, aw, new_step, m0, w2, w5, b, u, v, u0, v0, ku, un, nlocal,      \
+                                               ntotal, static_cast<hipStream_t>(s)));                              \
+  }
+FUS_NL2(double, f64)
+FUS_NL2(float, f32)
+#undef FUS_NL2
 #define FUS_WESTG(T, SUF)                                                                                          \
   int fus_westervelt_cell_apply_planned_geom_##SUF(const T* u, const T* v, const T* c2, const T* c3, const T* c4,  \
                                                    const T* c5, T* b, T* m, const T* x_g, const int32_t* x_dofs,   \

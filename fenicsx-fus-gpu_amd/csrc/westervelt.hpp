@@ -26,7 +26,11 @@ namespace fus {
 // values, and flushed before the flux cubes are written -- while the G loads are still in flight --
 // instead of living in a fourth array to the end of the kernel (P = 6: 58 -> 45 KB, 3 workgroups
 // per CU instead of 2 once the registers allow it).
-template <typename T, int P, int CPB, int MINW, int GPRE>
+// MASS = false: the stiffness part alone, b += K(c3) u + K(c4) v (detJ, c2, c5, m unused).  With GLL
+// collocation the mass operator is diagonal, M(c) x = diag(M(c) 1) x, so a driver can precompute the two
+// diagonals once and apply the mass terms pointwise in its vector kernel (fus_rk4_stage_nl2_*): no
+// detJ stream, no second atomic flush and no extra barriers in the cell pass.
+template <typename T, int P, int CPB, int MINW, int GPRE, bool MASS = true>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     westervelt_cell_kernel(const T* __restrict__ u_in, const T* __restrict__ v_in, const T* __restrict__ c2,
                            const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
@@ -78,15 +82,17 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const uint16_t* sp = slot + pos * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
-    const T* dc = detJ + cell * Nd + t;
+    if constexpr (MASS) {
+      const T* dc = detJ + cell * Nd + t;
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) dj[ix] = dc[ix * n2];
+      for (int ix = 0; ix < n; ++ix) dj[ix] = dc[ix * n2];
+      k2 = c2[cell];
+      k5 = c5[cell];
+    }
 #pragma unroll
     for (int ix = 0; ix < GPRE; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
-    k2 = c2[cell];
     k3 = c3[cell];
     k4 = c4[cell];
-    k5 = c5[cell];
   }
   batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
   {
@@ -116,22 +122,26 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int ix = 0; ix < n; ++ix) {
       const T uu = sxu[sl[ix]], vv = sxv[sl[ix]];
       w[ix] = k3 * uu + k4 * vv;
-      bextra[ix] = dj[ix] * k5 * vv * vv;
-      madd[ix] = dj[ix] * k2 * uu;
+      if constexpr (MASS) {
+        bextra[ix] = dj[ix] * k5 * vv * vv;
+        madd[ix] = dj[ix] * k2 * uu;
+      }
       cu[ix * n2] = w[ix];
     }
   }
   __syncthreads();  // B2: u / v values are dead; the input cube is complete
-  // ---- lumped mass: pre-reduce in the dead u-value region and flush, under the shadow of the G loads
-  plan_zero<T, SPT, BLOCK>(sm, nu_b, tid);
-  __syncthreads();
-  if (active) {
+  if constexpr (MASS) {
+    // ---- lumped mass: pre-reduce in the dead u-value region and flush, under the shadow of the G loads
+    plan_zero<T, SPT, BLOCK>(sm, nu_b, tid);
+    __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], madd[ix]);
+      for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], madd[ix]);
+    }
+    __syncthreads();
+    plan_flush<T, SPT, BLOCK>(m, mydof, nu_b, tid, sm);
+    __syncthreads();  // the m sums have been read: the region becomes the flux-y cube
   }
-  __syncthreads();
-  plan_flush<T, SPT, BLOCK>(m, mydof, nu_b, tid, sm);
-  __syncthreads();  // the m sums have been read: the region becomes the flux-y cube
 
   T fx[n];
   if (active) {
@@ -173,7 +183,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const T* cf_z = sfz + lc * S + ty * n;
 #pragma unroll
     for (int jx = 0; jx < n; ++jx) {
-      T acc = bextra[jx];
+      T acc = MASS ? bextra[jx] : T(0);
 #pragma unroll
       for (int qx = 0; qx < n; ++qx) acc += dphi[qx * n + jx] * fx[qx];
 #pragma unroll
@@ -194,7 +204,7 @@ __host__ __device__ constexpr int westervelt_g_ring() {
   return P <= 3 ? P + 1 : plan_g_ring<P>();
 }
 
-template <typename T, int P>
+template <typename T, int P, bool MASS = true>
 inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5,
                                          T* b, T* m, const T* G, const T* detJ, const void* workspace, const T* dphi,
                                          int64_t ncell, hipStream_t stream, bool ordered = false) {
@@ -203,7 +213,9 @@ inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, co
   PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   constexpr int MINW = 1;
-  hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, westervelt_g_ring<P>()>), dim3((unsigned)pv.nbatch),
+  // stiffness-only: the ring sizes of the stiffness kernel (its register profile + one more gather)
+  constexpr int RING = MASS ? westervelt_g_ring<P>() : ((P == 6 || P == 7 || P == 10) ? plan_g_ring<P>() : P + 1);
+  hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, RING, MASS>), dim3((unsigned)pv.nbatch),
                      dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell,
                      ordered ? pv.order : nullptr);
   return hipGetLastError();
@@ -255,6 +267,68 @@ __global__ void __launch_bounds__(256)
     m[i] = (i < nlocal) ? m0[i] : T(0);
     b[i] = T(0);
   }
+}
+
+// The same stage with the mass terms applied POINTWISE from two precomputed diagonals (GLL
+// collocation: M(c) x = diag(M(c) 1) x):  w2 = M(c2) 1,  w5 = M(c5) 1, assembled once like m0, so
+//   m = m0 + M(c2) u_n = m0 + w2 u_n ,   b += M(c5) v_n^2 = w5 v_n^2        (cuda/demo_nonlinear_bowl.py:603-632)
+// and the cell pass is the stiffness part alone.  (u_n, v_n) = the stage's inputs: (u0, v0) for kind FIRST,
+// else (un, ku).  No m array is read, written or reverse-scattered any more.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    rk4_stage_nl2_kernel(T bw, T aw, int kind, const T* __restrict__ m0, const T* __restrict__ w2,
+                         const T* __restrict__ w5, T* __restrict__ b, T* __restrict__ u, T* __restrict__ v,
+                         T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ ku, T* __restrict__ un,
+                         int64_t nlocal, int64_t ntotal) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntotal; i += stride) {
+    if (i < nlocal) {
+      if (kind == 2) {  // FIRST: stage inputs are (u0, v0); u == u0, v == v0, ku == v0
+        const T u0i = u0[i], v0i = v0[i];
+        const T kv = (b[i] + w5[i] * v0i * v0i) / (m0[i] + w2[i] * u0i);
+        u[i] = u0i + bw * v0i;
+        v[i] = v0i + bw * kv;
+        un[i] = u0i + aw * v0i;
+        ku[i] = v0i + aw * kv;
+      } else {
+        const T uni = un[i], kui = ku[i];
+        const T kv = (b[i] + w5[i] * kui * kui) / (m0[i] + w2[i] * uni);
+        if (kind == 3) {  // LAST
+          u0[i] = u[i] + bw * kui;
+          v0[i] = v[i] + bw * kv;
+        } else {
+          const T ui = u[i] + bw * kui;
+          const T vi = v[i] + bw * kv;
+          u[i] = ui;
+          v[i] = vi;
+          T u0i, v0i;
+          if (kind == 1) {
+            u0i = ui;
+            v0i = vi;
+            u0[i] = ui;
+            v0[i] = vi;
+          } else {
+            u0i = u0[i];
+            v0i = v0[i];
+          }
+          un[i] = u0i + aw * kui;
+          ku[i] = v0i + aw * kv;
+        }
+      }
+    }
+    b[i] = T(0);
+  }
+}
+
+template <typename T>
+inline hipError_t launch_rk4_stage_nl2(T bw, T aw, int kind, const T* m0, const T* w2, const T* w5, T* b, T* u, T* v,
+                                       T* u0, T* v0, T* ku, T* un, int64_t nlocal, int64_t ntotal, hipStream_t stream) {
+  if (ntotal <= 0) return hipSuccess;
+  int64_t nblocks = (ntotal + 255) / 256;
+  if (nblocks > 4096) nblocks = 4096;
+  hipLaunchKernelGGL((rk4_stage_nl2_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5, b,
+                     u, v, u0, v0, ku, un, nlocal, ntotal);
+  return hipGetLastError();
 }
 
 template <typename T>

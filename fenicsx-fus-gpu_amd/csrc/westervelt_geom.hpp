@@ -10,7 +10,7 @@
 
 namespace fus {
 
-template <typename T, int P, int CPB, int MINW>
+template <typename T, int P, int CPB, int MINW, bool MASS = true>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     westervelt_cell_geom_kernel(const T* __restrict__ u_in, const T* __restrict__ v_in, const T* __restrict__ c2,
                                 const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
@@ -67,10 +67,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const uint16_t* sp = slot + pos * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
-    k2 = c2[cell];
+    if constexpr (MASS) {
+      k2 = c2[cell];
+      k5 = c5[cell];
+    }
     k3 = c3[cell];
     k4 = c4[cell];
-    k5 = c5[cell];
   }
   batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
   stage_vertex_coords<T, VPT, BLOCK, CPB>(x_g, vid, tid, sX);
@@ -104,23 +106,27 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) {
       const T uu = sxu[sl[ix]], vv = sxv[sl[ix]];
-      const T dj = column_absdet_at<T>(pts[ix], J0, Ja, Jba, Jc, Jdc) * (wts[ix] * wyz);  // scaled Jacobian determinant
       w[ix] = k3 * uu + k4 * vv;
-      bextra[ix] = dj * k5 * vv * vv;
-      madd[ix] = dj * k2 * uu;
+      if constexpr (MASS) {
+        const T dj = column_absdet_at<T>(pts[ix], J0, Ja, Jba, Jc, Jdc) * (wts[ix] * wyz);  // scaled Jacobian determinant
+        bextra[ix] = dj * k5 * vv * vv;
+        madd[ix] = dj * k2 * uu;
+      }
       cu[ix * n2] = w[ix];
     }
   }
   __syncthreads();  // B2
-  plan_zero<T, SPT, BLOCK>(sm, nu_b, tid);
-  __syncthreads();
-  if (active) {
+  if constexpr (MASS) {
+    plan_zero<T, SPT, BLOCK>(sm, nu_b, tid);
+    __syncthreads();
+    if (active) {
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], madd[ix]);
+      for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], madd[ix]);
+    }
+    __syncthreads();
+    plan_flush<T, SPT, BLOCK>(m, mydof, nu_b, tid, sm);
+    __syncthreads();
   }
-  __syncthreads();
-  plan_flush<T, SPT, BLOCK>(m, mydof, nu_b, tid, sm);
-  __syncthreads();
 
   T fx[n];
   if (active) {
@@ -160,7 +166,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     const T* cf_z = sfz + lc * S + ty * n;
 #pragma unroll
     for (int jx = 0; jx < n; ++jx) {
-      T acc = bextra[jx];
+      T acc = MASS ? bextra[jx] : T(0);
 #pragma unroll
       for (int qx = 0; qx < n; ++qx) acc += dphi[qx * n + jx] * fx[qx];
 #pragma unroll
@@ -175,7 +181,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   plan_flush<T, SPT, BLOCK>(b, mydof, nu_b, tid, sb);
 }
 
-template <typename T, int P>
+template <typename T, int P, bool MASS = true>
 inline hipError_t launch_westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const T* c4,
                                               const T* c5, T* b, T* m, const T* x_g, const int32_t* x_dofs,
                                               const T* pts, const T* wts, const void* workspace, const T* dphi,
@@ -184,7 +190,7 @@ inline hipError_t launch_westervelt_cell_geom(const T* u, const T* v, const T* c
   if (ncell <= 0) return hipSuccess;
   PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
-  hipLaunchKernelGGL((westervelt_cell_geom_kernel<T, P, CPB, 1>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u,
+  hipLaunchKernelGGL((westervelt_cell_geom_kernel<T, P, CPB, 1, MASS>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u,
                      v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, pv.nu, pv.udofs, pv.slot, dphi, ncell,
                      ordered ? pv.order : nullptr);
   return hipGetLastError();

@@ -93,6 +93,16 @@ class WesterveltSpectral3D:
             self.halo.rev(self.m0)
 
         self.cell_fused = ops.westervelt_cell_operator(P, D.flatten(), ft)
+        # fused mode: with GLL collocation the mass operator is diagonal, M(c) x = diag(M(c) 1) x, so the
+        # stage's two cell mass applies (M(c2) u_n for the lumped mass, M(c5) v_n^2 for the right-hand side,
+        # cuda/demo_nonlinear_bowl.py:612-616,630-632) are pointwise products with two diagonals assembled
+        # once, like m0; the cell pass is then the stiffness part alone and m needs no reverse scatter
+        self.w2, self.w5 = z(), z()
+        self.mass_cell(self.g, self.cc2, self.w2, self.detJ, self.dofmap)  # g == 1 here
+        self.mass_cell(self.g, self.cc5, self.w5, self.detJ, self.dofmap)
+        if self.halo is not None:
+            self.halo.rev(self.w2)
+            self.halo.rev(self.w5)
         # opt-in (fused mode): G and detJ formed in the cell kernel from the vertices -- the cells of
         # the reference's meshes are trilinear (P1 geometry, cuda/demo_nonlinear_bowl.py:317)
         self.in_kernel_geometry = bool(in_kernel_geometry)
@@ -110,12 +120,12 @@ class WesterveltSpectral3D:
 
     # -- fused stage: one cell pass + one vector pass ------------------------------------------------
     def _stage_vector_kernel(self, bw, aw, new_step):
-        fn = getattr(_lib.load(), f"fus_rk4_stage_nl_{_lib.suffix(self.tdt)}")
+        fn = getattr(_lib.load(), f"fus_rk4_stage_nl2_{_lib.suffix(self.tdt)}")
         _lib.check(
-            fn(float(bw), float(aw), int(new_step), self.m0.data_ptr(), self.m.data_ptr(), self.b.data_ptr(),
-               self.u.data_ptr(), self.v.data_ptr(), self.u0.data_ptr(), self.v0.data_ptr(), self.ku.data_ptr(),
-               self.un.data_ptr(), self.nlocal, self.ndofs, _lib.stream_ptr()),
-            "fus_rk4_stage_nl",
+            fn(float(bw), float(aw), int(new_step), self.m0.data_ptr(), self.w2.data_ptr(), self.w5.data_ptr(),
+               self.b.data_ptr(), self.u.data_ptr(), self.v.data_ptr(), self.u0.data_ptr(), self.v0.data_ptr(),
+               self.ku.data_ptr(), self.un.data_ptr(), self.nlocal, self.ndofs, _lib.stream_ptr()),
+            "fus_rk4_stage_nl2",
         )
 
     def _operator_fused(self, ts, u_n=None, v_n=None):
@@ -126,25 +136,24 @@ class WesterveltSpectral3D:
             ops.scale(gv, self.fc1_1, self.fc_src)        # M_f1(fc1_1) g + M_f1(fc2_1) dg
             ops.axpy[1, 1](dgv, self.fc2_1, self.fc_src)  #   = M_f1(fc1_1 g + fc2_1 dg) 1
 
-        def cells(c2, c3, c4, c5, G_, dJ_, dm_):
-            self.cell_fused(u_n, v_n, c2, c3, c4, c5, self.b, self.m, G_, dJ_, dm_)
+        def cells(c3, c4, G_, dm_):
+            self.cell_fused.stiffness_only(u_n, v_n, c3, c4, self.b, G_, dm_)
 
         def facets():
             self.mass_facet(self.g, self.fc_src, self.b, self.dF1, self.fdm1)  # g == 1
             self.mass_facet(v_n, self.fc2_2, self.b, self.dF2, self.fdm2)
 
-        percell = (self.cc2, self.cc3, self.cc4, self.cc5, self.G, self.detJ, self.dofmap)
+        percell = (self.cc3, self.cc4, self.G, self.dofmap)
         if self.in_kernel_geometry:
-            def cells(c2, c3, c4, c5, xd_, dm_):  # noqa: F811
-                self.cell_fused_geom(u_n, v_n, c2, c3, c4, c5, self.b, self.m, xd_, dm_)
+            def cells(c3, c4, xd_, dm_):  # noqa: F811
+                self.cell_fused_geom.stiffness_only(u_n, v_n, c3, c4, self.b, xd_, dm_)
 
-            percell = (self.cc2, self.cc3, self.cc4, self.cc5, self.x_dofs, self.dofmap)
+            percell = (self.cc3, self.cc4, self.x_dofs, self.dofmap)
         if self.halo is None:
             cells(*percell)
             facets()
         else:
-            self.halo.run(cells, percell, [(self.fwd_u, u_n), (self.fwd_v, v_n)],
-                          [(self.halo.rev, self.b), (self.rev_m, self.m)], facets)
+            self.halo.run(cells, percell, [(self.fwd_u, u_n), (self.fwd_v, v_n)], [(self.halo.rev, self.b)], facets)
 
     def source_values(self, t):
         """g and dg/dt (cuda/demo_nonlinear_bowl.py:560-595)."""
@@ -202,8 +211,6 @@ class WesterveltSpectral3D:
         if self.fused:
             ops.fill(1.0, self.g)  # source enters through scaled facet constants
             ops.fill(0.0, self.b)
-            ops.copy(self.m0, self.m)
-            ops.fill(0.0, self.m[self.nlocal:])  # ghost entries collect partial sums
             ops.copy(self.u, self.u0)  # between steps the solution lives in (u0, v0): stage kinds 2, 0, 0, 3
             ops.copy(self.v, self.v0)
         while t < tf and (max_steps is None or step < max_steps):

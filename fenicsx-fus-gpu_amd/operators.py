@@ -414,6 +414,51 @@ def westervelt_cell_operator(P, dphi, float_type, geometry=None):
     return _WesterveltCellOperator(P, dphi, float_type)
 
 
+def _westervelt_stiffness_only(self, u, v, c3, c4, b, G_or_xdofs, dofmap, geom):
+    dt = self.dtype
+    for name, t in (("u", u), ("v", v), ("c3", c3), ("c4", c4), ("b", b)):
+        _req(t, dt, name)
+    _req(dofmap, torch.int32, "dofmap")
+    nd = self.n**3
+    ncell = dofmap.shape[0]
+    if dofmap.dim() != 2 or dofmap.shape[1] != nd or c3.numel() != ncell or c4.numel() != ncell:
+        raise ValueError(f"dofmap [ncell, {nd}] and one c3 / c4 value per cell expected")
+    if ncell == 0:
+        return
+    ws, _ = _PLANS.get(dofmap)
+    if geom:
+        _req(G_or_xdofs, torch.int32, "x_dofs")
+        if tuple(G_or_xdofs.shape) != (ncell, 8):
+            raise ValueError("x_dofs [ncell, 8] expected")
+        rc = self._fn(u.data_ptr(), v.data_ptr(), None, c3.data_ptr(), c4.data_ptr(), None, b.data_ptr(), None,
+                      self.x_g.data_ptr(), G_or_xdofs.data_ptr(), self.pts.data_ptr(), self.wts.data_ptr(), ws.data_ptr(),
+                      self._st._dphi.data_ptr(), self.P, int(ncell), _lib.stream_ptr())
+    else:
+        _req(G_or_xdofs, dt, "G")
+        if G_or_xdofs.numel() != ncell * nd * 6:
+            raise ValueError(f"G [ncell, {nd}, 6] expected")
+        rc = self._fn(u.data_ptr(), v.data_ptr(), None, c3.data_ptr(), c4.data_ptr(), None, b.data_ptr(), None,
+                      G_or_xdofs.data_ptr(), None, ws.data_ptr(), self._st._dphi.data_ptr(), self.P, int(ncell),
+                      _lib.stream_ptr())
+    _lib.check(rc, "fus_westervelt_cell_apply_planned (stiffness part)")
+
+
+def _stiffness_only_general(self, u, v, c3, c4, b, G, dofmap):
+    """``b += K(c3) u + K(c4) v`` in one pass over the cells (G read once, u and v gathered once): the
+    stiffness part of the Westervelt stage; the mass terms are applied pointwise by the driver from
+    precomputed diagonals (``fus_rk4_stage_nl2_*``)."""
+    _westervelt_stiffness_only(self, u, v, c3, c4, b, G, dofmap, False)
+
+
+def _stiffness_only_geom(self, u, v, c3, c4, b, x_dofs, dofmap):
+    """As above with G formed in the kernel from the cell vertices."""
+    _westervelt_stiffness_only(self, u, v, c3, c4, b, x_dofs, dofmap, True)
+
+
+_WesterveltCellOperator.stiffness_only = _stiffness_only_general
+_WesterveltCellGeomOperator.stiffness_only = _stiffness_only_geom
+
+
 def locality_cell_order(dofmap):
     """Set-up helper: permutation of the cells (int64 tensor on the dofmap's device) that puts cells
     with nearby dofs next to each other -- cells sorted by their smallest dof.  The planned kernels

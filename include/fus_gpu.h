@@ -221,7 +221,22 @@ int fus_rk4_stage_f32(float bw, float aw, int new_step, const float* minv, float
  *   b += K(c3) u + K(c4) v + M(c5) v^2 ;   m += M(c2) u
  * reading G and detJ once and gathering u, v once.  c2..c5: per-cell constants T[ncell].
  * fus_rk4_stage_nl_*: fus_rk4_stage_* for a stage-dependent lumped mass: kv = b / m, then m = m0.
+ *
+ * Diagonal form (what the Westervelt solver of this repo runs): with GLL collocation the mass operator
+ * is diagonal, M(c) x = diag(M(c) 1) x, so the two mass terms can be applied pointwise from diagonals
+ * assembled once, w2 = M(c2) 1 and w5 = M(c5) 1:
+ *   fus_westervelt_cell_apply_planned[_geom]_* with c2 = c5 = m = detJ = NULL computes the stiffness part
+ *   alone, b += K(c3) u + K(c4) v  (no detJ stream, one atomic flush, no m array);
+ *   fus_rk4_stage_nl2_*: kv = (b + w5 v_n^2) / (m0 + w2 u_n) with (u_n, v_n) the stage's inputs ((u0, v0)
+ *   for new_step = 2, else (un, ku)), then the updates of fus_rk4_stage_*.
+ * Same result as the four reference launches up to summation order.
  */
+int fus_rk4_stage_nl2_f64(double bw, double aw, int new_step, const double* m0, const double* w2, const double* w5,
+                          double* b, double* u, double* v, double* u0, double* v0, double* ku, double* un,
+                          int64_t nlocal, int64_t ntotal, void* stream);
+int fus_rk4_stage_nl2_f32(float bw, float aw, int new_step, const float* m0, const float* w2, const float* w5,
+                          float* b, float* u, float* v, float* u0, float* v0, float* ku, float* un, int64_t nlocal,
+                          int64_t ntotal, void* stream);
 int fus_westervelt_cell_apply_planned_f64(const double* u, const double* v, const double* c2, const double* c3,
                                           const double* c4, const double* c5, double* b, double* m, const double* G,
                                           const double* detJ, const void* workspace, const double* dphi, int P,

@@ -611,3 +611,34 @@ def test_westervelt_cell_pass_in_kernel_geometry(gpu, oracle_c, P, dtype):
        b, m, dev.to_device(mesh.x_dofs), dev.to_device(mesh.dofmap))
     _check(b.copy_to_host(), b_ref, dtype, f"Westervelt b, in-kernel geometry P={P}")
     _check(m.copy_to_host(), m_ref, dtype, f"Westervelt m, in-kernel geometry P={P}")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [2, 4, 6, 7])
+def test_westervelt_stiffness_part_and_diagonal_mass(gpu, oracle_c, P, dtype):
+    """The diagonal form of the Westervelt stage: (i) the cell pass with c2 = c5 = m = detJ = NULL is
+    b += K(c3) u + K(c4) v (general G and in-kernel geometry); (ii) GLL collocation: M(c) x == diag(M(c) 1) x,
+    the identity the solver's pointwise mass terms rest on, checked on the reference-pinned mass operator."""
+    dev, ops = gpu
+    pb = build_problem(P, (3, 2, 3), dtype=dtype, perturb=0.25, seed=60 + P)
+    mesh = pb["mesh"]
+    rng = np.random.default_rng(P)
+    v = rng.standard_normal(mesh.ndofs).astype(dtype)
+    c3, c4 = ((0.5 + rng.random(mesh.ncells)).astype(dtype) for _ in range(2))
+    b_ref = np.zeros(mesh.ndofs, dtype=dtype)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], c3, b_ref, pb["G"], mesh.dofmap)
+    oracle_c.stiffness_apply(P, pb["D"], v, c4, b_ref, pb["G"], mesh.dofmap)
+    args = (dev.to_device(pb["x"]), dev.to_device(v), dev.to_device(c3), dev.to_device(c4))
+    b = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    ops.westervelt_cell_operator(P, pb["D"].flatten(), dtype).stiffness_only(*args, b, dev.to_device(pb["G"]), dev.to_device(mesh.dofmap))
+    _check(b.copy_to_host(), b_ref, dtype, f"K(c3)u + K(c4)v P={P}")
+    b = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    opg = ops.westervelt_cell_operator(P, pb["D"].flatten(), dtype, geometry=(mesh.x_g, pb["pts"], pb["wts"]))
+    opg.stiffness_only(*args, b, dev.to_device(mesh.x_dofs), dev.to_device(mesh.dofmap))
+    _check(b.copy_to_host(), b_ref, dtype, f"K(c3)u + K(c4)v, in-kernel geometry P={P}")
+    # (ii)
+    ones = np.ones(mesh.ndofs, dtype=dtype)
+    diag, full = np.zeros(mesh.ndofs, dtype=dtype), np.zeros(mesh.ndofs, dtype=dtype)
+    oracle_c.mass_apply(ones, c3, diag, pb["detJ"], mesh.dofmap)
+    oracle_c.mass_apply(v, c3, full, pb["detJ"], mesh.dofmap)
+    _check(diag * v, full, dtype, "M(c) x == diag(M(c) 1) x")

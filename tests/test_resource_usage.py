@@ -46,14 +46,16 @@ SHIPPED = [
     (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true>", 128, 4),
     (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, 1, false>", 168, 3),
     (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, 1, true>", 96, 5),
-    (r"westervelt_cell_geom_kernel<double, 6, 5, 1>", 168, 3),
+    (r"westervelt_cell_geom_kernel<double, 6, 5, 1, false>", 168, 3),
     # affine fast path
     (r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>", 96, 5),
     (r"stiffness_plan_affine_kernel<double, 6, 5, true, true, 1>", 168, 3),
     # fused Westervelt cell pass
-    (r"westervelt_cell_kernel<double, 4, 10, 1, 3>", 128, 4),
-    (r"westervelt_cell_kernel<double, 6, 5, 1, 4>", 168, 3),   # BASELINE config 5 degree
-    (r"westervelt_cell_kernel<float, 4, 10, 1, 3>", 96, 5),
+    (r"westervelt_cell_kernel<double, 4, 10, 1, 3, true>", 128, 4),
+    (r"westervelt_cell_kernel<double, 6, 5, 1, 4, true>", 168, 3),
+    (r"westervelt_cell_kernel<double, 6, 5, 1, 4, false>", 168, 3),   # BASELINE config 5: what the solver runs
+    (r"westervelt_cell_kernel<double, 4, 10, 1, 5, false>", 128, 4),
+    (r"westervelt_cell_kernel<float, 4, 10, 1, 3, true>", 96, 5),
     # plan-free column kernel
     (r"stiffness_col_kernel<double, 4, 10>", 128, 4),
 ]
