@@ -240,6 +240,33 @@ def dry_run(args, rank, world):
     return 0 if ok.item() == 1.0 else 1
 
 
+def make_comm(args, scat, world, device):
+    """The halo transport of this run, decided COLLECTIVELY: the native communicator (libfusgpu.so issues
+    the RCCL calls) unless --halo torch; if its creation fails on ANY rank, every rank falls back to
+    torch.distributed's all_to_all_single (also RCCL) and the line says so."""
+    import torch
+    import torch.distributed as dist
+
+    if args.halo != "native":
+        return scat.TorchComm(), "torch"
+    comm, ok = None, 1.0
+    try:
+        comm = scat.NativeComm()
+    except Exception as e:  # noqa: BLE001
+        log(f"native communicator failed on rank {dist.get_rank() if dist.is_initialized() else 0}: {e!r}")
+        ok = 0.0
+    if world > 1:
+        flag = torch.tensor([ok], dtype=torch.float64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        ok = float(flag.item())
+    if ok == 1.0:
+        return comm, "native"
+    if comm is not None:
+        comm.close()
+    log("falling back to the torch.distributed transport on all ranks")
+    return scat.TorchComm(), "torch (native communicator failed)"
+
+
 def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
     """Time the oracle (C restatement of numba-cpu/operators.py:71-227) on the host
     cores of this box, on the same mesh the GPU ran.  Reported, never shipped."""
@@ -332,7 +359,7 @@ def bench_rk4(args, rank, world, device):
     dts, tf, nstep = ls.snap_time_step(h, P, 1500.0, 0.5e6, L * grid[0])  # the wave crosses the whole (partitioned) box
     if args.warmup + args.steps > nstep:
         raise SystemExit(f"--warmup + --steps = {args.warmup + args.steps} exceeds the {nstep} steps to the final time")
-    comm = (scat.NativeComm() if args.halo == "native" else scat.TorchComm()) if world > 1 else None
+    comm = make_comm(args, scat, world, device)[0] if world > 1 else None
     if args.mode == "westervelt":  # BASELINE config 5 shape: Westervelt, bowl-warped trilinear cells
         nls = fusgpu_loader.submodule("nonlinear_solver")
         Lx = L * grid[0]
@@ -511,7 +538,7 @@ def main():
     halo = None
     if use_dist:
         scat = fusgpu_loader.submodule("scatterer")
-        comm = scat.NativeComm() if args.halo == "native" else scat.TorchComm()
+        comm, transport = make_comm(args, scat, world, device)
         halo = scat.HaloApply(mesh, op, comm, dt, overlap=os.environ.get("FUS_HALO_OVERLAP", "1") != "0")
 
     def step():
@@ -644,8 +671,8 @@ def main():
             "xcd_remap": lib.get_tuning(lib.TUNE_XCD_REMAP),
             "halo": None if halo is None else ("overlapped" if halo.overlap else "sequential"),
             "halo_transport": None if halo is None else (
-                "libfusgpu.so: grouped ncclSend/ncclRecv on a library-owned stream" if args.halo == "native"
-                else "torch.distributed.all_to_all_single (RCCL)"),
+                "libfusgpu.so: grouped ncclSend/ncclRecv on a library-owned stream" if transport == "native"
+                else f"torch.distributed.all_to_all_single (RCCL) [{transport}]"),
             "halo_exposed_ms": None if halo is None else max(0.0, ms_per_step - kern_ms),
             "halo_exposed_frac": None if halo is None else max(0.0, ms_per_step - kern_ms) / kern_ms,
             "ranks": world,
