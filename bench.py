@@ -375,7 +375,10 @@ def bench_rk4(args, rank, world, device):
                                           in_kernel_geometry=args.in_kernel_geometry)
         solver.affine = False
     else:
-        solver = ls.LinearSpectral3D(mesh, dt_np, comm=comm, fused=True)
+        if args.perturbed:  # non-affine cells: general G, or G formed in the kernel
+            mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, length=tuple(L * g for g in grid), dtype=dt_np,
+                                   perturb=0.16, seed=0)
+        solver = ls.LinearSpectral3D(mesh, dt_np, comm=comm, fused=True, in_kernel_geometry=args.in_kernel_geometry)
     solver.init()
     solver.rk4(0.0, tf, dts, max_steps=max(1, args.warmup))
     if world > 1:
@@ -433,7 +436,8 @@ def main():
                     help="CPU rehearsal of the N-rank path (gloo): launcher, partition, halo plan and exchange; no "
                          "GPU, no operator, the printed line is marked invalid")
     ap.add_argument("--in-kernel-geometry", action="store_true",
-                    help="--mode westervelt: the fused cell pass forms G and detJ from the cell vertices")
+                    help="--mode westervelt / rk4: the cell pass forms G (and detJ) from the cell vertices")
+    ap.add_argument("--perturbed", action="store_true", help="--mode rk4: perturbed (non-affine) cells instead of the affine box")
     ap.add_argument("--halo", default=os.environ.get("FUS_HALO", "native"), choices=["native", "torch"],
                     help="N > 1 transport: native = grouped ncclSend/ncclRecv issued by libfusgpu.so on its own "
                          "stream (default); torch = torch.distributed all_to_all_single")

@@ -72,7 +72,7 @@ def _signatures():
         sig[f"fus_westervelt_cell_apply_planned_{suf}"] = [_vp] * 12 + [_int, _i64, _vp]
         sig[f"fus_westervelt_cell_apply_planned_geom_{suf}"] = [_vp] * 14 + [_int, _i64, _vp]
         sig[f"fus_rk4_stage_nl_{suf}"] = [ct, ct, _int] + [_vp] * 9 + [_i64, _i64, _vp]
-        sig[f"fus_rk4_stage_nl2_{suf}"] = [ct, ct, _int] + [_vp] * 10 + [_i64, _i64, _vp]
+        sig[f"fus_rk4_stage_nl2_{suf}"] = [ct, ct, _int] + [_vp] * 10 + [ct, _vp, _i64, _i64, _vp]
         sig[f"fus_rk4_stage_{suf}"] = [ct, ct, _int] + [_vp] * 8 + [_i64, _i64, _vp]
         sig[f"fus_pack_fwd_{suf}"] = [_vp, _vp, _vp, _i64, _vp]
         sig[f"fus_unpack_fwd_{suf}"] = [_vp, _vp, _vp, _i64, _i64, _vp]

@@ -564,12 +564,12 @@ FUS_WEST(double, f64)
 FUS_WEST(float, f32)
 #define FUS_NL2(T, SUF)                                                                                            \
   int fus_rk4_stage_nl2_##SUF(T bw, T aw, int new_step, const T* m0, const T* w2, const T* w5, T* b, T* u, T* v,   \
-                              T* u0, T* v0, T* ku, T* un, int64_t nlocal, int64_t ntotal, void* s) {               \
+                              T* u0, T* v0, T* ku, T* un, T kappa, T* w, int64_t nlocal, int64_t ntotal, void* s) { \
     if (nlocal < 0 || ntotal < nlocal) return FUS_ERR_INVALID_ARGUMENT;                                            \
     if (ntotal == 0) return FUS_OK;                                                                                \
     if (!m0 || !w2 || !w5 || !b || !u || !v || !u0 || !v0 || !ku || !un) return FUS_ERR_INVALID_ARGUMENT;          \
-    return hip_rc(fus::launch_rk4_stage_nl2<T>(bw, aw, new_step, m0, w2, w5, b, u, v, u0, v0, ku, un, nlocal,      \
-                                               ntotal, static_cast<hipStream_t>(s)));                              \
+    return hip_rc(fus::launch_rk4_stage_nl2<T>(bw, aw, new_step, m0, w2, w5, b, u, v, u0, v0, ku, un, kappa, w,    \
+                                               nlocal, ntotal, static_cast<hipStream_t>(s)));                      \
   }
 FUS_NL2(double, f64)
 FUS_NL2(float, f32)

@@ -274,28 +274,36 @@ __global__ void __launch_bounds__(256)
 //   m = m0 + M(c2) u_n = m0 + w2 u_n ,   b += M(c5) v_n^2 = w5 v_n^2        (cuda/demo_nonlinear_bowl.py:603-632)
 // and the cell pass is the stiffness part alone.  (u_n, v_n) = the stage's inputs: (u0, v0) for kind FIRST,
 // else (un, ku).  No m array is read, written or reverse-scattered any more.
+// ``w`` (optional): the combined stiffness input of the NEXT cell pass, w = u_n' + kappa v_n', for media where
+// c4 = kappa c3 in every cell (then K(c3) u + K(c4) v = K(c3)(u + kappa v): one plain stiffness apply, one
+// gather, one forward halo exchange less); for kind LAST it is formed from the new (u0, v0).
 template <typename T>
 __global__ void __launch_bounds__(256)
     rk4_stage_nl2_kernel(T bw, T aw, int kind, const T* __restrict__ m0, const T* __restrict__ w2,
                          const T* __restrict__ w5, T* __restrict__ b, T* __restrict__ u, T* __restrict__ v,
                          T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ ku, T* __restrict__ un,
-                         int64_t nlocal, int64_t ntotal) {
+                         T kappa, T* __restrict__ w, int64_t nlocal, int64_t ntotal) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntotal; i += stride) {
     if (i < nlocal) {
+      T un_new, vn_new;
       if (kind == 2) {  // FIRST: stage inputs are (u0, v0); u == u0, v == v0, ku == v0
         const T u0i = u0[i], v0i = v0[i];
         const T kv = (b[i] + w5[i] * v0i * v0i) / (m0[i] + w2[i] * u0i);
         u[i] = u0i + bw * v0i;
         v[i] = v0i + bw * kv;
-        un[i] = u0i + aw * v0i;
-        ku[i] = v0i + aw * kv;
+        un_new = u0i + aw * v0i;
+        vn_new = v0i + aw * kv;
+        un[i] = un_new;
+        ku[i] = vn_new;
       } else {
         const T uni = un[i], kui = ku[i];
         const T kv = (b[i] + w5[i] * kui * kui) / (m0[i] + w2[i] * uni);
-        if (kind == 3) {  // LAST
-          u0[i] = u[i] + bw * kui;
-          v0[i] = v[i] + bw * kv;
+        if (kind == 3) {  // LAST: the next stage's inputs are the new (u0, v0)
+          un_new = u[i] + bw * kui;
+          vn_new = v[i] + bw * kv;
+          u0[i] = un_new;
+          v0[i] = vn_new;
         } else {
           const T ui = u[i] + bw * kui;
           const T vi = v[i] + bw * kv;
@@ -311,10 +319,13 @@ __global__ void __launch_bounds__(256)
             u0i = u0[i];
             v0i = v0[i];
           }
-          un[i] = u0i + aw * kui;
-          ku[i] = v0i + aw * kv;
+          un_new = u0i + aw * kui;
+          vn_new = v0i + aw * kv;
+          un[i] = un_new;
+          ku[i] = vn_new;
         }
       }
+      if (w != nullptr) w[i] = un_new + kappa * vn_new;
     }
     b[i] = T(0);
   }
@@ -322,12 +333,13 @@ __global__ void __launch_bounds__(256)
 
 template <typename T>
 inline hipError_t launch_rk4_stage_nl2(T bw, T aw, int kind, const T* m0, const T* w2, const T* w5, T* b, T* u, T* v,
-                                       T* u0, T* v0, T* ku, T* un, int64_t nlocal, int64_t ntotal, hipStream_t stream) {
+                                       T* u0, T* v0, T* ku, T* un, T kappa, T* w, int64_t nlocal, int64_t ntotal,
+                                       hipStream_t stream) {
   if (ntotal <= 0) return hipSuccess;
   int64_t nblocks = (ntotal + 255) / 256;
   if (nblocks > 4096) nblocks = 4096;
   hipLaunchKernelGGL((rk4_stage_nl2_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5, b,
-                     u, v, u0, v0, ku, un, nlocal, ntotal);
+                     u, v, u0, v0, ku, un, kappa, w, nlocal, ntotal);
   return hipGetLastError();
 }
 

@@ -91,7 +91,7 @@ def snap_time_step(mesh_size, P, speed_of_sound, source_frequency, domain_length
 class LinearSpectral3D:
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1500.0, density=1000.0,
                  source_frequency=0.5e6, source_amplitude=60000.0, comm=None, fused=True,
-                 source_time="tn", overlap=True, halo_kernels=None, affine="auto"):
+                 source_time="tn", overlap=True, halo_kernels=None, affine="auto", in_kernel_geometry=False):
         self.mesh, self.P = mesh, mesh.P
         self.dt_np = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(float_type)
@@ -130,6 +130,14 @@ class LinearSpectral3D:
         self.affine = bool(affine) if affine != "auto" else ops.is_affine_geometry(
             self.G, w3, rtol=1e-11 if ft == np.float64 else 1e-5)
         self.stiff = ops.stiffness_operator(P, D.flatten(), ft, affine_weights=w3 if self.affine else None)
+        # opt-in for non-affine (trilinear) cells: G formed in the kernel from the cell vertices; the
+        # per-cell argument of the stiffness apply is then the cell's vertex ids instead of G
+        self.in_kernel_geometry = bool(in_kernel_geometry) and not self.affine
+        if self.in_kernel_geometry:
+            pts1, wts1 = gll_points_weights(P)
+            self.x_dofs = td(mesh.x_dofs)
+            self.stiff = ops.stiffness_operator(P, D.flatten(), ft, geometry=(self.x_dofs, mesh.x_g, pts1, wts1))
+            self.G = self.x_dofs  # x_dofs rows travel in the G position (cell sub-ranges slice them)
         self.mass_cell = ops.mass_operator(n**3, ft)
         self.mass_facet = ops.mass_operator(n * n, ft)
         self.axpy = ops.axpy(self.ndofs)

@@ -32,7 +32,7 @@ class WesterveltSpectral3D:
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
                  source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
                  attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False,
-                 in_kernel_geometry=False):
+                 in_kernel_geometry=False, uniform_ratio="auto"):
         self.mesh, self.P = mesh, mesh.P
         ft = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(ft)
@@ -103,6 +103,14 @@ class WesterveltSpectral3D:
         if self.halo is not None:
             self.halo.rev(self.w2)
             self.halo.rev(self.w5)
+        # uniform ratio c4 / c3 (= delta / c^2: every homogeneous medium): K(c3) u + K(c4) v = K(c3)(u + kappa v),
+        # so the cell pass is ONE plain stiffness apply on w = u_n + kappa v_n, which the vector kernel writes
+        ratio = self.cc4 / self.cc3
+        kmin, kmax = float(ratio.min().item()), float(ratio.max().item())
+        self.kappa = kmin if abs(kmax - kmin) <= 1e-14 * max(abs(kmin), abs(kmax), 1e-300) else None
+        if uniform_ratio is False:  # force the general (two-gather) cell pass
+            self.kappa = None
+        self.w = z() if self.kappa is not None else None
         # opt-in (fused mode): G and detJ formed in the cell kernel from the vertices -- the cells of
         # the reference's meshes are trilinear (P1 geometry, cuda/demo_nonlinear_bowl.py:317)
         self.in_kernel_geometry = bool(in_kernel_geometry)
@@ -112,6 +120,7 @@ class WesterveltSpectral3D:
             pts, wts, _ = tabulate_1d(P, ft)
             self.x_dofs = torch.from_numpy(np.ascontiguousarray(mesh.x_dofs)).to(dev)
             self.cell_fused_geom = ops.westervelt_cell_operator(P, D.flatten(), ft, geometry=(mesh.x_g, pts, wts))
+            self.stiff_geom = ops.stiffness_operator(P, D.flatten(), ft, geometry=(self.x_dofs, mesh.x_g, pts, wts))
         self.fc_src = torch.zeros_like(self.fc1_1)  # per-stage source-facet constants (fused mode)
 
     def init(self):
@@ -124,7 +133,8 @@ class WesterveltSpectral3D:
         _lib.check(
             fn(float(bw), float(aw), int(new_step), self.m0.data_ptr(), self.w2.data_ptr(), self.w5.data_ptr(),
                self.b.data_ptr(), self.u.data_ptr(), self.v.data_ptr(), self.u0.data_ptr(), self.v0.data_ptr(),
-               self.ku.data_ptr(), self.un.data_ptr(), self.nlocal, self.ndofs, _lib.stream_ptr()),
+               self.ku.data_ptr(), self.un.data_ptr(), float(self.kappa or 0.0),
+               self.w.data_ptr() if self.w is not None else None, self.nlocal, self.ndofs, _lib.stream_ptr()),
             "fus_rk4_stage_nl2",
         )
 
@@ -136,8 +146,14 @@ class WesterveltSpectral3D:
             ops.scale(gv, self.fc1_1, self.fc_src)        # M_f1(fc1_1) g + M_f1(fc2_1) dg
             ops.axpy[1, 1](dgv, self.fc2_1, self.fc_src)  #   = M_f1(fc1_1 g + fc2_1 dg) 1
 
+        single = self.kappa is not None  # one gather: the cell pass is K(c3) w, w = u_n + kappa v_n
+        w_n = self.w
+
         def cells(c3, c4, G_, dm_):
-            self.cell_fused.stiffness_only(u_n, v_n, c3, c4, self.b, G_, dm_)
+            if single:
+                self.stiff(w_n, c3, self.b, G_, dm_)
+            else:
+                self.cell_fused.stiffness_only(u_n, v_n, c3, c4, self.b, G_, dm_)
 
         def facets():
             self.mass_facet(self.g, self.fc_src, self.b, self.dF1, self.fdm1)  # g == 1
@@ -146,14 +162,18 @@ class WesterveltSpectral3D:
         percell = (self.cc3, self.cc4, self.G, self.dofmap)
         if self.in_kernel_geometry:
             def cells(c3, c4, xd_, dm_):  # noqa: F811
-                self.cell_fused_geom.stiffness_only(u_n, v_n, c3, c4, self.b, xd_, dm_)
+                if single:
+                    self.stiff_geom(w_n, c3, self.b, xd_, dm_)  # x_dofs rows travel in the G position
+                else:
+                    self.cell_fused_geom.stiffness_only(u_n, v_n, c3, c4, self.b, xd_, dm_)
 
             percell = (self.cc3, self.cc4, self.x_dofs, self.dofmap)
         if self.halo is None:
             cells(*percell)
             facets()
         else:
-            self.halo.run(cells, percell, [(self.fwd_u, u_n), (self.fwd_v, v_n)], [(self.halo.rev, self.b)], facets)
+            self.halo.run(cells, percell, [(self.fwd_u, w_n if single else u_n), (self.fwd_v, v_n)],
+                          [(self.halo.rev, self.b)], facets)
 
     def source_values(self, t):
         """g and dg/dt (cuda/demo_nonlinear_bowl.py:560-595)."""
@@ -213,6 +233,9 @@ class WesterveltSpectral3D:
             ops.fill(0.0, self.b)
             ops.copy(self.u, self.u0)  # between steps the solution lives in (u0, v0): stage kinds 2, 0, 0, 3
             ops.copy(self.v, self.v0)
+            if self.kappa is not None:
+                ops.copy(self.u0, self.w)
+                self.axpy(self.kappa, self.v0, self.w)
         while t < tf and (max_steps is None or step < max_steps):
             dt = min(dt, tf - t)
             if self.fused:

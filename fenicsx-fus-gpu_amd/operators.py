@@ -245,7 +245,7 @@ class _StiffnessOperator(_Launchable):
         _req(cell_constants, dt, "cell_constants")
         _req(y, dt, "y")
         if self._geom is None:
-            _req(G, dt, "G")
+            _req(G, dt, "G")  # with geometry=: G is ignored (None), or carries the x_dofs rows of a cell sub-range
         _req(dofmap, torch.int32, "dofmap")
         nd = self.n**3
         if dofmap.dim() != 2 or dofmap.shape[1] != nd:
@@ -259,6 +259,13 @@ class _StiffnessOperator(_Launchable):
             return
         if self._geom is not None:
             xd, xg, pt, wt = self._geom
+            # a cell sub-range hands its rows of x_dofs in the G position (int32 [ncell, 8]: cannot be
+            # mistaken for a geometric-factor array)
+            if isinstance(G, torch.Tensor) and G.dtype == torch.int32:
+                _req(G, torch.int32, "x_dofs")
+                if tuple(G.shape) != (ncell, 8):
+                    raise ValueError(f"x_dofs must be [{ncell}, 8]")
+                xd = G
             if xd.shape[0] != ncell:
                 raise ValueError(f"geometry: x_dofs has {xd.shape[0]} cells, dofmap has {ncell}")
             ws, _ = _PLANS.get(dofmap)

@@ -228,15 +228,17 @@ int fus_rk4_stage_f32(float bw, float aw, int new_step, const float* minv, float
  *   fus_westervelt_cell_apply_planned[_geom]_* with c2 = c5 = m = detJ = NULL computes the stiffness part
  *   alone, b += K(c3) u + K(c4) v  (no detJ stream, one atomic flush, no m array);
  *   fus_rk4_stage_nl2_*: kv = (b + w5 v_n^2) / (m0 + w2 u_n) with (u_n, v_n) the stage's inputs ((u0, v0)
- *   for new_step = 2, else (un, ku)), then the updates of fus_rk4_stage_*.
+ *   for new_step = 2, else (un, ku)), then the updates of fus_rk4_stage_*.  If w != NULL it also writes
+ *   w = u_n' + kappa v_n' of the NEXT stage's inputs: where c4 = kappa c3 in every cell the next cell pass is
+ *   then ONE plain stiffness apply K(c3) w (one gather).
  * Same result as the four reference launches up to summation order.
  */
 int fus_rk4_stage_nl2_f64(double bw, double aw, int new_step, const double* m0, const double* w2, const double* w5,
                           double* b, double* u, double* v, double* u0, double* v0, double* ku, double* un,
-                          int64_t nlocal, int64_t ntotal, void* stream);
+                          double kappa, double* w, int64_t nlocal, int64_t ntotal, void* stream);
 int fus_rk4_stage_nl2_f32(float bw, float aw, int new_step, const float* m0, const float* w2, const float* w5,
-                          float* b, float* u, float* v, float* u0, float* v0, float* ku, float* un, int64_t nlocal,
-                          int64_t ntotal, void* stream);
+                          float* b, float* u, float* v, float* u0, float* v0, float* ku, float* un, float kappa,
+                          float* w, int64_t nlocal, int64_t ntotal, void* stream);
 int fus_westervelt_cell_apply_planned_f64(const double* u, const double* v, const double* c2, const double* c3,
                                           const double* c4, const double* c5, double* b, double* m, const double* G,
                                           const double* detJ, const void* workspace, const double* dphi, int P,

@@ -42,12 +42,14 @@ def test_fused_matches_reference_sequence_perturbed_mesh():
     h = ls.time_step_parameters(mesh, 3, 1500.0, 0.5e6, 0.01)
     dt, tf, _ = ls.snap_time_step(h, 3, 1500.0, 0.5e6, 0.01)
     res = []
-    for fused in (False, True):
-        s = ls.LinearSpectral3D(mesh, np.float64, fused=fused)
+    for fused, geom in ((False, False), (True, False), (True, True), (False, True)):
+        s = ls.LinearSpectral3D(mesh, np.float64, fused=fused, in_kernel_geometry=geom)
+        assert s.in_kernel_geometry == geom
         s.init()
         s.rk4(0.0, tf, dt, max_steps=20)
         res.append((s.u_sol(), s.v_sol()))
-    assert rel_l2(res[1][0], res[0][0]) < 1e-12 and rel_l2(res[1][1], res[0][1]) < 1e-12
+    for r in res[1:]:  # fused, fused + G formed in the kernel, reference sequence + G formed in the kernel
+        assert rel_l2(r[0], res[0][0]) < 1e-12 and rel_l2(r[1], res[0][1]) < 1e-12
 
 
 def _bowl_warp(xg):
@@ -59,7 +61,8 @@ def _bowl_warp(xg):
     return out
 
 
-@pytest.mark.parametrize("fused", [False, True, "geom"], ids=["reference-sequence", "fused", "fused-in-kernel-geometry"])
+@pytest.mark.parametrize("fused", [False, True, "geom", "two-gather", "geom-two-gather"],
+                         ids=["reference-sequence", "fused", "fused-in-kernel-geometry", "fused-two-gather", "fused-geom-two-gather"])
 @pytest.mark.parametrize("P,cells", [(6, (3, 2, 2)), (4, (4, 3, 3)), (2, (7, 5, 6))], ids=["P6", "P4", "P2"])
 def test_westervelt_bowl_pressure_field(oracle_c, P, cells, fused):
     """BASELINE config 5 shape (Westervelt, curved trilinear cells, P = 6) at test size; "geom": the fused
@@ -73,7 +76,9 @@ def test_westervelt_bowl_pressure_field(oracle_c, P, cells, fused):
     h = ls.time_step_parameters(mesh, P, 1480.0, 1.1e6, L)
     dt, tf, _ = ls.snap_time_step(h, P, 1480.0, 1.1e6, L)
     nsteps = 10
-    s = nls.WesterveltSpectral3D(mesh, np.float64, fused=bool(fused), in_kernel_geometry=(fused == "geom"))
+    s = nls.WesterveltSpectral3D(mesh, np.float64, fused=bool(fused), in_kernel_geometry=str(fused).startswith("geom"),
+                                 uniform_ratio=False if str(fused).endswith("two-gather") else "auto")
+    assert (s.kappa is not None) == (fused in (True, "geom") or fused is False)
     s.init()
     s.rk4(0.0, tf, dt, max_steps=nsteps)
     u_ref, v_ref = rk4_oracle.solve_westervelt(mesh, nsteps, dt, oracle_c=oracle_c)
