@@ -186,8 +186,11 @@ class _NativeScatter:
         self.end(buffer)
 
     def close(self):
+        # a halo must be destroyed before its communicator; if the communicator is already gone
+        # (interpreter shutdown order) the handle is dropped without touching it
         if self._owner is None and self.handle:
-            self._lib.fus_halo_destroy(self.handle)
+            if getattr(self.comm, "handle", None):
+                self._lib.fus_halo_destroy(self.handle)
             self.handle = None
 
     def __del__(self):

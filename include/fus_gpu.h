@@ -332,7 +332,7 @@ int fus_halo_create(fus_comm_t comm, int elem_bytes, int64_t nlocal, int64_t ngh
                     int n_ghost_ranks, const int32_t* ghost_ranks, const int64_t* ghost_sizes,
                     const int64_t* ghosts_idx, fus_halo_t* halo);
 int fus_halo_is_direct(fus_halo_t halo);
-int fus_halo_destroy(fus_halo_t halo);
+int fus_halo_destroy(fus_halo_t halo); /* before fus_comm_destroy of its communicator */
 /*
  * forward: buffer[nlocal + g] = owner's value, for every ghost g          (scatter_forward, overwrite)
  * reverse: owner's buffer[i] += every ghosting rank's partial sum of i     (scatter_reverse, add)
