@@ -31,12 +31,19 @@ std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab
 std::atomic<int> g_mass_variant{0};
 std::atomic<int> g_plan_runs{1};  // 0 never, 1 auto, 2 always
 
-// Run-length coded dof lists pay off where the index stream is a large share of the bytes
-// (P <= 3: +6 % at P = 2) and cost an extra barrier + LDS search elsewhere (P = 4 neutral,
-// P = 6 -12 %): profiles/r01d_ab_plan_runs.log.
+// Run-length coded dof lists (8 bytes per run of consecutive dofs instead of 4 per dof; expanded in LDS by
+// the apply kernels): the builder decides per batch (a list that does not compress stays raw).
 inline int plan_allow_runs(int ndof_per_entity) {
+  (void)ndof_per_entity;
+  return g_plan_runs.load(std::memory_order_relaxed) != 0;
+}
+// which encoding of the dof lists a launch reads (the plan holds both): fp64 kernels are bandwidth-bound and
+// read the run table (P = 4: +6.8 %, P = 6: +3.9 %, P = 2: +2.7 %), fp32 kernels are latency-bound and read
+// the list (the expansion's extra barrier costs them 6 %): profiles/r02n_ab_run_tables.log
+template <typename T>
+inline bool plan_use_runs() {
   const int mode = g_plan_runs.load(std::memory_order_relaxed);
-  return mode == 2 ? 1 : (mode == 1 ? (ndof_per_entity <= 64) : 0);
+  return mode == 2 || (mode == 1 && sizeof(T) == 8);
 }
 std::atomic<int> g_plan_variant{-1};  // -1 = auto
 
@@ -135,11 +142,11 @@ int64_t plan_bytes(int P, int64_t ncell) {
 // fp32 build with 5 waves per SIMD (only instantiated for float)
 template <typename T, int P>
 hipError_t launch_plan_f32_5w(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int64_t ncell,
-                              int remap, hipStream_t s, bool ord) {
+                              int remap, hipStream_t s, bool ord, bool runs) {
   if constexpr (sizeof(T) == 4 && P <= 4)
-    return fus::launch_stiffness_plan<T, P, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s, ord);
+    return fus::launch_stiffness_plan<T, P, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, runs);
   else
-    return fus::launch_stiffness_plan<T, P, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord);
+    return fus::launch_stiffness_plan<T, P, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, runs);
 }
 
 template <typename T>
@@ -175,10 +182,10 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
-      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break; \
-      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break; \
-      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord); break; \
+      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break;   \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
+      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
+      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
     }                                                                                                     \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
@@ -205,7 +212,7 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord); \
+    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -229,7 +236,7 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -255,8 +262,8 @@ int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord) \
-             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord); \
+    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>()) \
+             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -283,8 +290,8 @@ int westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord) \
-             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord); \
+    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>()) \
+             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -326,7 +333,7 @@ int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const v
   if (!x || !consts || !y || !detJ || !ws || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   bool ord = false;
   if (!plan_check(ws, N, epb, nent, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord));
+  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>()));
 }
 
 }  // namespace

@@ -52,7 +52,7 @@ __global__ void __launch_bounds__(256)
     mass_plan_kernel(const T* __restrict__ x, const T* __restrict__ entity_constants, T* __restrict__ y,
                      const T* __restrict__ detJ, const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
                      const uint16_t* __restrict__ slot, int N, int epb, int64_t nent, uint32_t inv_n,
-                     const int32_t* __restrict__ order) {
+                     const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int M = N * epb;
   T* sx = reinterpret_cast<T*>(smem_raw);
@@ -63,14 +63,14 @@ __global__ void __launch_bounds__(256)
   const int64_t ent0 = batch * epb;
   const int64_t left = nent - ent0;
   const int valid = (int)((left < epb ? left : epb) * N);
-  __shared__ int s_runs[2 * kPlanMaxRuns];
   const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int64_t base = batch * (int64_t)M;
   const int32_t* ud = udofs + base;
+  const int32_t* rn = runs != nullptr ? runs + batch * (int64_t)(2 * kPlanMaxRuns) : nullptr;
 
   int32_t mydof[EPT];
-  const int rt = batch_dofs_issue<EPT, 256>(ud, M, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<EPT, 256>(ud, rn, M, nu_b, nr_b, tid, mydof);
   uint16_t sl[EPT];
   T w[EPT];
 #pragma unroll
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256)
       w[r] = detJ[base + ic] * entity_constants[ent0 + e];
     }
   }
-  batch_dofs_resolve<EPT, 256>(rt, nu_b, nr_b, tid, s_runs, mydof);
+  batch_dofs_resolve<EPT, 256, true>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(sy), mydof);
   T xv[EPT];
 #pragma unroll
   for (int r = 0; r < EPT; ++r) xv[r] = x[mydof[r]];
@@ -114,7 +114,7 @@ __global__ void __launch_bounds__(256)
 
 template <typename T>
 inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* detJ, const void* workspace, int N,
-                                   int epb, int64_t nent, hipStream_t stream, bool ordered = false) {
+                                   int epb, int64_t nent, hipStream_t stream, bool ordered = false, bool use_runs = false) {
   if (nent <= 0) return hipSuccess;
   const int M = N * epb;
   if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
@@ -124,7 +124,7 @@ inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* d
   const dim3 grid((unsigned)v.nbatch), block(256);
 #define FUS_MASS_LAUNCH(E)                                                                                        \
   hipLaunchKernelGGL((mass_plan_kernel<T, E>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \
-                     N, epb, nent, inv_n, ordered ? v.order : nullptr)
+                     N, epb, nent, inv_n, ordered ? v.order : nullptr, use_runs ? v.runs : nullptr)
   const int ept = (M + 255) / 256;
   if (ept <= 1) FUS_MASS_LAUNCH(1);
   else if (ept <= 2) FUS_MASS_LAUNCH(2);

@@ -13,12 +13,16 @@
 //
 // Workspace layout (caller-owned device buffer, fus_stiffness_plan_bytes() bytes, 256-B aligned):
 //   [0, 256)                        header (int64: magic, P, cpb, ncell, nbatch, entries/batch)
-//   nu     int32 [nbatch]           nu | (nr << 16): distinct dofs of the batch, and the number
-//                                   of runs when the dof list is stored run-length coded (0 = raw)
-//   udofs  int32 [nbatch][CPB*Nd]   raw: the sorted distinct dofs, first nu valid;
-//                                   runs: nr pairs (first dof of the run, slot of its first dof) --
-//                                   a structured numbering gives ~n^2 long runs per batch, so the
-//                                   list shrinks from 4 nu bytes to 8 nr bytes (P = 4: 4100 -> 200)
+//   nu     int32 [nbatch]           nu | (nr << 16): distinct dofs of the batch, and the number of
+//                                   runs in its run table (0 = the batch has none: too many, or no gain)
+//   udofs  int32 [nbatch][CPB*Nd]   the sorted distinct dofs, first nu valid (the rest padded)
+//   runs   int32 [nbatch][2*kPlanMaxRuns]  the SAME list run-length coded: nr pairs (first dof of the run,
+//                                   slot of its first dof) -- a structured numbering gives ~n^2 long
+//                                   runs per batch, so a kernel that reads the table instead of the
+//                                   list moves 8 nr bytes instead of 4 nu (P = 4: 4100 -> 200) and
+//                                   expands it in LDS.  Which of the two a launch reads is the host's
+//                                   choice per kernel (bandwidth-bound fp64 builds: the table; fp32
+//                                   builds, which are latency-bound: the list)
 //   slot   uint16[nbatch][CPB*Nd]   slot of (cell, local dof) = position in udofs[b]
 //   order  int32 [nent]             optional cell order: batch b holds the entities order[b*CPB ..]
 //                                   (set-up-time locality reordering WITHOUT moving G / detJ / constants:
@@ -36,7 +40,7 @@
 namespace fus {
 
 constexpr int64_t kPlanMagic = 0x46555350314c414eLL;  // "FUSP1LAN"
-constexpr int kPlanMaxRuns = 128;                      // run table of a batch: 2 ints per run, one per thread of a 256-thread workgroup
+constexpr int kPlanMaxRuns = 128;                      // runs of a batch: one per thread of (at least) two waves
 constexpr int kPlanHeaderBytes = 256;
 
 __host__ __device__ constexpr int next_pow2(int v) {
@@ -56,6 +60,7 @@ struct PlanView {
   int64_t entries;  // CPB * Nd
   int32_t* nu;
   int32_t* udofs;
+  int32_t* runs;
   uint16_t* slot;
   int32_t* order;
   int64_t bytes;
@@ -72,6 +77,8 @@ inline PlanView plan_view_generic(void* workspace, int N, int epb, int64_t nent)
   off += align256(v.nbatch * (int64_t)sizeof(int32_t));
   v.udofs = reinterpret_cast<int32_t*>(base + off);
   off += align256(v.nbatch * v.entries * (int64_t)sizeof(int32_t));
+  v.runs = reinterpret_cast<int32_t*>(base + off);
+  off += align256(v.nbatch * (int64_t)(2 * kPlanMaxRuns) * (int64_t)sizeof(int32_t));
   v.slot = reinterpret_cast<uint16_t*>(base + off);
   off += align256(v.nbatch * v.entries * (int64_t)sizeof(uint16_t));
   v.order = reinterpret_cast<int32_t*>(base + off);
@@ -90,8 +97,8 @@ inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
 template <int M2>
 __global__ void __launch_bounds__(256)
     plan_build_kernel(const int32_t* __restrict__ dofmap, int64_t nent, int N, int epb, int32_t* __restrict__ nu,
-                      int32_t* __restrict__ udofs, uint16_t* __restrict__ slot, int allow_runs,
-                      const int32_t* __restrict__ order) {
+                      int32_t* __restrict__ udofs, int32_t* __restrict__ runs, uint16_t* __restrict__ slot,
+                      int allow_runs, const int32_t* __restrict__ order) {
   constexpr int CH = M2 / 256;  // elements per thread in the scan phase
   __shared__ uint64_t keys[M2];
   __shared__ int cnt[256];
@@ -168,6 +175,7 @@ __global__ void __launch_bounds__(256)
   int r = excl >> 16;     // index of the first new run in this chunk
   if (tid == 255) nu[batch] = nu_b | ((use_runs ? nr_b : 0) << 16);
   int32_t* ud = udofs + batch * (int64_t)M;
+  int32_t* rn = runs + batch * (int64_t)(2 * kPlanMaxRuns);
   uint16_t* sl = slot + batch * (int64_t)M;
 #pragma unroll
   for (int c = 0; c < CH; ++c) {
@@ -179,10 +187,10 @@ __global__ void __launch_bounds__(256)
       const bool first = (i == 0) || (d != dp);
       const bool rstart = first && ((i == 0) || (d != dp + 1u));
       if (first) {
-        if (!use_runs) ud[s] = (int32_t)d;
+        ud[s] = (int32_t)d;
         if (use_runs && rstart) {
-          ud[2 * r] = (int32_t)d;
-          ud[2 * r + 1] = s;
+          rn[2 * r] = (int32_t)d;
+          rn[2 * r + 1] = s;
           ++r;
         }
         ++s;
@@ -190,9 +198,9 @@ __global__ void __launch_bounds__(256)
       sl[key & 0xffffu] = (uint16_t)(s - 1);
     }
   }
-  // raw lists: pad [nu, M) with the batch's first dof, so the apply kernels can issue their
-  // per-slot loads without first waiting for nu (entries beyond nu are loaded but never used)
-  if (!use_runs && valid > 0) {
+  // pad [nu, M) with the batch's first dof, so the apply kernels can issue their per-slot loads
+  // without first waiting for nu (entries beyond nu are loaded but never used)
+  if (valid > 0) {
     const int32_t d0 = (int32_t)(uint32_t)(keys[0] >> 16);
     for (int i = nu_b + tid; i < M; i += 256) ud[i] = d0;
   }
@@ -219,19 +227,19 @@ inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int ep
   }
   const dim3 grid((unsigned)v.nbatch), block(256);
   if (M <= 256)
-    hipLaunchKernelGGL((plan_build_kernel<256>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
+    hipLaunchKernelGGL((plan_build_kernel<256>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
                        allow_runs, order);
   else if (M <= 512)
-    hipLaunchKernelGGL((plan_build_kernel<512>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
+    hipLaunchKernelGGL((plan_build_kernel<512>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
                        allow_runs, order);
   else if (M <= 1024)
-    hipLaunchKernelGGL((plan_build_kernel<1024>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
+    hipLaunchKernelGGL((plan_build_kernel<1024>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
                        allow_runs, order);
   else if (M <= 2048)
-    hipLaunchKernelGGL((plan_build_kernel<2048>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
+    hipLaunchKernelGGL((plan_build_kernel<2048>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
                        allow_runs, order);
   else
-    hipLaunchKernelGGL((plan_build_kernel<4096>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.slot,
+    hipLaunchKernelGGL((plan_build_kernel<4096>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
                        allow_runs, order);
   return hipGetLastError();
 }
@@ -245,44 +253,53 @@ inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* 
 
 // Distinct dofs owned by this thread (slots tid, tid + BLOCK, ...), for both plan encodings.
 // Phase 1 (issue the global loads; call BEFORE the other HBM loads of the batch so that the x
-// gather, which depends on them, can be issued while those are still in flight):
+// gather, which depends on them, can be issued while those are still in flight).  Raw list: one
+// dof per slot.  Run-length list: thread t < nr holds run t = (first dof, first slot, end slot).
+struct RunWords {
+  int32_t d0, s0, s1;
+};
+// ``rn`` = the batch's run table, or nullptr when this launch reads the lists; ``nr_b`` is then forced to 0
+// by the caller (plan_runs_of) so that both phases take the list path.
+__device__ __forceinline__ int plan_runs_of(int packed, const int32_t* runs) { return runs != nullptr ? (packed >> 16) : 0; }
+
 template <int SPT, int BLOCK>
-__device__ __forceinline__ int batch_dofs_issue(const int32_t* __restrict__ ud, int M, int nr_b, int tid,
-                                                int32_t (&mydof)[SPT]) {
-  int rt = 0;
-  if (nr_b == 0) {  // raw list; the builder padded [nu, M) with a valid dof
+__device__ __forceinline__ RunWords batch_dofs_issue(const int32_t* __restrict__ ud, const int32_t* __restrict__ rn,
+                                                     int M, int nu_b, int nr_b, int tid, int32_t (&mydof)[SPT]) {
+  RunWords rw = {0, 0, 0};
+  if (nr_b == 0) {  // the list; the builder padded [nu, M) with a valid dof
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const int s = tid + r * BLOCK;
       mydof[r] = ud[s < M ? s : 0];
     }
-  } else if constexpr (BLOCK >= 2 * kPlanMaxRuns) {  // one run-table word per thread
-    rt = ud[tid < 2 * nr_b ? tid : 0];
+  } else if (tid < nr_b) {
+    rw.d0 = rn[2 * tid];
+    rw.s0 = rn[2 * tid + 1];
+    rw.s1 = (tid + 1 < nr_b) ? rn[2 * tid + 3] : nu_b;
   }
-  return rt;
+  return rw;
 }
-// Phase 2 (run-length plans only): stage the run table in LDS and locate each slot's run.
-template <int SPT, int BLOCK>
-__device__ __forceinline__ void batch_dofs_resolve(int rt, int nu_b, int nr_b, int tid, int* __restrict__ s_runs,
-                                                   int32_t (&mydof)[SPT]) {
+// Phase 2 (run-length plans only): the owners of the runs expand them into ``s_dofs`` (an LDS region
+// of >= 4 * nu_b bytes that nothing else uses until the next barrier of the caller -- every kernel
+// passes a cube that is written only after its gather), one barrier, every thread reads its slots.
+// A run is <= a few dozen consecutive dofs, so the serial expansion by <= 128 threads is a fraction of
+// a microsecond; what it buys is 8 bytes per RUN instead of 4 per DOF in HBM (P = 4: 4.1 kB -> 0.2 kB
+// per batch).
+// TRAIL: end with a barrier (for callers that overwrite the region before their next barrier).
+template <int SPT, int BLOCK, bool TRAIL = false>
+__device__ __forceinline__ void batch_dofs_resolve(const RunWords& rw, int nu_b, int nr_b, int tid,
+                                                   int32_t* __restrict__ s_dofs, int32_t (&mydof)[SPT]) {
   if (nr_b == 0) return;  // block-uniform
-  if constexpr (BLOCK < 2 * kPlanMaxRuns) return;  // such builds only accept raw plans (host-checked)
-  if (tid < 2 * kPlanMaxRuns) s_runs[tid] = rt;
+  if (tid < nr_b) {
+    for (int s = rw.s0; s < rw.s1; ++s) s_dofs[s] = rw.d0 + (s - rw.s0);
+  }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
-    const int sc = s < nu_b ? s : 0;
-    int lo = 0, hi = nr_b - 1;
-    while (lo < hi) {  // largest run whose first slot is <= sc
-      const int mid = (lo + hi + 1) >> 1;
-      if (s_runs[2 * mid + 1] <= sc)
-        lo = mid;
-      else
-        hi = mid - 1;
-    }
-    mydof[r] = s_runs[2 * lo] + (sc - s_runs[2 * lo + 1]);
+    mydof[r] = s_dofs[s < nu_b ? s : 0];
   }
+  if constexpr (TRAIL) __syncthreads();
 }
 
 template <typename T>

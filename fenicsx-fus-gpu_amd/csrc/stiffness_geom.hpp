@@ -137,7 +137,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                                const T* __restrict__ pts, const T* __restrict__ wts,
                                const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
                                const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell,
-                               const int32_t* __restrict__ order) {
+                               const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
   constexpr int VPT = (CPB * 24 + BLOCK - 1) / BLOCK;  // vertex coordinates staged per thread (1 for P >= 4)
@@ -149,7 +149,6 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
   __shared__ T sxy_own[ALIAS ? 1 : M];
-  __shared__ int s_runs[2 * kPlanMaxRuns];
   T* const sx = ALIAS ? sfy : sxy_own;
   T* const sy = ALIAS ? su : sxy_own;
 
@@ -163,8 +162,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const bool active = (lc < CPB) && (pos < ncell);
   const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
   const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
+  const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
 
   if (tid < n2) sD[tid] = dphi[tid];
   if (tid < n) {
@@ -173,7 +173,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   }
 
   int32_t mydof[SPT];
-  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
   int32_t vid[VPT];
   stage_vertex_ids<VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
   uint16_t sl[n];
@@ -184,7 +184,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
     coeff = cell_constants[cell];
   }
-  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
+  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
   stage_vertex_coords<T, VPT, BLOCK, CPB>(x_g, vid, tid, sX);
 
   // ---- gather x (as plan_gather_x) with the column geometry formed between its two barriers
@@ -261,14 +261,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, bool PREG>
 inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs,
                                              const T* pts, const T* wts, const void* workspace, const T* dphi,
-                                             int64_t ncell, hipStream_t stream, bool ordered = false) {
+                                             int64_t ncell, hipStream_t stream, bool ordered = false, bool use_runs = false) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
-                     ordered ? v.order : nullptr);
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr);
   return hipGetLastError();
 }
 

@@ -149,7 +149,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
                           const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
                           const T* __restrict__ dphi, int64_t ncell, int xcd_remap,
-                          const int32_t* __restrict__ order) {
+                          const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
   static_assert(GPRE >= 1 && GPRE <= n, "GPRE: slabs of G held in registers");
@@ -159,7 +159,6 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
   __shared__ T sxy_own[ALIAS ? 1 : M];
-  __shared__ int s_runs[2 * kPlanMaxRuns];
   T* const sx = ALIAS ? sfy : sxy_own;  // x values of the batch's distinct dofs
   T* const sy = ALIAS ? su : sxy_own;   // their y partial sums
 
@@ -172,14 +171,15 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const bool active = (lc < CPB) && (pos < ncell);
   const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
   const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
+  const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
 
   if (tid < n2) sD[tid] = dphi[tid];
 
   // ---- issue every HBM load of the batch up front ---------------------------------------------
   int32_t mydof[SPT];
-  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
   uint16_t sl[n];
   T g[GPRE][6];
   T coeff = T(0);
@@ -192,7 +192,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int ix = 0; ix < GPRE; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
     coeff = cell_constants[cell];
   }
-  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
+  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
 
   T u[n];
   plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sl, sx, su + lc * S + t, u);
@@ -237,14 +237,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, int GPRE = P + 1>
 inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* G, const void* workspace,
                                         const T* dphi, int64_t ncell, int xcd_remap, hipStream_t stream,
-                                        bool ordered = false) {
+                                        bool ordered = false, bool use_runs = false) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GPRE>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap,
-                     ordered ? v.order : nullptr);
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr);
   return hipGetLastError();
 }
 

@@ -37,7 +37,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                            T* __restrict__ b, T* __restrict__ m, const T* __restrict__ G, const T* __restrict__ detJ,
                            const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
                            const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell,
-                           const int32_t* __restrict__ order) {
+                           const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
   constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
   constexpr int S = lds_cell_stride<T, P>();
   constexpr int BLOCK = col_block_threads<P, CPB>();
@@ -51,7 +51,6 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
-  __shared__ int s_runs[2 * kPlanMaxRuns];
   T* const sxu = sfy;
   T* const sxv = sfz;
   T* const sm = sfy;
@@ -66,13 +65,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const bool active = (lc < CPB) && (pos < ncell);
   const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
   const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = packed >> 16;
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
+  const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
 
   if (tid < n2) sD[tid] = dphi[tid];
 
   int32_t mydof[SPT];
-  const int rt = batch_dofs_issue<SPT, BLOCK>(ud, M, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
   uint16_t sl[n];
   T g[GPRE][6];
   T dj[n];
@@ -94,7 +94,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     k3 = c3[cell];
     k4 = c4[cell];
   }
-  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, s_runs, mydof);
+  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
   {
     T xu[SPT], xv[SPT];
 #pragma unroll
@@ -207,7 +207,7 @@ __host__ __device__ constexpr int westervelt_g_ring() {
 template <typename T, int P, bool MASS = true>
 inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5,
                                          T* b, T* m, const T* G, const T* detJ, const void* workspace, const T* dphi,
-                                         int64_t ncell, hipStream_t stream, bool ordered = false) {
+                                         int64_t ncell, hipStream_t stream, bool ordered = false, bool use_runs = false) {
   constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
@@ -217,7 +217,7 @@ inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, co
   constexpr int RING = MASS ? westervelt_g_ring<P>() : ((P == 6 || P == 7 || P == 10) ? plan_g_ring<P>() : P + 1);
   hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, RING, MASS>), dim3((unsigned)pv.nbatch),
                      dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell,
-                     ordered ? pv.order : nullptr);
+                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr);
   return hipGetLastError();
 }
 

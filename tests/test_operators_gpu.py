@@ -642,3 +642,36 @@ def test_westervelt_stiffness_part_and_diagonal_mass(gpu, oracle_c, P, dtype):
     oracle_c.mass_apply(ones, c3, diag, pb["detJ"], mesh.dofmap)
     oracle_c.mass_apply(v, c3, full, pb["detJ"], mesh.dofmap)
     _check(diag * v, full, dtype, "M(c) x == diag(M(c) 1) x")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [2, 4, 6])
+def test_lists_and_run_tables_of_one_plan(gpu, oracle_c, P, dtype):
+    """A plan holds the distinct-dof lists AND their run-length tables; which one a launch reads is a
+    launch-time choice (auto: fp64 tables, fp32 lists).  All three settings on ONE cached plan, for the
+    stiffness, in-kernel-geometry and mass kernels."""
+    dev, ops = gpu
+    lib = pkg("_lib")
+    pb = build_problem(P, (5, 3, 4) if P < 6 else (3, 2, 3), dtype=dtype, perturb=0.16, seed=13)
+    mesh = pb["mesh"]
+    y_ref, m_ref = np.zeros(mesh.ndofs, dtype=dtype), np.zeros(mesh.ndofs, dtype=dtype)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    oracle_c.mass_apply(pb["x"], pb["cc"], m_ref, pb["detJ"], mesh.dofmap)
+    x, cc, G, dJ, dm = (dev.to_device(a) for a in (pb["x"], pb["cc"], pb["G"], pb["detJ"], mesh.dofmap))
+    op = ops.stiffness_operator(P, pb["D"].flatten(), dtype)
+    opg = ops.stiffness_operator(P, pb["D"].flatten(), dtype, geometry=(mesh.x_dofs, mesh.x_g, pb["pts"], pb["wts"]))
+    ops._PLANS.clear()
+    old_min, ops._MASS_PLAN_MIN_ENTRIES = ops._MASS_PLAN_MIN_ENTRIES, 1
+    try:
+        for mode in (1, 0, 2, 1):
+            lib.set_tuning(lib.TUNE_PLAN_RUNS, mode)  # the plan is built at the first apply (mode 1: tables built)
+            for fn, ref, what in ((lambda y: op(x, cc, y, G, dm), y_ref, "stiffness"), (lambda y: opg(x, cc, y, None, dm), y_ref, "geom"),
+                                  (lambda y: ops.mass_operator((P + 1) ** 3, dtype)(x, cc, y, dJ, dm), m_ref, "mass")):
+                y = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+                fn(y)
+                _check(y.copy_to_host(), ref, dtype, f"{what}, run-table mode {mode}, P={P}")
+        assert len(ops._PLANS._plans) == 1
+    finally:
+        ops._MASS_PLAN_MIN_ENTRIES = old_min
+        lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
+        ops._PLANS.clear()

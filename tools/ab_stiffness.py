@@ -7,7 +7,8 @@ N variants x M rounds on one workload; prints median / min per variant.
 ``cfg``:  ``plan``      shipped planned kernel, auto build
           ``plan:K``    planned kernel build K (FUS_TUNE_PLAN_VARIANT, csrc/fus_gpu.hip: 0 three cubes + own
                         buffer, 1 LDS-aliased, 2 LDS-aliased + G ring, 30 fp32 5-waves)
-          ``raw:K``     the same on a plan without run-length coded dof lists
+          ``raw:K``     the same reading the plan's dof lists instead of its run tables (FUS_TUNE_PLAN_RUNS = 0)
+          ``runs:K``    the same reading the run tables whatever the dtype (FUS_TUNE_PLAN_RUNS = 2)
           ``geom``      geometry formed in the kernel from the 8 vertices (no G stream)
           ``col:V``     plan-free column kernel, workgroup variant V (0: ~256 threads, 1: ~128)
 Add ``@x`` to a cfg to run it with the XCD remap on.  Two builds of the library are compared by
@@ -60,11 +61,8 @@ def main():
     pts, wts, _ = gll.tabulate_1d(a.degree, dt)
     op = ops.stiffness_operator(a.degree, pb["D"].flatten(), dt)
     opg = ops.stiffness_operator(a.degree, pb["D"].flatten(), dt, geometry=(xd, xg, pts, wts))
-    dm_raw = dm.clone()  # a second dofmap array => its own cached plan, built with runs disabled
-    lib.set_tuning(lib.TUNE_PLAN_RUNS, 0)
-    op(x, cc, y, G, dm_raw)
+    op(x, cc, y, G, dm)  # builds the plan (lists + run tables)
     torch.cuda.synchronize()
-    lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
 
     def parse(c):
         remap = c.endswith("@x")
@@ -85,7 +83,7 @@ def main():
                 fn = opg
             else:
                 lib.set_tuning(lib.TUNE_PLAN_VARIANT, k)
-                d_ = dm_raw if kind == "raw" else dm
+            lib.set_tuning(lib.TUNE_PLAN_RUNS, {"raw": 0, "runs": 2}.get(kind, 1))
             fn(x, cc, y, G, d_)
             if a.isolated:
                 evs = [(torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)) for _ in range(a.reps)]
@@ -106,6 +104,7 @@ def main():
             if rnd > 0:
                 times[name].append(tms)
     lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
+    lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
     bpc = bench.stiffness_bytes_per_cell(a.degree, np.dtype(dt).itemsize)
     print(f"P={a.degree} cells={a.cells}^3 dtype={a.dtype} order={a.order} dofs={mesh.ndofs} lib={lib.LIB_PATH} "
           f"timing={'isolated launches' if a.isolated else 'back-to-back launches'}")
