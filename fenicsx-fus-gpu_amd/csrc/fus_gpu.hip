@@ -479,6 +479,20 @@ int fus_mass_apply_f32(const float* x, const float* c, float* y, const float* de
   return mass_apply<float>(x, c, y, detJ, dofmap, N, nent, stream);
 }
 
+#define FUS_FACET(T, SUF)                                                                                        \
+  int fus_facet_terms_##SUF(T* y, const T* cA1, T sA1, const T* cA2, T sA2, const T* detJA, const int32_t* dmA,   \
+                            int64_t nentA, const T* xB, const T* cB, const T* detJB, const int32_t* dmB,          \
+                            int64_t nentB, int N, void* s) {                                                      \
+    if (nentA < 0 || nentB < 0 || N < 1 || !y) return FUS_ERR_INVALID_ARGUMENT;                                   \
+    if (nentA > 0 && (!cA1 || !detJA || !dmA)) return FUS_ERR_INVALID_ARGUMENT;                                   \
+    if (nentB > 0 && (!xB || !cB || !detJB || !dmB)) return FUS_ERR_INVALID_ARGUMENT;                             \
+    return hip_rc(fus::launch_facet_terms<T>(y, cA1, sA1, cA2, sA2, detJA, dmA, nentA, xB, cB, detJB, dmB, nentB, \
+                                             N, static_cast<hipStream_t>(s)));                                    \
+  }
+FUS_FACET(double, f64)
+FUS_FACET(float, f32)
+#undef FUS_FACET
+
 #define FUS_VEC(T, SUF)                                                                                       \
   int fus_axpy_##SUF(T alpha, const T* x, T* y, int64_t n, void* s) {                                         \
     return ew<T, fus::OpAxpy<T>, true, true>(x, y, y, n, fus::OpAxpy<T>{alpha}, s);                           \

@@ -43,6 +43,49 @@ inline hipError_t launch_mass(const T* x, const T* consts, T* y, const T* detJ, 
   return hipGetLastError();
 }
 
+// The boundary-facet terms of one RK4 stage in ONE launch.  The reference launches, per stage,
+//   mass(g, facet_coeff1) on the source facets (+ mass(dg, facet_coeff2_1) in the Westervelt solver) and
+//   mass(v_n, facet_coeff2) on the absorbing facets          cuda/demo_linear_box.py:546-549,
+//                                                            cuda/demo_nonlinear_bowl.py:633-641
+// where g / dg are the source value and its derivative filled into whole vectors.  Here:
+//   set A (x = 1):  y[dmA[e][i]] += (sA1 cA1[e] + sA2 cA2[e]) detJA[e][i]          (sA* = g(t), dg(t))
+//   set B:          y[dmB[e][i]] += xB[dmB[e][i]] cB[e] detJB[e][i]
+// a few thousand facets: launch-latency-bound, so one launch instead of three to five matters.
+template <typename T>
+__global__ void __launch_bounds__(256)
+    facet_terms_kernel(T* __restrict__ y, const T* __restrict__ cA1, T sA1, const T* __restrict__ cA2, T sA2,
+                       const T* __restrict__ detJA, const int32_t* __restrict__ dmA, int64_t totalA,
+                       const T* __restrict__ xB, const T* __restrict__ cB, const T* __restrict__ detJB,
+                       const int32_t* __restrict__ dmB, int64_t totalB, int N) {
+  const int64_t stride = (int64_t)gridDim.x * 256;
+  for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < totalA + totalB; idx += stride) {
+    if (idx < totalA) {
+      const int64_t e = idx / N;
+      T c = sA1 * cA1[e];
+      if (cA2 != nullptr) c += sA2 * cA2[e];
+      unsafeAtomicAdd(y + dmA[idx], c * detJA[idx]);
+    } else {
+      const int64_t j = idx - totalA;
+      const int64_t e = j / N;
+      const int32_t dof = dmB[j];
+      unsafeAtomicAdd(y + dof, xB[dof] * (cB[e] * detJB[j]));
+    }
+  }
+}
+
+template <typename T>
+inline hipError_t launch_facet_terms(T* y, const T* cA1, T sA1, const T* cA2, T sA2, const T* detJA, const int32_t* dmA,
+                                     int64_t nentA, const T* xB, const T* cB, const T* detJB, const int32_t* dmB,
+                                     int64_t nentB, int N, hipStream_t stream) {
+  const int64_t total = (nentA + nentB) * (int64_t)N;
+  if (total <= 0) return hipSuccess;
+  int64_t nblocks = (total + 255) / 256;
+  if (nblocks > 4096) nblocks = 4096;
+  hipLaunchKernelGGL((facet_terms_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, stream, y, cA1, sA1, cA2, sA2, detJA,
+                     dmA, nentA * (int64_t)N, xB, cB, detJB, dmB, nentB * (int64_t)N, N);
+  return hipGetLastError();
+}
+
 // Planned mass apply (batch plan of csrc/plan.hpp built for the same entity dofmap, N dofs per
 // entity, epb entities per batch).  Per batch: gather x once per distinct dof into LDS, every
 // (entity, local dof) entry multiplies and pre-reduces into LDS, one global atomic per distinct

@@ -222,12 +222,10 @@ class LinearSpectral3D:
         u_n = self.un if u_n is None else u_n
         v_n = self.ku if v_n is None else v_n
         gval = self.source_value(tn_or_t)
-        if self.fc1_work.numel():
-            ops.scale(gval, self.facet_coeff1, self.fc1_work)  # facet constants x g (x = 1 on the facets)
 
-        def facets():
-            self.mass_facet(self.g, self.fc1_work, self.b, self.detJ_f1, self.fdm1)
-            self.mass_facet(v_n, self.facet_coeff2, self.b, self.detJ_f2, self.fdm2)
+        def facets():  # M_f1(g c1) 1 + M_f2(c2) v_n in one launch (the reference fills g into a vector)
+            ops.facet_terms(self.b, (self.facet_coeff1, gval, None, 0.0, self.detJ_f1, self.fdm1),
+                            (v_n, self.facet_coeff2, self.detJ_f2, self.fdm2))
 
         if self.halo is None:
             self.stiff(u_n, self.cell_coeff2, self.b, self.G, self.dofmap)

@@ -142,9 +142,6 @@ class WesterveltSpectral3D:
         u_n = self.un if u_n is None else u_n
         v_n = self.ku if v_n is None else v_n  # ku == v_n
         gv, dgv = self.source_values(ts)
-        if self.fc_src.numel():
-            ops.scale(gv, self.fc1_1, self.fc_src)        # M_f1(fc1_1) g + M_f1(fc2_1) dg
-            ops.axpy[1, 1](dgv, self.fc2_1, self.fc_src)  #   = M_f1(fc1_1 g + fc2_1 dg) 1
 
         single = self.kappa is not None  # one gather: the cell pass is K(c3) w, w = u_n + kappa v_n
         w_n = self.w
@@ -155,9 +152,8 @@ class WesterveltSpectral3D:
             else:
                 self.cell_fused.stiffness_only(u_n, v_n, c3, c4, self.b, G_, dm_)
 
-        def facets():
-            self.mass_facet(self.g, self.fc_src, self.b, self.dF1, self.fdm1)  # g == 1
-            self.mass_facet(v_n, self.fc2_2, self.b, self.dF2, self.fdm2)
+        def facets():  # M_f1(fc1_1 g + fc2_1 dg) 1 + M_f2(fc2_2) v_n in one launch
+            ops.facet_terms(self.b, (self.fc1_1, gv, self.fc2_1, dgv, self.dF1, self.fdm1), (v_n, self.fc2_2, self.dF2, self.fdm2))
 
         percell = (self.cc3, self.cc4, self.G, self.dofmap)
         if self.in_kernel_geometry:

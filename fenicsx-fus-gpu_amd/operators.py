@@ -182,6 +182,42 @@ class _MassOperator(_Launchable):
 mass_operator = _MassOperator()
 
 
+def facet_terms(y, source, field):
+    """The boundary-facet terms of one RK4 stage in one launch (csrc/mass.hpp, ``fus_facet_terms_*``):
+
+        source = (c1, s1, c2, s2, detJ_f, facet_dofmap)   y += M_f(s1 c1 + s2 c2) 1      (c2 may be None)
+        field  = (x, c, detJ_f, facet_dofmap)             y += M_f(c) x
+
+    i.e. ``mass_operator(g, facet_coeff1, b, ...)`` [+ the dg term] and ``mass_operator(v_n, facet_coeff2, b, ...)``
+    of cuda/demo_linear_box.py:546-549 / cuda/demo_nonlinear_bowl.py:633-641 without filling g into a vector."""
+    c1, s1, c2, s2, dA, dmA = source
+    xB, cB, dB, dmB = field
+    dt = y.dtype if isinstance(y, torch.Tensor) else None
+    _req(y, dt, "y")
+    for name, t in (("c1", c1), ("detJ_source", dA), ("x", xB), ("c", cB), ("detJ_field", dB)):
+        _req(t, dt, name)
+    if c2 is not None:
+        _req(c2, dt, "c2")
+    _req(dmA, torch.int32, "source dofmap")
+    _req(dmB, torch.int32, "field dofmap")
+    nA, nB = dmA.shape[0], dmB.shape[0]
+    N = dmA.shape[1] if nA else (dmB.shape[1] if nB else 1)
+    if (nA and (dA.shape != dmA.shape or c1.numel() != nA)) or (nB and (dB.shape != dmB.shape or cB.numel() != nB)):
+        raise ValueError("facet arrays: detJ must have the dofmap's shape, one constant per facet")
+    if nA and nB and dmA.shape[1] != dmB.shape[1]:
+        raise ValueError("both facet sets must have the same number of dofs per facet")
+    if nA + nB == 0:
+        return
+    fn = getattr(_lib.load(), f"fus_facet_terms_{_lib.suffix(dt)}")
+    _lib.check(
+        fn(y.data_ptr(), c1.data_ptr() if nA else None, float(s1), c2.data_ptr() if (nA and c2 is not None) else None, float(s2),
+           dA.data_ptr() if nA else None, dmA.data_ptr() if nA else None, int(nA), xB.data_ptr() if nB else None,
+           cB.data_ptr() if nB else None, dB.data_ptr() if nB else None, dmB.data_ptr() if nB else None, int(nB), int(N),
+           _lib.stream_ptr()),
+        "fus_facet_terms",
+    )
+
+
 # ---------------------------------------------------------------------- stiffness
 class _StiffnessOperator(_Launchable):
     """Returned by ``stiffness_operator``; callable both ways."""

@@ -97,6 +97,21 @@ int fus_mass_apply_f32(const float* x, const float* entity_constants, float* y, 
                        const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, void* stream);
 
 /*
+ * The boundary-facet mass terms of one RK4 stage in one launch (ndof_per_entity = n^2 for both sets):
+ *   set A (source facets, x = 1):  y[dmA[e][i]] += (sA1 cA1[e] + sA2 cA2[e]) detJA[e][i]      cA2 may be NULL
+ *   set B (absorbing facets):      y[dmB[e][i]] += xB[dmB[e][i]] cB[e] detJB[e][i]
+ * replaces  mass_operator[..](g, facet_coeff1, b, detJ_f1, dofmap_f1) (+ the dg term of the Westervelt solver)
+ *      and  mass_operator[..](v_n, facet_coeff2, b, detJ_f2, dofmap_f2) with g, dg filled into vectors:
+ *           cuda/demo_linear_box.py:510-530,546-549; cuda/demo_nonlinear_bowl.py:560-595,633-641
+ */
+int fus_facet_terms_f64(double* y, const double* cA1, double sA1, const double* cA2, double sA2, const double* detJA,
+                        const int32_t* dmA, int64_t nentA, const double* xB, const double* cB, const double* detJB,
+                        const int32_t* dmB, int64_t nentB, int ndof_per_entity, void* stream);
+int fus_facet_terms_f32(float* y, const float* cA1, float sA1, const float* cA2, float sA2, const float* detJA,
+                        const int32_t* dmA, int64_t nentA, const float* xB, const float* cB, const float* detJB,
+                        const int32_t* dmB, int64_t nentB, int ndof_per_entity, void* stream);
+
+/*
  * Opt-in fast path for AFFINE cells (reported separately from the headline, whose
  * bytes contract is the general per-quadrature-point G): on an affine cell
  * G[c][q] = G[c][0] * (w_q / w_0), so the apply reads only the first 6-value record of each cell of

@@ -675,3 +675,40 @@ def test_lists_and_run_tables_of_one_plan(gpu, oracle_c, P, dtype):
         ops._MASS_PLAN_MIN_ENTRIES = old_min
         lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
         ops._PLANS.clear()
+
+
+@pytest.mark.parametrize("path", golden_files("ops_P4_"), ids=lambda p: p.split("/")[-1][:-4])
+def test_facet_terms_one_launch(gpu, oracle_c, path):
+    """fus_facet_terms_*: the stage's boundary-facet mass applies (source facets with x = g filled into a
+    vector -- and the dg term of the Westervelt solver -- plus the absorbing facets on v_n) in one launch,
+    against the oracle's mass operator applied the reference's way on the golden facet arrays."""
+    dev, ops = gpu
+    d = np.load(path)
+    dt = d["x"].dtype
+    fdm, dJf, fc = d["bfacet_dofmap"], d["ref_detJ_f"], d["facet_constants"]
+    half = fdm.shape[0] // 2
+    A, B = slice(0, half), slice(half, None)  # "source" and "absorbing" facet sets
+    g, dg = dt.type(0.37), dt.type(-1.9)
+    c2 = (0.5 + np.random.default_rng(2).random(half)).astype(dt)
+    v = d["x"]
+    ref = d["y0"].copy()
+    ones = np.ones_like(v)
+    oracle_c.mass_apply((g * ones).astype(dt), np.ascontiguousarray(fc[A]), ref, np.ascontiguousarray(dJf[A]), np.ascontiguousarray(fdm[A]))
+    oracle_c.mass_apply((dg * ones).astype(dt), c2, ref, np.ascontiguousarray(dJf[A]), np.ascontiguousarray(fdm[A]))
+    oracle_c.mass_apply(v, np.ascontiguousarray(fc[B]), ref, np.ascontiguousarray(dJf[B]), np.ascontiguousarray(fdm[B]))
+    y = dev.to_device(d["y0"])
+    td = lambda a: dev.to_device(np.ascontiguousarray(a))  # noqa: E731
+    ops.facet_terms(y, (td(fc[A]), float(g), td(c2), float(dg), td(dJf[A]), td(fdm[A])), (td(v), td(fc[B]), td(dJf[B]), td(fdm[B])))
+    _check(y.copy_to_host(), ref, dt, "facet terms (two source constants + field)")
+    # linear solver form: no second source constant; and an empty source set
+    ref = d["y0"].copy()
+    oracle_c.mass_apply((g * ones).astype(dt), np.ascontiguousarray(fc[A]), ref, np.ascontiguousarray(dJf[A]), np.ascontiguousarray(fdm[A]))
+    oracle_c.mass_apply(v, np.ascontiguousarray(fc[B]), ref, np.ascontiguousarray(dJf[B]), np.ascontiguousarray(fdm[B]))
+    y = dev.to_device(d["y0"])
+    ops.facet_terms(y, (td(fc[A]), float(g), None, 0.0, td(dJf[A]), td(fdm[A])), (td(v), td(fc[B]), td(dJf[B]), td(fdm[B])))
+    _check(y.copy_to_host(), ref, dt, "facet terms (linear solver form)")
+    y2 = dev.to_device(d["y0"])
+    ops.facet_terms(y2, (td(fc[:0]), 1.0, None, 0.0, td(dJf[:0]), td(fdm[:0])), (td(v), td(fc[B]), td(dJf[B]), td(fdm[B])))
+    ref2 = d["y0"].copy()
+    oracle_c.mass_apply(v, np.ascontiguousarray(fc[B]), ref2, np.ascontiguousarray(dJf[B]), np.ascontiguousarray(fdm[B]))
+    _check(y2.copy_to_host(), ref2, dt, "facet terms (no source facets on this rank)")
