@@ -163,9 +163,10 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
   // Builds (profiles/r01d_ab_alias_by_degree.log, r02*_ab_*.log; pinned by tests/test_resource_usage.py):
-  //   0  three LDS cubes + own x/y buffer           (P <= 3, 8, 9)
+  //   0  three LDS cubes + own x/y buffer           (P <= 3)
   //   1  LDS-aliased, whole G slab issued up front  (P = 4, 5: 4 workgroups per CU at P = 4)
-  //   2  LDS-aliased, ring of G slabs               (P = 6, 7, 10: registers are the binding limit there)
+  //   2  LDS-aliased, ring of G slabs               (P >= 6: registers are the binding limit there; P = 8 also
+  //                                                  drops the LDS padding to fit a third workgroup per CU)
   //   30 fp32, registers allow 5 waves per SIMD     (fp32, P <= 4)
   int pv = g_plan_variant.load(std::memory_order_relaxed);
   if (pv < 0) {
@@ -173,8 +174,8 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
       pv = 30;
     else {
       // measured per degree at ~10 M dofs (profiles/r02a_ab_builds_and_slp.log, r02b_ab_isolated_and_degrees.log,
-      // r02h_ab_degrees_3_9_10.log): the ring wins where it buys a workgroup per CU (P = 6, 7, 10)
-      static const int best[11] = {0, 0, 0, 0, 1, 1, 2, 2, 0, 0, 2};
+      // r02h_ab_degrees_3_9_10.log, r02r_ab_degrees_8_9_10.log): the ring wins where it buys a workgroup per CU
+      static const int best[11] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2};
       pv = best[P];
     }
   }
@@ -183,7 +184,7 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
       case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, true, fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, (PP != 8), fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
       case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
       default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
     }                                                                                                     \

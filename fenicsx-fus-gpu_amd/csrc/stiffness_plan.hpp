@@ -32,7 +32,7 @@ struct PlanShape {
 // waves per SIMD, <= 168: 3; tools/resource_usage.py), e.g. P = 6: 4 of 7 slabs, 156 VGPRs.
 template <int P>
 __host__ __device__ constexpr int plan_g_ring() {
-  constexpr int ring[11] = {1, 2, 3, 4, 3, 3, 4, 3, 5, 4, 6};
+  constexpr int ring[11] = {1, 2, 3, 4, 3, 3, 4, 3, 2, 1, 6};
   return ring[P];
 }
 // occupancy the ring build asks of the register allocator (P = 5: 130 VGPRs unforced, 2 over the step)
