@@ -214,7 +214,7 @@ inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, co
   constexpr int threads = col_block_threads<P, CPB>();
   constexpr int MINW = 1;
   // stiffness-only: the ring sizes of the stiffness kernel (its register profile + one more gather)
-  constexpr int RING = MASS ? westervelt_g_ring<P>() : ((P == 6 || P == 7 || P == 10) ? plan_g_ring<P>() : P + 1);
+  constexpr int RING = MASS ? westervelt_g_ring<P>() : (P >= 6 ? plan_g_ring<P>() : P + 1);
   hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, RING, MASS>), dim3((unsigned)pv.nbatch),
                      dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell,
                      ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr);
