@@ -447,6 +447,12 @@ int fus_plan_build(const int32_t* dofmap, int N, int entities_per_batch, int64_t
   return fus_plan_build_ordered(dofmap, nullptr, N, entities_per_batch, nent, workspace, workspace_bytes, stream);
 }
 
+int fus_plan_release(const void* workspace) {
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  g_plans.erase(workspace);
+  return FUS_OK;
+}
+
 int fus_plan_build_ordered(const int32_t* dofmap, const int32_t* entity_order, int N, int entities_per_batch,
                            int64_t nent, void* workspace, int64_t workspace_bytes, void* stream) {
   const int64_t need = fus_plan_bytes(N, entities_per_batch, nent);

@@ -103,9 +103,11 @@ class _PlanCache:
                     order = torch.argsort(mins, stable=True).to(torch.int32)
                     ws2 = build(order)
                     if distinct_dofs(ws2) < 0.97 * distinct_dofs(ws):
-                        ws, self.last_order = ws2, order
+                        ws, ws2, self.last_order = ws2, ws, order
+                    lib.fus_plan_release(ws2.data_ptr())  # the plan that was not kept
             if len(self._plans) >= self.capacity:  # bounded: drop the oldest plan
-                self._plans.pop(next(iter(self._plans)))
+                old = self._plans.pop(next(iter(self._plans)))
+                lib.fus_plan_release(old[0].data_ptr())
             # the entry holds the dofmap tensor itself: while a plan is cached its memory cannot be
             # freed and handed to another array with the same address / shape / version
             hit = (ws, epb, dofmap)
@@ -113,6 +115,9 @@ class _PlanCache:
         return hit[0], hit[1]
 
     def clear(self):
+        lib = _lib.load()
+        for ws, _, _ in self._plans.values():
+            lib.fus_plan_release(ws.data_ptr())
         self._plans.clear()
 
 

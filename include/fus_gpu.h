@@ -168,6 +168,8 @@ int fus_plan_build(const int32_t* entity_dofmap, int ndof_per_entity, int entiti
 int fus_plan_build_ordered(const int32_t* entity_dofmap, const int32_t* entity_order, int ndof_per_entity,
                            int entities_per_batch, int64_t nent, void* workspace, int64_t workspace_bytes,
                            void* stream);
+/* Forget a workspace (before freeing it): drops its entry of the registry the planned applies check. */
+int fus_plan_release(const void* workspace);
 int fus_mass_apply_planned_f64(const double* x, const double* entity_constants, double* y, const double* entity_detJ,
                                const void* workspace, int ndof_per_entity, int entities_per_batch, int64_t nent,
                                void* stream);
