@@ -37,13 +37,13 @@ inline int plan_allow_runs(int ndof_per_entity) {
   (void)ndof_per_entity;
   return g_plan_runs.load(std::memory_order_relaxed) != 0;
 }
-// which encoding of the dof lists a launch reads (the plan holds both): fp64 kernels are bandwidth-bound and
-// read the run table (P = 4: +6.8 %, P = 6: +3.9 %, P = 2: +2.7 %), fp32 kernels are latency-bound and read
-// the list (the expansion's extra barrier costs them 6 %): profiles/r02n_ab_run_tables.log
+// which encoding of the dof lists a launch reads (the plan holds both)
 template <typename T>
-inline bool plan_use_runs() {
+inline bool plan_use_runs(int ndof_per_entity) {
   const int mode = g_plan_runs.load(std::memory_order_relaxed);
-  return mode == 2 || (mode == 1 && sizeof(T) == 8);
+  // auto: fp64 always (+2..7 % at every degree); fp32 up to P = 4 (+6.5 % at P = 2 and 4, -12 % at P = 6,
+  // where the kernel is not bandwidth-bound): profiles/r02o_ab_run_tables.log, r02y_ab_fp32.log
+  return mode == 2 || (mode == 1 && (sizeof(T) == 8 || ndof_per_entity <= 125));
 }
 std::atomic<int> g_plan_variant{-1};  // -1 = auto
 
@@ -170,8 +170,8 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   //   30 fp32, registers allow 5 waves per SIMD     (fp32, P <= 4)
   int pv = g_plan_variant.load(std::memory_order_relaxed);
   if (pv < 0) {
-    if (sizeof(T) == 4 && P <= 4)
-      pv = 30;
+    if (sizeof(T) == 4)
+      pv = (P <= 4) ? 30 : 1;  // fp32: registers are not the limit, the whole G slab up front wins (r02y_ab_fp32.log)
     else {
       // measured per degree at ~10 M dofs (profiles/r02a_ab_builds_and_slp.log, r02b_ab_isolated_and_degrees.log,
       // r02h_ab_degrees_3_9_10.log, r02r_ab_degrees_8_9_10.log): the ring wins where it buys a workgroup per CU
@@ -183,10 +183,10 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
-      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, (PP != 8), fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
-      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
-      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>()); break; \
+      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break;   \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, (PP != 8), fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
+      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
+      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
     }                                                                                                     \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
@@ -213,7 +213,7 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
+    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -237,7 +237,7 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -263,8 +263,8 @@ int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>()) \
-             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
+    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))) \
+             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -291,8 +291,8 @@ int westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>()) \
-             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>()); \
+    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))) \
+             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -334,7 +334,7 @@ int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const v
   if (!x || !consts || !y || !detJ || !ws || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   bool ord = false;
   if (!plan_check(ws, N, epb, nent, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>()));
+  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>(N)));
 }
 
 }  // namespace

@@ -9,6 +9,7 @@
 #include <stdint.h>
 
 #include "plan.hpp"
+#include "stiffness_plan.hpp"
 
 namespace fus {
 
@@ -98,8 +99,8 @@ __global__ void __launch_bounds__(256)
                      const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   const int M = N * epb;
-  T* sx = reinterpret_cast<T*>(smem_raw);
-  T* sy = sx + M;
+  PlanAcc* sy = reinterpret_cast<PlanAcc*>(smem_raw);  // partial sums in double also for fp32 (stiffness_plan.hpp)
+  T* sx = reinterpret_cast<T*>(sy + M);
 
   const int tid = threadIdx.x;
   const int64_t batch = blockIdx.x;
@@ -138,20 +139,20 @@ __global__ void __launch_bounds__(256)
     const int s = tid + r * 256;
     if (s < nu_b) {
       sx[s] = xv[r];
-      sy[s] = T(0);
+      sy[s] = PlanAcc(0);
     }
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int i = tid + r * 256;
-    if (i < valid) lds_atomic_add(&sy[sl[r]], sx[sl[r]] * w[r]);
+    if (i < valid) lds_atomic_add(&sy[sl[r]], (PlanAcc)(sx[sl[r]] * w[r]));
   }
   __syncthreads();
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int s = tid + r * 256;
-    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sy[s]);
+    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], (T)sy[s]);
   }
 }
 
@@ -163,7 +164,7 @@ inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* d
   if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
   PlanView v = plan_view_generic(const_cast<void*>(workspace), N, epb, nent);
   const uint32_t inv_n = (uint32_t)((0x100000000ull + (uint64_t)N - 1) / (uint64_t)N);  // ceil(2^32 / N), N >= 2
-  const size_t lds = 2 * (size_t)M * sizeof(T);
+  const size_t lds = (size_t)M * (sizeof(PlanAcc) + sizeof(T));
   const dim3 grid((unsigned)v.nbatch), block(256);
 #define FUS_MASS_LAUNCH(E)                                                                                        \
   hipLaunchKernelGGL((mass_plan_kernel<T, E>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \

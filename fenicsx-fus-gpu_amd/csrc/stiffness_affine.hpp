@@ -23,9 +23,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
-  __shared__ T sxy_own[ALIAS ? 1 : M];
-  T* const sx = ALIAS ? sfy : sxy_own;
-  T* const sy = ALIAS ? su : sxy_own;
+  __shared__ PlanAcc sacc[PlanOwnAcc<T, ALIAS>::value ? M : 1];
+  T* const sx = ALIAS ? sfy : reinterpret_cast<T*>(sacc);  // x values of the batch's distinct dofs
+  PlanAcc* const sy = PlanOwnAcc<T, ALIAS>::value ? sacc : reinterpret_cast<PlanAcc*>(su);  // their y partial sums
 
   const int tid = threadIdx.x;
   const unsigned batch = blockIdx.x;

@@ -27,6 +27,13 @@ struct PlanShape {
   static constexpr int SPT = (M + BLOCK - 1) / BLOCK;      // distinct-dof slots per thread (upper bound)
 };
 
+// Type of the per-batch partial sums in LDS.  ds_add_f32 is several times slower than ds_add_f64 on
+// gfx950 (the fp32 planned kernel spent 28 % of its wave cycles stalled on LDS issue and ran 20 % faster
+// with the LDS atomics removed, the fp64 kernel not at all: profiles/r02x_lds_atomic_f32.log), so fp32
+// kernels also accumulate in double (which costs them nothing else: the sums are rounded to float once,
+// at the flush).
+typedef double PlanAcc;
+
 // Slabs of G a thread keeps resident in the ring build of stiffness_plan_kernel (GPRE below): the
 // largest ring that still reaches the next occupancy step of the register file (<= 128 VGPRs: 4
 // waves per SIMD, <= 168: 3; tools/resource_usage.py), e.g. P = 6: 4 of 7 slabs, 156 VGPRs.
@@ -91,7 +98,7 @@ template <typename T, int n, int n2>
 __device__ __forceinline__ void plan_backward(const T* __restrict__ dphi, const T* __restrict__ sD, int ty, int tz,
                                               bool active, const T (&fx)[n], const T* __restrict__ cf_y,
                                               const T* __restrict__ cf_z, const uint16_t (&sl)[n],
-                                              T* __restrict__ sy) {
+                                              PlanAcc* __restrict__ sy) {
   if (active) {
     T dyT[n], dzT[n];
 #pragma unroll
@@ -109,7 +116,7 @@ __device__ __forceinline__ void plan_backward(const T* __restrict__ dphi, const 
         acc += dyT[q] * cf_y[jx * n2 + q * n];
         acc += dzT[q] * cf_z[jx * n2 + q];
       }
-      lds_atomic_add(&sy[sl[jx]], acc);
+      lds_atomic_add(&sy[sl[jx]], (PlanAcc)acc);
     }
   }
   __syncthreads();
@@ -118,22 +125,30 @@ __device__ __forceinline__ void plan_backward(const T* __restrict__ dphi, const 
 // Phase D: one global atomic per distinct dof; consecutive lanes -> ascending, mostly contiguous addresses.
 template <typename T, int SPT, int BLOCK>
 __device__ __forceinline__ void plan_flush(T* __restrict__ y, const int32_t (&mydof)[SPT], int nu_b, int tid,
-                                           const T* __restrict__ sy) {
+                                           const PlanAcc* __restrict__ sy) {
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
-    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], sy[s]);
+    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], (T)sy[s]);
   }
 }
 
 template <typename T, int SPT, int BLOCK>
-__device__ __forceinline__ void plan_zero(T* __restrict__ sy, int nu_b, int tid) {
+__device__ __forceinline__ void plan_zero(PlanAcc* __restrict__ sy, int nu_b, int tid) {
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
-    if (s < nu_b) sy[s] = T(0);
+    if (s < nu_b) sy[s] = PlanAcc(0);
   }
 }
+
+// LDS regions of the x values (sx) and of the partial sums (sy).  fp64: ALIAS puts sx in the f_y cube and sy
+// in the u cube (no array of their own), otherwise both share one array of M values.  fp32: sy is double
+// and gets an array of its own (M doubles; sx shares it when not ALIAS).
+template <typename T, bool ALIAS>
+struct PlanOwnAcc {
+  static constexpr bool value = !ALIAS || sizeof(T) != sizeof(PlanAcc);
+};
 
 // General geometry.  GPRE = number of qx slabs of G a thread holds in registers: GPRE == n issues the
 // whole 48 n^3-byte slab of the cell up front (most bytes in flight; best while registers allow >= 4
@@ -158,9 +173,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
-  __shared__ T sxy_own[ALIAS ? 1 : M];
-  T* const sx = ALIAS ? sfy : sxy_own;  // x values of the batch's distinct dofs
-  T* const sy = ALIAS ? su : sxy_own;   // their y partial sums
+  __shared__ PlanAcc sacc[PlanOwnAcc<T, ALIAS>::value ? M : 1];
+  T* const sx = ALIAS ? sfy : reinterpret_cast<T*>(sacc);  // x values of the batch's distinct dofs
+  PlanAcc* const sy = PlanOwnAcc<T, ALIAS>::value ? sacc : reinterpret_cast<PlanAcc*>(su);  // their y partial sums
 
   const int tid = threadIdx.x;
   const unsigned batch = remap_block(blockIdx.x, gridDim.x, xcd_remap);

@@ -35,8 +35,13 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   __shared__ T sfz[CPB * S];
   T* const sxu = sfy;
   T* const sxv = sfz;
-  T* const sm = sfy;
-  T* const sb = su;
+  // partial sums are accumulated in double (PlanAcc, stiffness_plan.hpp): fp64 kernels alias them onto dead
+  // cubes, fp32 kernels get arrays of their own
+  constexpr bool OWN_ACC = sizeof(T) != sizeof(PlanAcc);
+  __shared__ PlanAcc sacc_b[OWN_ACC ? M : 1];
+  __shared__ PlanAcc sacc_m[(OWN_ACC && MASS) ? M : 1];
+  PlanAcc* const sm = OWN_ACC ? sacc_m : reinterpret_cast<PlanAcc*>(sfy);
+  PlanAcc* const sb = OWN_ACC ? sacc_b : reinterpret_cast<PlanAcc*>(su);
 
   const int tid = threadIdx.x;
   const unsigned batch = blockIdx.x;
@@ -122,7 +127,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     __syncthreads();
     if (active) {
 #pragma unroll
-      for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], madd[ix]);
+      for (int ix = 0; ix < n; ++ix) lds_atomic_add(&sm[sl[ix]], (PlanAcc)madd[ix]);
     }
     __syncthreads();
     plan_flush<T, SPT, BLOCK>(m, mydof, nu_b, tid, sm);
@@ -175,7 +180,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
         acc += dyT[q] * cf_y[jx * n2 + q * n];
         acc += dzT[q] * cf_z[jx * n2 + q];
       }
-      lds_atomic_add(&sb[sl[jx]], acc);
+      lds_atomic_add(&sb[sl[jx]], (PlanAcc)acc);
     }
   }
   __syncthreads();  // B4

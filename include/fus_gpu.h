@@ -52,7 +52,7 @@ int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_byt
 #define FUS_TUNE_XCD_REMAP 2         /* 1 = give each XCD a contiguous range of cell batches */
 #define FUS_TUNE_MASS_VARIANT 3
 #define FUS_TUNE_PLAN_VARIANT 4      /* planned stiffness kernel build: see csrc/fus_gpu.hip */
-#define FUS_TUNE_PLAN_RUNS 5         /* which encoding of a plan's dof lists the apply kernels read: 0 the lists, 2 the run tables, 1 auto (default: fp64 run tables, fp32 lists); 0 at plan build = no run tables are built */
+#define FUS_TUNE_PLAN_RUNS 5         /* which encoding of a plan's dof lists the apply kernels read: 0 the lists, 2 the run tables, 1 auto (default: fp64 run tables; fp32 run tables up to 125 dofs per entity, lists above); 0 at plan build = no run tables are built */
 int fus_set_tuning(int key, int value);
 int fus_get_tuning(int key);
 
