@@ -318,7 +318,7 @@ def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
     }
 
 
-def load_traffic(P, ncell, sha):
+def load_traffic(P, ncell, sha, dtype="f64"):
     """(per-launch HBM bytes, source) from the committed rocprofv3 PMC passes (profiles/), or
     (None, reason).  PMC counters cannot be read from inside the run, so this is a REPLAYED figure:
     it is reported only when the profiled library is the one loaded now (same hash), and the
@@ -329,7 +329,7 @@ def load_traffic(P, ncell, sha):
             t = json.load(f)
     except Exception:
         return None, "no profiles/traffic_latest.json"
-    if int(t.get("P", -1)) != P or int(t.get("ncell", -1)) != ncell:
+    if int(t.get("P", -1)) != P or int(t.get("ncell", -1)) != ncell or t.get("dtype", "f64") != dtype:
         return None, "profiled workload differs from this run"
     if t.get("lib_sha") != sha:
         return None, f"profiled library {t.get('lib_sha')} is not the loaded one ({sha})"
@@ -643,7 +643,7 @@ def main():
     bpc = geom_bytes_per_cell(P, T) if geom else stiffness_bytes_per_cell(P, T)
     achieved = mesh.ncells * bpc / (kern_ms * 1e-3) / 1e9
     sha = lib_sha()
-    traffic, traffic_source = (None, "not profiled for this mode") if geom else load_traffic(P, mesh.ncells, sha)
+    traffic, traffic_source = (None, "not profiled for this mode") if geom else load_traffic(P, mesh.ncells, sha, args.dtype)
     if geom:
         kname = "fus::stiffness_plan_geom_kernel"
     else:

@@ -65,7 +65,7 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     res["algorithmic_bytes_per_launch"] = ncell * bench["roofline"]["algorithmic_bytes_per_cell"]
     res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
     json.dump({"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
-               "source": f"profiles/{tag}_counters.json", "lib_sha": res["lib_sha"]},
+               "source": f"profiles/{tag}_counters.json", "lib_sha": res["lib_sha"], "dtype": bench.get("dtype", "f64")},
               open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
 if "TCC_EA0_ATOMIC_sum" in counters and stats:
     res["atomic_requests_per_s"] = counters["TCC_EA0_ATOMIC_sum"]["mean_per_launch"] / (stats["avg_ns"] * 1e-9)
