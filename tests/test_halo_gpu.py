@@ -280,3 +280,33 @@ def test_rccl_self_exchange(gpu, dtype, direct):
     torch.cuda.synchronize()
     assert np.allclose(buf.cpu().numpy(), ref, rtol=0, atol=1e-14 if dtype == np.float64 else 1e-6)
     fwd.close(), rev.close(), comm.close()
+
+
+def test_halo_create_rejects_bad_plans(gpu):
+    """fus_halo_create range-checks what the pack / unpack kernels would index with (the reference does not):
+    ghost positions outside the ghost block, owned indices outside [0, nlocal), neighbour ranks outside the
+    communicator, sizes that do not add up -- FUS_ERR_INVALID_ARGUMENT, nothing launched."""
+    import ctypes as C
+
+    scat, lib = pkg("scatterer"), pkg("_lib").load()
+    comm = scat.NativeComm(local=(next(_world_ids), 2, 0))
+
+    def create(nlocal, nghost, o_ranks, o_sizes, o_idx, g_ranks, g_sizes, g_idx):
+        arr = lambda a, dt: np.ascontiguousarray(a, dtype=dt)  # noqa: E731
+        keep = [arr(o_ranks, np.int32), arr(o_sizes, np.int64), arr(o_idx, np.int64), arr(g_ranks, np.int32), arr(g_sizes, np.int64), arr(g_idx, np.int64)]
+        h = C.c_void_p()
+        rc = lib.fus_halo_create(comm.handle, 8, nlocal, nghost, len(o_ranks), *(k.ctypes.data_as(C.c_void_p) for k in keep[:3]),
+                                 len(g_ranks), *(k.ctypes.data_as(C.c_void_p) for k in keep[3:]), C.byref(h))
+        if rc == 0:
+            lib.fus_halo_destroy(h)
+        return rc
+
+    ok = create(10, 3, [1], [3], [0, 1, 2], [1], [2], [4, 9])
+    assert ok == 0
+    assert create(10, 3, [1], [3], [0, 1, 3], [1], [2], [4, 9]) == -1     # ghost position 3 outside the ghost block
+    assert create(10, 3, [1], [3], [0, 1, 2], [1], [2], [4, 10]) == -1    # owned index 10 outside [0, nlocal)
+    assert create(10, 3, [2], [3], [0, 1, 2], [1], [2], [4, 9]) == -1     # rank 2 in a 2-rank world
+    assert create(10, 2, [1], [3], [0, 1, 2], [1], [2], [4, 9]) == -1     # more owner entries than ghosts
+    assert create(10, 3, [1], [-1], [0, 1, 2], [1], [2], [4, 9]) == -1    # negative size
+    assert lib.fus_halo_create(None, 8, 10, 3, 0, None, None, None, 0, None, None, None, C.byref(C.c_void_p())) == -1
+    comm.close()
