@@ -52,6 +52,8 @@ def _signatures():
         "fus_halo_forward_end": [_vp, _vp, _vp],
         "fus_halo_reverse_begin": [_vp, _vp, _vp],
         "fus_halo_reverse_end": [_vp, _vp, _vp],
+        "fus_halo_forward_begin_group": [_vp, _vp, _int, _vp],
+        "fus_halo_reverse_begin_group": [_vp, _vp, _int, _vp],
         "fus_halo_forward": [_vp, _vp, _vp],
         "fus_halo_reverse": [_vp, _vp, _vp],
     }

@@ -812,6 +812,20 @@ FUS_HALO_OP(fus_halo_reverse_begin, halo_begin, 1)
 FUS_HALO_OP(fus_halo_reverse_end, halo_end, 1)
 #undef FUS_HALO_OP
 
+#define FUS_HALO_GROUP(NAME, DIR)                                                                          \
+  int NAME(const fus_halo_t* halos, void* const* buffers, int n, void* stream) {                           \
+    if (n < 0 || n > 8 || (n > 0 && (!halos || !buffers))) return FUS_ERR_INVALID_ARGUMENT;                \
+    fus::Halo* hs[8];                                                                                      \
+    for (int k = 0; k < n; ++k) {                                                                          \
+      if (!halos[k] || !buffers[k]) return FUS_ERR_INVALID_ARGUMENT;                                       \
+      hs[k] = &halos[k]->h;                                                                                \
+    }                                                                                                      \
+    return fus::halo_begin_group(hs, buffers, n, static_cast<hipStream_t>(stream), DIR) == 0 ? FUS_OK : FUS_ERR_COMM; \
+  }
+FUS_HALO_GROUP(fus_halo_forward_begin_group, 0)
+FUS_HALO_GROUP(fus_halo_reverse_begin_group, 1)
+#undef FUS_HALO_GROUP
+
 int fus_halo_forward(fus_halo_t halo, void* buffer, void* stream) {
   const int rc = fus_halo_forward_begin(halo, buffer, stream);
   return rc != FUS_OK ? rc : fus_halo_forward_end(halo, buffer, stream);

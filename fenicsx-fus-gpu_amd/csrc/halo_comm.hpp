@@ -188,27 +188,20 @@ inline hipError_t halo_kernel_any(int eb, int mode, const void* in, void* out, c
                  : halo_launch<float>(mode, in, out, index, count, offset, s);
 }
 
-// One grouped neighbour exchange on the comm stream: send ``sside`` segments of ``sendbuf``, receive
-// ``rside`` segments into ``recvbuf``.
-inline int halo_exchange_rccl(Halo* h, const Side& sside, const char* sendbuf, const Side& rside, char* recvbuf) {
+// Post the receives and sends of one exchange (inside an open ncclGroup): send ``sside`` segments of
+// ``sendbuf``, receive ``rside`` segments into ``recvbuf``.
+inline ncclResult_t halo_post_rccl(Halo* h, const Side& sside, const char* sendbuf, const Side& rside, char* recvbuf) {
   Comm* c = h->comm;
   RcclApi& api = rccl();
   const ncclDataType_t dt = h->eb == 8 ? ncclFloat64 : ncclFloat32;
-  if (sside.total == 0 && rside.total == 0) return 0;
-  ncclResult_t r = api.GroupStart();
+  ncclResult_t r = ncclSuccess;
   for (size_t i = 0; r == ncclSuccess && i < rside.ranks.size(); ++i)
     if (rside.counts[i] > 0)
       r = api.Recv(recvbuf + rside.offsets[i] * h->eb, (size_t)rside.counts[i], dt, rside.ranks[i], c->nccl, c->stream);
   for (size_t i = 0; r == ncclSuccess && i < sside.ranks.size(); ++i)
     if (sside.counts[i] > 0)
       r = api.Send(sendbuf + sside.offsets[i] * h->eb, (size_t)sside.counts[i], dt, sside.ranks[i], c->nccl, c->stream);
-  ncclResult_t r2 = api.GroupEnd();
-  if (r == ncclSuccess) r = r2;
-  if (r != ncclSuccess) {
-    c->last_error = std::string("RCCL: ") + api.GetErrorString(r);
-    return -1;
-  }
-  return 0;
+  return r;
 }
 
 // LOCAL transport, receiver side: pull every incoming segment out of the peer's current message.
@@ -257,15 +250,6 @@ inline hipError_t halo_wait_readers_local(Halo* h, const Side& sside) {
   return hipSuccess;
 }
 
-// dir 0: forward (owners -> ghosts, overwrite)   cuda/scatterer.py:191-277
-// dir 1: reverse (ghosts -> owners, add)         cuda/scatterer.py:104-188
-inline int halo_begin(Halo* h, void* buffer, hipStream_t stream, int dir) {
-  Comm* c = h->comm;
-  if (h->owners.total == 0 && h->ghosts.total == 0) return 0;  // no neighbours: nothing to order, nothing to move
-  char* vec = static_cast<char*>(buffer);
-  char* ghost_block = vec + h->nlocal * h->eb;
-  const Side& sside = dir == 0 ? h->ghosts : h->owners;
-  const Side& rside = dir == 0 ? h->owners : h->ghosts;
 #define FUS_H(e_)                                \
   do {                                           \
     hipError_t _e = (e_);                        \
@@ -274,37 +258,89 @@ inline int halo_begin(Halo* h, void* buffer, hipStream_t stream, int dir) {
       return -1;                                 \
     }                                            \
   } while (0)
-  FUS_H(hipEventRecord(h->ev_ready, stream));
-  FUS_H(hipStreamWaitEvent(c->stream, h->ev_ready, 0));
-  if (c->kind == Comm::LOCAL) FUS_H(halo_wait_readers_local(h, sside));
-  // ---- pack
-  const char* sendbuf;
-  if (dir == 0) {
-    FUS_H(halo_kernel_any(h->eb, PACK, vec, h->buf_ghost, h->ghosts.idx_d, h->ghosts.total, 0, c->stream));
-    sendbuf = h->buf_ghost;
-  } else if (h->direct) {
-    sendbuf = ghost_block;
-  } else {
-    FUS_H(halo_kernel_any(h->eb, PACK, vec, h->buf_owner, h->owners.idx_d, h->owners.total, h->nlocal, c->stream));
-    sendbuf = h->buf_owner;
-  }
-  char* recvbuf = dir == 0 ? (h->direct ? ghost_block : h->buf_owner) : h->buf_ghost;
-  if (c->kind == Comm::RCCL) {
-    if (halo_exchange_rccl(h, sside, sendbuf, rside, recvbuf) != 0) return -1;
-    // ---- unpack
-    if (dir == 0) {
-      if (!h->direct)
-        FUS_H(halo_kernel_any(h->eb, UNPACK_SET, h->buf_owner, vec, h->owners.idx_d, h->owners.total, h->nlocal, c->stream));
-    } else {
-      FUS_H(halo_kernel_any(h->eb, UNPACK_ADD, h->buf_ghost, vec, h->ghosts.idx_d, h->ghosts.total, 0, c->stream));
+
+// dir 0: forward (owners -> ghosts, overwrite)   cuda/scatterer.py:191-277
+// dir 1: reverse (ghosts -> owners, add)         cuda/scatterer.py:104-188
+//
+// Begin ``nh`` exchanges (one per vector, halos of ONE communicator) as one unit: one event edge from the
+// caller's stream, the packs, ONE ncclGroup with every receive and send of every vector (two messages to
+// the same peer are matched in issue order, which is the same on both sides), the unpacks, each halo's
+// "done" event.  The RK4 stage forward-scatters two vectors (u_n, v_n): one RCCL launch instead of two.
+inline int halo_begin_group(Halo* const* hs, void* const* buffers, int nh, hipStream_t stream, int dir) {
+  if (nh <= 0) return 0;
+  Comm* c = hs[0]->comm;
+  bool any = false;
+  for (int k = 0; k < nh; ++k) {
+    if (hs[k]->comm != c) {
+      c->last_error = "halo group: the halos belong to different communicators";
+      return -1;
     }
-    FUS_H(hipEventRecord(h->ev_done, c->stream));
+    any = any || hs[k]->owners.total > 0 || hs[k]->ghosts.total > 0;
+  }
+  if (!any) return 0;  // no neighbours: nothing to order, nothing to move
+  FUS_H(hipEventRecord(hs[0]->ev_ready, stream));
+  FUS_H(hipStreamWaitEvent(c->stream, hs[0]->ev_ready, 0));
+  const char* sendbuf[8];
+  char* recvbuf[8];
+  if (nh > 8) {
+    c->last_error = "halo group: at most 8 vectors";
+    return -1;
+  }
+  // ---- pack
+  for (int k = 0; k < nh; ++k) {
+    Halo* h = hs[k];
+    char* vec = static_cast<char*>(buffers[k]);
+    char* ghost_block = vec + h->nlocal * h->eb;
+    const Side& sside = dir == 0 ? h->ghosts : h->owners;
+    if (c->kind == Comm::LOCAL) FUS_H(halo_wait_readers_local(h, sside));
+    if (dir == 0) {
+      FUS_H(halo_kernel_any(h->eb, PACK, vec, h->buf_ghost, h->ghosts.idx_d, h->ghosts.total, 0, c->stream));
+      sendbuf[k] = h->buf_ghost;
+    } else if (h->direct) {
+      sendbuf[k] = ghost_block;
+    } else {
+      FUS_H(halo_kernel_any(h->eb, PACK, vec, h->buf_owner, h->owners.idx_d, h->owners.total, h->nlocal, c->stream));
+      sendbuf[k] = h->buf_owner;
+    }
+    recvbuf[k] = dir == 0 ? (h->direct ? ghost_block : h->buf_owner) : h->buf_ghost;
+  }
+  if (c->kind == Comm::RCCL) {
+    RcclApi& api = rccl();
+    ncclResult_t r = api.GroupStart();
+    for (int k = 0; r == ncclSuccess && k < nh; ++k) {
+      Halo* h = hs[k];
+      r = halo_post_rccl(h, dir == 0 ? h->ghosts : h->owners, sendbuf[k], dir == 0 ? h->owners : h->ghosts, recvbuf[k]);
+    }
+    const ncclResult_t r2 = api.GroupEnd();
+    if (r == ncclSuccess) r = r2;
+    if (r != ncclSuccess) {
+      c->last_error = std::string("RCCL: ") + api.GetErrorString(r);
+      return -1;
+    }
+    // ---- unpack
+    for (int k = 0; k < nh; ++k) {
+      Halo* h = hs[k];
+      char* vec = static_cast<char*>(buffers[k]);
+      if (dir == 0) {
+        if (!h->direct)
+          FUS_H(halo_kernel_any(h->eb, UNPACK_SET, h->buf_owner, vec, h->owners.idx_d, h->owners.total, h->nlocal, c->stream));
+      } else {
+        FUS_H(halo_kernel_any(h->eb, UNPACK_ADD, h->buf_ghost, vec, h->ghosts.idx_d, h->ghosts.total, 0, c->stream));
+      }
+      FUS_H(hipEventRecord(h->ev_done, c->stream));
+    }
   } else {
-    h->cur_send = sendbuf;
-    h->cur_dir = dir;
-    FUS_H(hipEventRecord(h->ev_packed, c->stream));
+    for (int k = 0; k < nh; ++k) {
+      hs[k]->cur_send = sendbuf[k];
+      hs[k]->cur_dir = dir;
+      FUS_H(hipEventRecord(hs[k]->ev_packed, c->stream));
+    }
   }
   return 0;
+}
+
+inline int halo_begin(Halo* h, void* buffer, hipStream_t stream, int dir) {
+  return halo_begin_group(&h, &buffer, 1, stream, dir);
 }
 
 inline int halo_end(Halo* h, void* buffer, hipStream_t stream, int dir) {

@@ -363,6 +363,13 @@ int fus_halo_forward_begin(fus_halo_t halo, void* buffer, void* stream);
 int fus_halo_forward_end(fus_halo_t halo, void* buffer, void* stream);
 int fus_halo_reverse_begin(fus_halo_t halo, void* buffer, void* stream);
 int fus_halo_reverse_end(fus_halo_t halo, void* buffer, void* stream);
+/*
+ * Several vectors at once (the RK4 stage forward-scatters u_n and v_n; n <= 8, halos of one communicator, one
+ * per vector): one event edge and ONE RCCL group for all of them instead of one per vector.  Each is then
+ * completed with its own fus_halo_*_end.
+ */
+int fus_halo_forward_begin_group(const fus_halo_t* halos, void* const* buffers, int n, void* stream);
+int fus_halo_reverse_begin_group(const fus_halo_t* halos, void* const* buffers, int n, void* stream);
 int fus_halo_forward(fus_halo_t halo, void* buffer, void* stream); /* begin + end */
 int fus_halo_reverse(fus_halo_t halo, void* buffer, void* stream);
 

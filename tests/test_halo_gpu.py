@@ -310,3 +310,71 @@ def test_halo_create_rejects_bad_plans(gpu):
     assert create(10, 3, [1], [-1], [0, 1, 2], [1], [2], [4, 9]) == -1    # negative size
     assert lib.fus_halo_create(None, 8, 10, 3, 0, None, None, None, 0, None, None, None, C.byref(C.c_void_p())) == -1
     comm.close()
+
+
+def test_grouped_exchange_two_vectors_rccl_self(gpu):
+    """fus_halo_forward_begin_group / reverse: two vectors in ONE RCCL group (two messages to the same peer,
+    matched in issue order) in a 1-rank world that is its own neighbour; one direct halo, one permuted."""
+    torch = gpu
+    scat = pkg("scatterer")
+    comm = scat.NativeComm()
+    rng = np.random.default_rng(21)
+    N, ng = 3000, 700
+    g_idx = rng.choice(N, size=ng, replace=False)
+    mk = lambda o: ([o.astype(np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)],  # noqa: E731
+                    [g_idx.astype(np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)])
+    o_a, o_b = np.arange(ng), rng.permutation(ng)
+    fa, fb = scat.scatter_forward(comm, *mk(o_a), N, np.float64), scat.scatter_forward(comm, *mk(o_b), N, np.float64)
+    ra, rb = scat.scatter_reverse(comm, *mk(o_a), N, np.float64), scat.scatter_reverse(comm, *mk(o_b), N, np.float64)
+    dev = torch.device("cuda", 0)
+    ha, hb = rng.standard_normal(N + ng), rng.standard_normal(N + ng)
+    a, b = torch.from_numpy(ha).to(dev), torch.from_numpy(hb).to(dev)
+    for sc, vec, wk in scat.begin_all([(fa, a), (fb, b)]):
+        sc.end(vec, wk)
+    torch.cuda.synchronize()
+    ea, eb = ha.copy(), hb.copy()
+    ea[N + o_a] = ha[g_idx]
+    eb[N + o_b] = hb[g_idx]
+    assert np.array_equal(a.cpu().numpy(), ea) and np.array_equal(b.cpu().numpy(), eb)
+    a, b = torch.from_numpy(ha).to(dev), torch.from_numpy(hb).to(dev)
+    for sc, vec, wk in scat.begin_all([(ra, a), (rb, b)]):
+        sc.end(vec, wk)
+    torch.cuda.synchronize()
+    ea, eb = ha.copy(), hb.copy()
+    np.add.at(ea, g_idx, ha[N + o_a])
+    np.add.at(eb, g_idx, hb[N + o_b])
+    assert np.allclose(a.cpu().numpy(), ea, rtol=0, atol=1e-14) and np.allclose(b.cpu().numpy(), eb, rtol=0, atol=1e-14)
+
+
+@pytest.mark.parametrize("ghost_order", ["owner", 9])
+def test_grouped_exchange_two_vectors_in_process_ranks(gpu, ghost_order):
+    """The same through the in-process transport with 4 ranks: u and v forward-scattered as one unit per
+    rank (what an RK4 stage does), then both reverse-scattered as one unit."""
+    from oracle import oracle_np
+
+    torch = gpu
+    scat, boxmesh, utils = pkg("scatterer"), pkg("boxmesh"), pkg("utils")
+    grid, R = (2, 2, 1), 4
+    meshes = [boxmesh.BoxMesh(2, (4, 4, 2), grid=grid, rank=r, ghost_order=ghost_order) for r in range(R)]
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = next(_world_ids)
+    comms = [scat.NativeComm(local=(wid, R, r)) for r in range(R)]
+    mk = lambda fn: [fn(comms[r], od[r], gd[r], meshes[r].nlocal, np.float64) for r in range(R)]  # noqa: E731
+    fu, fv, ru, rv = mk(scat.scatter_forward), mk(scat.scatter_forward), mk(scat.scatter_reverse), mk(scat.scatter_reverse)
+    rng = np.random.default_rng(6)
+    hu, hv = [rng.standard_normal(m.ndofs) for m in meshes], [rng.standard_normal(m.ndofs) for m in meshes]
+    nl = [m.nlocal for m in meshes]
+    dev = torch.device("cuda", 0)
+    for closures, oracle in (((fu, fv), oracle_np.scatter_forward_all), ((ru, rv), oracle_np.scatter_reverse_all)):
+        eu, ev = [h.copy() for h in hu], [h.copy() for h in hv]
+        oracle(eu, od, gd, nl)
+        oracle(ev, od, gd, nl)
+        du, dv = [torch.from_numpy(h).to(dev) for h in hu], [torch.from_numpy(h).to(dev) for h in hv]
+        pending = [scat.begin_all([(closures[0][r], du[r]), (closures[1][r], dv[r])]) for r in range(R)]
+        for p in pending:
+            for sc, vec, wk in p:
+                sc.end(vec, wk)
+        torch.cuda.synchronize()
+        for r in range(R):
+            assert np.allclose(du[r].cpu().numpy(), eu[r], rtol=0, atol=1e-13)
+            assert np.allclose(dv[r].cpu().numpy(), ev[r], rtol=0, atol=1e-13)
