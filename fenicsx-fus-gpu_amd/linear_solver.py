@@ -91,7 +91,8 @@ def snap_time_step(mesh_size, P, speed_of_sound, source_frequency, domain_length
 class LinearSpectral3D:
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1500.0, density=1000.0,
                  source_frequency=0.5e6, source_amplitude=60000.0, comm=None, fused=True,
-                 source_time="tn", overlap=True, halo_kernels=None, affine="auto", in_kernel_geometry=False):
+                 source_time="tn", overlap=True, halo_kernels=None, affine="auto", in_kernel_geometry=False,
+                 halo_plan=None, defer_setup_exchange=False):
         self.mesh, self.P = mesh, mesh.P
         self.dt_np = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(float_type)
@@ -147,7 +148,9 @@ class LinearSpectral3D:
         if comm is not None and comm.size > 1:
             from .scatterer import HaloApply, scatter_forward
 
-            self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap, kernels=halo_kernels)
+            # halo_plan = (owners_data, ghosts_data) computed elsewhere (a host that drives several ranks from
+            # one process has no index exchange to run); default: exchanged over ``comm`` now
+            self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap, kernels=halo_kernels, plan=halo_plan)
             self.fwd_v = scatter_forward(comm, self.halo.owners_data, self.halo.ghosts_data, mesh.nlocal, ft, halo_kernels)
 
         z = lambda: torch.zeros(self.ndofs, dtype=self.tdt, device=dev)  # noqa: E731
@@ -159,12 +162,24 @@ class LinearSpectral3D:
         # ---- lumped mass: m = M(1/(rho c^2)) 1, reverse-scattered (:421-428) ---------------------
         ops.fill(1.0, self.g)
         self.mass_cell(self.g, self.cell_coeff1, self.m, self.detJ, self.dofmap)
-        if self.halo is not None:
-            self.halo.rev(self.m)
         self.minv = z()
+        # the reverse scatter of m: now, or (several ranks driven from one process: every rank must have
+        # posted before any completes) by the driver through setup_schedule()
+        self._setup = self.setup_schedule()
+        if not defer_setup_exchange:
+            for _ in self._setup:
+                pass
+        # g stays 1 for the fused path (source enters through scaled facet constants)
+
+    def setup_schedule(self):
+        """Generator: post the set-up exchange (reverse scatter of the lumped mass), yield, complete it and
+        form 1/m.  One rank per process exhausts it in the constructor."""
+        if self.halo is not None:
+            wk = self.halo.rev.begin(self.m)
+            yield "reverse"
+            self.halo.rev.end(self.m, wk)
         ops.fill(1.0, self.minv)
         ops.pointwise_divide(self.minv, self.m, self.minv)  # owned entries are what the fused kernel reads
-        # g stays 1 for the fused path (source enters through scaled facet constants)
 
     # ------------------------------------------------------------------------------------------
     def init(self):
@@ -200,8 +215,8 @@ class LinearSpectral3D:
             self.stiff(self.u_n, self.cell_coeff2, self.b, self.G, self.dofmap)
             facets()
         else:
-            self.halo.apply(self.u_n, self.cell_coeff2, self.b, self.G, self.dofmap,
-                            extra_forward=[(self.fwd_v, self.v_n)], boundary_terms=facets)
+            yield from self.halo.apply_schedule(self.u_n, self.cell_coeff2, self.b, self.G, self.dofmap,
+                                                extra_forward=[(self.fwd_v, self.v_n)], boundary_terms=facets)
         ops.pointwise_divide(self.b, self.m, self.kv)
         axpy(B_RUNGE[i] * dt, self.ku, self.u)
         axpy(B_RUNGE[i] * dt, self.kv, self.v)
@@ -231,12 +246,22 @@ class LinearSpectral3D:
             self.stiff(u_n, self.cell_coeff2, self.b, self.G, self.dofmap)
             facets()
         else:
-            self.halo.apply(u_n, self.cell_coeff2, self.b, self.G, self.dofmap,
-                            extra_forward=[(self.fwd_v, v_n)], boundary_terms=facets)
+            yield from self.halo.apply_schedule(u_n, self.cell_coeff2, self.b, self.G, self.dofmap,
+                                                extra_forward=[(self.fwd_v, v_n)], boundary_terms=facets)
 
     def rk4(self, start_time, final_time, dt, max_steps=None):
         """Advance from ``start_time`` to ``final_time`` (cuda/demo_linear_box.py:487-566).
         Returns ``(t, steps)``."""
+        gen = self.rk4_schedule(start_time, final_time, dt, max_steps)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as done:
+                return done.value
+
+    def rk4_schedule(self, start_time, final_time, dt, max_steps=None):
+        """``rk4`` as a generator that yields whenever this rank has posted halo exchanges (see
+        ``HaloApply.schedule``); its return value is ``(t, steps)``."""
         t, step = float(start_time), 0
         tf = float(final_time)
         if self.fused:
@@ -252,16 +277,16 @@ class LinearSpectral3D:
                 for i in range(4):
                     tn = t + C_RUNGE[i] * dt
                     if i == 0:
-                        self._operator_fused(tn if self.source_time == "tn" else t, self.u0, self.v0)
+                        yield from self._operator_fused(tn if self.source_time == "tn" else t, self.u0, self.v0)
                     else:
-                        self._operator_fused(tn if self.source_time == "tn" else t)
+                        yield from self._operator_fused(tn if self.source_time == "tn" else t)
                     last = i == 3
                     self._rk4_stage_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if i == 0 else 0))
             else:
                 ops.copy(self.u, self.u0)
                 ops.copy(self.v, self.v0)
                 for i in range(4):
-                    self._stage_reference(i, t, dt)
+                    yield from self._stage_reference(i, t, dt)
             t += dt
             step += 1
         if self.fused:

@@ -236,3 +236,60 @@ def test_driver_scripts_run(tmp_path):
     r = subprocess.run([sys.executable, os.path.join(pkgdir, "time_operators.py"), "--degree", "2", "--cells", "6",
                         "--nreps", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.count("Elapsed time") == 3, r.stdout + r.stderr
+
+
+def _lockstep(gens):
+    """Advance the generators of several in-process ranks together: each ``next`` runs a rank up to the point
+    where it has posted a set of halo exchanges; results are the generators' return values."""
+    out = [None] * len(gens)
+    live = list(enumerate(gens))
+    while live:
+        nxt = []
+        for i, g in live:
+            try:
+                next(g)
+                nxt.append((i, g))
+            except StopIteration as done:
+                out[i] = done.value
+        live = nxt
+    return out
+
+
+@pytest.mark.parametrize("fused", [True, False], ids=["fused", "reference-sequence"])
+@pytest.mark.parametrize("grid,ghost_order", [((2, 1, 1), "owner"), ((2, 2, 1), 5)], ids=["2ranks", "4ranks-permuted-ghosts"])
+def test_partitioned_linear_solver_async_transport_one_gpu(oracle_c, grid, ghost_order, fused):
+    """The linear RK4 solver on 2 / 4 ranks sharing cuda:0 in this process with the exchange issued from
+    C++ on its own stream (in-process transport, no host synchronisation): the set-up reverse scatter of the
+    lumped mass, per stage the grouped forward scatter of (u_n, v_n) | interior cells | boundary cells +
+    facet terms | reverse scatter of b | interior cells, stage kinds FIRST / LAST -- against the single-rank
+    oracle-side solver."""
+    import itertools
+
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, scat, utils = pkg("boxmesh"), pkg("linear_solver"), pkg("scatterer"), pkg("utils")
+    P, cells, L = 3, (4, 4, 4), 0.012
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r, length=L, ghost_order=ghost_order) for r in range(R)]
+    serial = boxmesh.BoxMesh(P, cells, length=L)
+    h = ls.time_step_parameters(serial, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = 7000 + 10 * R + int(fused)
+    solvers = [ls.LinearSpectral3D(meshes[r], np.float64, comm=scat.NativeComm(local=(wid, R, r)), fused=fused,
+                                   halo_plan=(od[r], gd[r]), defer_setup_exchange=True) for r in range(R)]
+    _lockstep([s._setup for s in solvers])
+    for s in solvers:
+        s.init()
+    res = _lockstep([s.rk4_schedule(0.0, tf, dt, max_steps=8) for s in solvers])
+    torch.cuda.synchronize()
+    assert all(r[1] == 8 for r in res)
+    u_ref, _ = rk4_oracle.solve(serial, 8, dt, oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 0
+    seen = np.zeros(u_ref.size, dtype=int)
+    for m, s in zip(meshes, solvers):
+        lex = m.global_lexicographic_ids()[: m.nlocal]
+        seen[lex] += 1
+        assert rel_l2(s.u_sol(), u_ref[lex]) < 1e-11
+    assert np.all(seen == 1)
