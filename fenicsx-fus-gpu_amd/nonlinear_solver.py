@@ -32,9 +32,10 @@ class WesterveltSpectral3D:
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
                  source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
                  attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False,
-                 in_kernel_geometry=False, uniform_ratio="auto"):
+                 in_kernel_geometry=False, uniform_ratio="auto", halo_plan=None, defer_setup_exchange=False):
         self.mesh, self.P = mesh, mesh.P
         ft = np.dtype(float_type)
+        self.tdt_np = ft
         self.tdt = _lib.torch_dtype(ft)
         self.c0, self.rho0, self.f0 = float(speed_of_sound), float(density), float(source_frequency)
         self.p0 = float(source_amplitude) if source_amplitude is not None else self.rho0 * self.c0 * 0.38557513826589934
@@ -76,7 +77,7 @@ class WesterveltSpectral3D:
         if comm is not None and comm.size > 1:
             from .scatterer import HaloApply, scatter_forward
 
-            self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap)
+            self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap, plan=halo_plan)
             mk = lambda: scatter_forward(comm, self.halo.owners_data, self.halo.ghosts_data, mesh.nlocal, ft)  # noqa: E731
             self.fwd_u, self.fwd_v, self.fwd_w = self.halo.fwd, mk(), mk()
             from .scatterer import scatter_reverse
@@ -89,8 +90,6 @@ class WesterveltSpectral3D:
         ops.fill(1.0, self.g)
         self.mass_cell(self.g, self.cc1, self.m0, self.detJ, self.dofmap)
         self.mass_facet(self.g, self.fc1_2, self.m0, self.dF2, self.fdm2)
-        if self.halo is not None:
-            self.halo.rev(self.m0)
 
         self.cell_fused = ops.westervelt_cell_operator(P, D.flatten(), ft)
         # fused mode: with GLL collocation the mass operator is diagonal, M(c) x = diag(M(c) 1) x, so the
@@ -100,9 +99,12 @@ class WesterveltSpectral3D:
         self.w2, self.w5 = z(), z()
         self.mass_cell(self.g, self.cc2, self.w2, self.detJ, self.dofmap)  # g == 1 here
         self.mass_cell(self.g, self.cc5, self.w5, self.detJ, self.dofmap)
-        if self.halo is not None:
-            self.halo.rev(self.w2)
-            self.halo.rev(self.w5)
+        # the reverse scatters of the three assembled diagonals (m0, w2, w5), as one grouped exchange: now, or
+        # by a driver that runs several ranks from one process (setup_schedule, see LinearSpectral3D)
+        self._setup = self.setup_schedule()
+        if not defer_setup_exchange:
+            for _ in self._setup:
+                pass
         # uniform ratio c4 / c3 (= delta / c^2: every homogeneous medium): K(c3) u + K(c4) v = K(c3)(u + kappa v),
         # so the cell pass is ONE plain stiffness apply on w = u_n + kappa v_n, which the vector kernel writes
         ratio = self.cc4 / self.cc3
@@ -122,6 +124,18 @@ class WesterveltSpectral3D:
             self.cell_fused_geom = ops.westervelt_cell_operator(P, D.flatten(), ft, geometry=(mesh.x_g, pts, wts))
             self.stiff_geom = ops.stiffness_operator(P, D.flatten(), ft, geometry=(self.x_dofs, mesh.x_g, pts, wts))
         self.fc_src = torch.zeros_like(self.fc1_1)  # per-stage source-facet constants (fused mode)
+
+    def setup_schedule(self):
+        if self.halo is not None:
+            from .scatterer import begin_all, scatter_reverse
+
+            mk = lambda: scatter_reverse(self.halo.comm, self.halo.owners_data, self.halo.ghosts_data, self.nlocal,  # noqa: E731
+                                         self.tdt_np)
+            self._rev_setup = [self.halo.rev, self.rev_m, mk()]
+            pending = begin_all(zip(self._rev_setup, (self.m0, self.w2, self.w5)))
+            yield "reverse"
+            for sc, vec, wk in pending:
+                sc.end(vec, wk)
 
     def init(self):
         for t in (self.u, self.v, self.ku, self.kv):
@@ -168,8 +182,8 @@ class WesterveltSpectral3D:
             cells(*percell)
             facets()
         else:
-            self.halo.run(cells, percell, [(self.fwd_u, w_n if single else u_n), (self.fwd_v, v_n)],
-                          [(self.halo.rev, self.b)], facets)
+            yield from self.halo.schedule(cells, percell, [(self.fwd_u, w_n if single else u_n), (self.fwd_v, v_n)],
+                                          [(self.halo.rev, self.b)], facets)
 
     def source_values(self, t):
         """g and dg/dt (cuda/demo_nonlinear_bowl.py:560-595)."""
@@ -223,6 +237,15 @@ class WesterveltSpectral3D:
         axpy(B_RUNGE[i] * dt, self.kv, self.v)
 
     def rk4(self, start_time, final_time, dt, max_steps=None):
+        gen = self.rk4_schedule(start_time, final_time, dt, max_steps)
+        while True:
+            try:
+                next(gen)
+            except StopIteration as done:
+                return done.value
+
+    def rk4_schedule(self, start_time, final_time, dt, max_steps=None):
+        """``rk4`` as a generator that yields whenever this rank has posted halo exchanges; returns ``(t, steps)``."""
         t, step, tf = float(start_time), 0, float(final_time)
         if self.fused:
             ops.fill(1.0, self.g)  # source enters through scaled facet constants
@@ -238,9 +261,9 @@ class WesterveltSpectral3D:
                 for i in range(4):
                     tn = t + C_RUNGE[i] * dt
                     if i == 0:
-                        self._operator_fused(tn if self.source_time == "tn" else t, self.u0, self.v0)
+                        yield from self._operator_fused(tn if self.source_time == "tn" else t, self.u0, self.v0)
                     else:
-                        self._operator_fused(tn if self.source_time == "tn" else t)
+                        yield from self._operator_fused(tn if self.source_time == "tn" else t)
                     last = i == 3
                     self._stage_vector_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if i == 0 else 0))
             else:

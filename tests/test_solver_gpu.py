@@ -293,3 +293,36 @@ def test_partitioned_linear_solver_async_transport_one_gpu(oracle_c, grid, ghost
         seen[lex] += 1
         assert rel_l2(s.u_sol(), u_ref[lex]) < 1e-11
     assert np.all(seen == 1)
+
+
+@pytest.mark.parametrize("geom", [False, True], ids=["general-G", "in-kernel-geometry"])
+def test_partitioned_westervelt_solver_async_transport_one_gpu(oracle_c, geom):
+    """The fused Westervelt solver (BASELINE config 5 shape) on 2 in-process ranks over the asynchronous
+    native transport: grouped set-up scatter of the three assembled diagonals (m0, w2, w5), per stage the
+    grouped forward scatter of (w, v_n) and the reverse scatter of b."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, nls, scat, utils = pkg("boxmesh"), pkg("linear_solver"), pkg("nonlinear_solver"), pkg("scatterer"), pkg("utils")
+    P, cells, L, grid = 3, (4, 3, 3), 0.012, (2, 1, 1)
+    R = 2
+    meshes = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r, length=L, ghost_order=3) for r in range(R)]
+    serial = boxmesh.BoxMesh(P, cells, length=L)
+    h = ls.time_step_parameters(serial, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = 7100 + int(geom)
+    solvers = [nls.WesterveltSpectral3D(meshes[r], np.float64, speed_of_sound=1500.0, source_frequency=0.5e6,
+                                        comm=scat.NativeComm(local=(wid, R, r)), fused=True, in_kernel_geometry=geom,
+                                        halo_plan=(od[r], gd[r]), defer_setup_exchange=True) for r in range(R)]
+    _lockstep([s._setup for s in solvers])
+    for s in solvers:
+        s.init()
+    res = _lockstep([s.rk4_schedule(0.0, tf, dt, max_steps=8) for s in solvers])
+    torch.cuda.synchronize()
+    assert all(r[1] == 8 for r in res)
+    u_ref, _ = rk4_oracle.solve_westervelt(serial, 8, dt, c0=1500.0, f0=0.5e6, oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 0
+    for m, s in zip(meshes, solvers):
+        lex = m.global_lexicographic_ids()[: m.nlocal]
+        assert rel_l2(s.u_sol(), u_ref[lex]) < 1e-11
