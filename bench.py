@@ -84,6 +84,24 @@ def emit(obj):
         os.write(_JSON_FD, line)
 
 
+def start_watchdog(seconds, rank):
+    """A rank that is still running after ``seconds`` is taken to be hung (a collective whose peer never
+    arrived, a kernel that never drains): say so and leave with a non-zero code, so that the launcher
+    stops the other ranks and the caller sees a failure instead of a job that never ends."""
+    import threading
+
+    if seconds <= 0:
+        return
+
+    def fire():
+        log(f"rank {rank}: watchdog: still running after {seconds:.0f} s -- giving up (FUS_BENCH_WATCHDOG_S=0 disables)")
+        os._exit(124)
+
+    t = threading.Timer(seconds, fire)
+    t.daemon = True
+    t.start()
+
+
 def host_cores():
     """Cores this process may actually use: affinity mask capped by the cgroup CPU quota."""
     n = len(os.sched_getaffinity(0))
@@ -202,6 +220,8 @@ def dry_run(args, rank, world):
     dist.init_process_group("gloo")
     if os.environ.get("FUS_BENCH_TEST_FAIL_RANK") == str(rank):  # launcher test: one rank dies after rendezvous
         os._exit(3)
+    if os.environ.get("FUS_BENCH_TEST_HANG_RANK") == str(rank):  # launcher test: one rank never reaches the collectives
+        time.sleep(3600)
     boxmesh, scat, utils = (fusgpu_loader.submodule(m) for m in ("boxmesh", "scatterer", "utils"))
     P = args.degree
     grid = boxmesh.default_grid(world)
@@ -455,6 +475,7 @@ def main():
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but the launcher started {world} ranks")
     protect_stdout()
+    start_watchdog(float(os.environ.get("FUS_BENCH_WATCHDOG_S", "1500")), rank)
     if args.dry_run:
         raise SystemExit(dry_run(args, rank, world))
 

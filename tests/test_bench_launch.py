@@ -60,6 +60,19 @@ def test_failed_rank_fails_the_launch():
     assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
 
 
+def test_hung_rank_ends_the_launch():
+    """A rank that never arrives at a collective: its watchdog leaves with a non-zero code, the launcher
+    stops the ranks waiting for it, nothing is printed."""
+    import time
+
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--dry-run", "--steps", "1", "--warmup", "0", "--degree", "2", "--cells", "2"],
+                       env=_env(FUS_BENCH_TEST_HANG_RANK="1", FUS_BENCH_WATCHDOG_S="20"), capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0 and time.time() - t0 < 300
+    assert "watchdog" in r.stderr
+    assert not [l for l in r.stdout.splitlines() if l.strip().startswith("{")]
+
+
 def test_gpus_mismatch_is_an_error():
     r = subprocess.run([sys.executable, BENCH, "--gpus", "4", "--dry-run"], env=_env(RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"),
                        capture_output=True, text=True, timeout=120)
