@@ -48,6 +48,12 @@ def stiffness_bytes_per_cell(P, T):
     return 6 * nd * T + 4 * nd + T * P**3 + 2 * T * P**3 + T
 
 
+def mass_bytes_per_cell(P, T):
+    """Algorithmic HBM bytes per cell of the cell mass apply: detJ + dofmap + x once + y RMW + constant."""
+    nd = (P + 1) ** 3
+    return nd * T + 4 * nd + 3 * T * P**3 + T
+
+
 def geom_bytes_per_cell(P, T):
     """Algorithmic HBM bytes per cell of the in-kernel-geometry apply: dofmap + x once + y RMW +
     constant + the cell's vertex ids (8 int32) + vertex coordinates, each vertex read once
@@ -338,6 +344,31 @@ def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
     }
 
 
+def cpu_baseline_mass(P, mesh, x, cc, detJ, reps=5):
+    """The oracle's cell mass apply (C restatement of numba-cpu/operators.py:19-68), serial as the
+    reference runs it, on the whole workload."""
+    from oracle import oracle_c
+
+    try:
+        oracle_c.build(native=True)
+        O = oracle_c.OracleLib(native=True)
+    except Exception as e:
+        log(f"native oracle build failed ({e}); using the portable build")
+        O = oracle_c.OracleLib()
+    y = np.zeros(mesh.ndofs)
+    O.mass_apply(x, cc, y, detJ, mesh.dofmap)
+    ts = []
+    for _ in range(reps):
+        y[:] = 0.0
+        t0 = time.perf_counter()
+        O.mass_apply(x, cc, y, detJ, mesh.dofmap)
+        ts.append(time.perf_counter() - t0)
+    t = float(np.mean(ts))
+    return {"value": mesh.ndofs / t, "unit": "DOF/s", "cores": 1, "kind": "port",
+            "sample": f"full workload ({mesh.ncells} cells), {reps} reps, one thread (the reference's njit loop is serial)",
+            "ms_per_apply": t * 1e3, "impl": "oracle/fus_oracle.c oracle_mass_apply_f64"}
+
+
 def load_traffic(P, ncell, sha, dtype="f64"):
     """(per-launch HBM bytes, source) from the committed rocprofv3 PMC passes (profiles/), or
     (None, reason).  PMC counters cannot be read from inside the run, so this is a REPLAYED figure:
@@ -448,8 +479,8 @@ def main():
     ap.add_argument("--variant", type=int, default=None)
     ap.add_argument("--xcd-remap", type=int, default=None)
     ap.add_argument("--no-plan", action="store_true", help="plan-free kernel (reads dofmap directly)")
-    ap.add_argument("--mode", default="stiffness", choices=["stiffness", "stiffness_geom", "rk4", "westervelt"],
-                    help="stiffness: the headline metric; stiffness_geom: the same apply with G formed in the kernel "
+    ap.add_argument("--mode", default="stiffness", choices=["stiffness", "stiffness_geom", "mass", "rk4", "westervelt"],
+                    help="stiffness: the headline metric; mass: the cell mass apply (SURVEY 8d's second operator line); stiffness_geom: the same apply with G formed in the kernel "
                          "from the cell vertices (own bytes contract, separate line); rk4 / westervelt: one full RK4 "
                          "time step of the linear / Westervelt solver per 'step' (auxiliary metrics)")
     ap.add_argument("--dry-run", action="store_true",
@@ -550,6 +581,15 @@ def main():
         log(f"setup {time.time() - t0:.1f}s: P={P} cells/GPU={mesh.ncells} local dofs={mesh.ndofs} "
             f"global dofs={mesh.ndofs_global} grid={grid} G={G_d.numel() * T / 1e6:.0f} MB")
     geom = args.mode == "stiffness_geom"
+    mass = args.mode == "mass"
+    if mass:
+        # the operand in G's position is the scaled Jacobian determinant detJ[ncell][n^3] (numba-cpu/operators.py:19-68)
+        del G_d
+        G_d = torch.empty((mesh.ncells, n**3), dtype=x_d.dtype, device=device)
+        pre.compute_scaled_jacobian_determinant_device(
+            G_d, (torch.from_numpy(mesh.x_dofs).to(device), torch.from_numpy(mesh.x_g).to(device)), mesh.ncells,
+            torch.from_numpy(dphi_g).to(device), torch.from_numpy(wts3).to(device))
+        torch.cuda.synchronize()
     if geom and use_dist:
         raise SystemExit("--mode stiffness_geom is a single-GPU line")
     if geom:
@@ -557,6 +597,8 @@ def main():
         op = ops.stiffness_operator(P, D.flatten(), dt, geometry=(mesh.x_dofs, mesh.x_g, pts, wts))
         del G_d
         G_d = None
+    elif mass:
+        op = ops.mass_operator(n**3, dt)
     else:
         op = ops.stiffness_operator(P, D.flatten(), dt)
 
@@ -574,7 +616,8 @@ def main():
 
     # set-up outside every step: batch plans, communicator bring-up
     if halo is None:
-        op.prepare(dm_d)
+        if hasattr(op, "prepare"):
+            op.prepare(dm_d)
     else:
         halo.prepare(x_d, cc_d, G_d, dm_d)
     for _ in range(args.warmup):
@@ -661,17 +704,19 @@ def main():
 
     ndofs_global = mesh.ndofs_global
     value = ndofs_global / (elapsed / args.steps)
-    bpc = geom_bytes_per_cell(P, T) if geom else stiffness_bytes_per_cell(P, T)
+    bpc = geom_bytes_per_cell(P, T) if geom else (mass_bytes_per_cell(P, T) if mass else stiffness_bytes_per_cell(P, T))
     achieved = mesh.ncells * bpc / (kern_ms * 1e-3) / 1e9
     sha = lib_sha()
-    traffic, traffic_source = (None, "not profiled for this mode") if geom else load_traffic(P, mesh.ncells, sha, args.dtype)
+    traffic, traffic_source = (None, "not profiled for this mode") if (geom or mass) else load_traffic(P, mesh.ncells, sha, args.dtype)
     if geom:
         kname = "fus::stiffness_plan_geom_kernel"
+    elif mass:
+        kname = "fus::mass_plan_kernel" if ops._USE_PLAN else "fus::mass_kernel"
     else:
         kname = "fus::stiffness_plan_kernel" if ops._USE_PLAN else "fus::stiffness_col_kernel"
 
     out = {
-        "metric": "stiffness_apply_in_kernel_geometry_dof_per_s" if geom else "stiffness_apply_dof_per_s",
+        "metric": "stiffness_apply_in_kernel_geometry_dof_per_s" if geom else ("mass_apply_dof_per_s" if mass else "stiffness_apply_dof_per_s"),
         "value": value,
         "unit": "DOF/s",
         "n_gpus": world,
@@ -684,15 +729,16 @@ def main():
         "dtype": args.dtype,
         "data": "synthetic",
         "config": {
-            "workload": f"stiffness apply y+=Kx, P={P} GLL hex box, {gcells[0]}x{gcells[1]}x{gcells[2]} perturbed cells, "
+            "workload": ("cell mass apply y+=Mx" if mass else "stiffness apply y+=Kx") + f", P={P} GLL hex box, {gcells[0]}x{gcells[1]}x{gcells[2]} perturbed cells, "
             f"{ndofs_global} dofs" + (" (BASELINE config 3)" if (world == 1 and P == 4 and args.cells == 54) else ""),
             "degree": P,
             "cells_per_gpu": mesh.ncells,
             "global_dofs": ndofs_global,
             "partition": f"{grid[0]}x{grid[1]}x{grid[2]} blocks",
             "geometry": ("formed in the kernel from the 8 vertices of each trilinear cell (no G array; NOT the headline "
-                         "bytes contract)") if geom else "general per-quadrature-point G[ncell][n^3][6] (no affine shortcut)",
-            "stiffness_kernel": "planned (batch plan, LDS pre-reduction)" if ops._USE_PLAN else f"plan-free variant {lib.get_tuning(lib.TUNE_STIFFNESS_VARIANT)}",
+                         "bytes contract)") if geom else ("scaled Jacobian determinant detJ[ncell][n^3]" if mass else
+                                                           "general per-quadrature-point G[ncell][n^3][6] (no affine shortcut)"),
+            "stiffness_kernel": None if mass else ("planned (batch plan, LDS pre-reduction)" if ops._USE_PLAN else f"plan-free variant {lib.get_tuning(lib.TUNE_STIFFNESS_VARIANT)}"),
             "xcd_remap": lib.get_tuning(lib.TUNE_XCD_REMAP),
             "halo": None if halo is None else ("overlapped" if halo.overlap else "sequential"),
             "halo_transport": None if halo is None else (
@@ -727,7 +773,13 @@ def main():
         },
     }
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and not geom:
+        if world == 1 and not args.no_cpu_baseline and mass:
+            try:
+                out["cpu_baseline"] = cpu_baseline_mass(P, mesh, x.astype(np.float64), cc.astype(np.float64), G_d.cpu().numpy().astype(np.float64))
+            except Exception as e:
+                log(f"cpu_baseline failed: {e!r}")
+                out["cpu_baseline"] = None
+        elif world == 1 and not args.no_cpu_baseline and not geom:
             G = G_d.cpu().numpy()  # the CPU baseline streams the same G the GPU did
             pb = dict(mesh=mesh, D=D, x=x.astype(np.float64), cc=cc.astype(np.float64), G=G.astype(np.float64))
             if dt != np.float64:

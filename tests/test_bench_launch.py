@@ -93,3 +93,17 @@ def test_distributed_code_path_on_one_gpu(halo):
     assert cfg["halo_exposed_ms"] is not None and out["value"] > 0
     assert ("libfusgpu" in cfg["halo_transport"]) == (halo == "native")
     assert out["roofline"]["kernel_ms"] > 0 and cfg["lib_sha"]
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("dist_path", [False, True])
+def test_mass_mode_line(dist_path):
+    """SURVEY 8d's second operator line (cell mass apply), alone and through the N > 1 code path."""
+    r = subprocess.run([sys.executable, BENCH, "--mode", "mass", "--steps", "5", "--warmup", "2", "--cells", "16"],
+                       env=_env(FUS_BENCH_FORCE_DIST="1" if dist_path else "0"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["metric"] == "mass_apply_dof_per_s" and out["value"] > 0
+    assert out["roofline"]["algorithmic_bytes_per_cell"] == 3044 and "mass" in out["roofline"]["kernel"]
+    if not dist_path:
+        assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["value"] > 0
