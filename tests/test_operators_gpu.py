@@ -712,3 +712,80 @@ def test_facet_terms_one_launch(gpu, oracle_c, path):
     ref2 = d["y0"].copy()
     oracle_c.mass_apply(v, np.ascontiguousarray(fc[B]), ref2, np.ascontiguousarray(dJf[B]), np.ascontiguousarray(fdm[B]))
     _check(y2.copy_to_host(), ref2, dt, "facet terms (no source facets on this rank)")
+
+
+@pytest.mark.timeout(900)
+def test_maximum_size_beyond_32bit_offsets(gpu, oracle_c):
+    """A single-GPU mesh whose G array has more than 2^31 ELEMENTS (P = 4, 143^3 = 2 924 207 perturbed
+    cells, 188 M dofs, G = 17.5 GB): element offsets into G, the dofmap and the plan no longer fit 32 bits.
+    Built on the device (the host mesh class would take minutes).  Checks: planned == plan-free; the whole
+    launch == the sum of two launches over the cell halves (the second addressed through an offset base
+    pointer, i.e. with small indices); the contribution of the LAST cells == the oracle; K 1 = 0; the
+    in-kernel-geometry operator == the general one."""
+    import torch
+
+    dev, ops = gpu
+    gll, pre = pkg("gll"), pkg("precompute")
+    if torch.cuda.get_device_properties(0).total_memory < 100e9:
+        pytest.skip("needs ~40 GB of device memory")
+    d = torch.device("cuda", 0)
+    P, N = 4, 143
+    n, nd, vd = P + 1, P * N + 1, N + 1
+    ncell, ndofs = N**3, (P * N + 1) ** 3
+    assert ncell * n**3 * 6 > 2**31
+    ar = torch.arange(N, device=d)
+    cx, cy, cz = (t.reshape(-1) for t in torch.meshgrid(ar, ar, ar, indexing="ij"))
+    li = torch.arange(n, device=d)
+    I, J, K_ = (t.reshape(-1) for t in torch.meshgrid(li, li, li, indexing="ij"))
+    dm = (((cx[:, None] * P + I[None, :]) * nd + (cy[:, None] * P + J[None, :])) * nd + (cz[:, None] * P + K_[None, :])).to(torch.int32)
+    xd = torch.empty((ncell, 8), dtype=torch.int32, device=d)
+    for v in range(8):  # basix P1 hex vertex order, as boxmesh.BoxMesh
+        bx, by, bz = v & 1, (v >> 1) & 1, (v >> 2) & 1
+        xd[:, v] = (((cx + bx) * vd + (cy + by)) * vd + (cz + bz)).to(torch.int32)
+    del cx, cy, cz
+    av = torch.arange(vd, device=d, dtype=torch.float64)
+    h = 1.0 / N
+    gen = torch.Generator(device=d).manual_seed(11)
+    xg = torch.stack([t.reshape(-1) for t in torch.meshgrid(av, av, av, indexing="ij")], dim=1) * h
+    xg += 0.16 * h * (2.0 * torch.rand(xg.shape, dtype=torch.float64, device=d, generator=gen) - 1.0)
+    pts, wts, D = gll.tabulate_1d(P, np.float64)
+    G = torch.empty((ncell, n**3, 6), dtype=torch.float64, device=d)
+    pre.compute_scaled_geometrical_factor_device(
+        G, (xd, xg), ncell, torch.from_numpy(pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))).to(d),
+        torch.from_numpy(gll.tensor_weights_3d(wts)).to(d))
+    cc = 1.0 + 0.25 * torch.randn(ncell, dtype=torch.float64, device=d, generator=gen)
+    x = torch.randn(ndofs, dtype=torch.float64, device=d, generator=gen)
+    op = ops.stiffness_operator(P, D.flatten(), np.float64)
+
+    def K(vec, a=0, b=ncell, plan=True):
+        ops.use_plan(plan)
+        try:
+            y = torch.zeros(ndofs, dtype=torch.float64, device=d)
+            op(vec, cc[a:b], y, G[a:b], dm[a:b])
+            return y
+        finally:
+            ops.use_plan(True)
+
+    y_full = K(x)
+    nrm = float(y_full.norm())
+    scale = float(y_full.abs().max())
+    assert np.isfinite(nrm) and nrm > 0
+    assert float((K(x, plan=False) - y_full).norm()) < 1e-12 * nrm
+    half = (ncell // 2 // 10) * 10 + 3  # not a multiple of the batch size
+    y_parts = K(x, 0, half)
+    y_parts += K(x, half, ncell)
+    assert float((y_parts - y_full).norm()) < 1e-12 * nrm
+    # the last cells (offsets beyond 2^31 elements in the full launch) against the oracle
+    ntail = 3000
+    y_tail = (y_full - K(x, 0, ncell - ntail)).cpu().numpy()
+    ref = np.zeros(ndofs)
+    oracle_c.stiffness_apply(P, D, x.cpu().numpy(), cc[ncell - ntail:].cpu().numpy(), ref, G[ncell - ntail:].cpu().numpy(),
+                             dm[ncell - ntail:].cpu().numpy(), threads=1)
+    assert np.max(np.abs(y_tail - ref)) < 1e-11 * scale
+    assert float(K(torch.full_like(x, 2.5)).abs().max()) < 1e-9 * scale  # K const = 0
+    del y_parts
+    opg = ops.stiffness_operator(P, D.flatten(), np.float64, geometry=(xd, xg, pts, wts))
+    y_g = torch.zeros_like(x)
+    opg(x, cc, y_g, None, dm)
+    assert float((y_g - y_full).norm()) < 1e-11 * nrm
+    ops._PLANS.clear()
