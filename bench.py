@@ -293,7 +293,7 @@ def make_comm(args, scat, world, device):
     return scat.TorchComm(), "torch (native communicator failed)"
 
 
-def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
+def cpu_baseline(P, pb, reps_omp=60, reps_serial=10):
     """Time the oracle (C restatement of numba-cpu/operators.py:71-227) on the host
     cores of this box, on the same mesh the GPU ran.  Reported, never shipped."""
     from oracle import oracle_c
@@ -318,8 +318,9 @@ def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
             best = (th, dtm)
     ncores = best[0]
     y = np.zeros(mesh.ndofs)
-    # bounded sample for the serial leg: a contiguous slab of cells
-    ns = min(mesh.ncells, 40000)
+    # bounded sample (a few seconds of CPU work in all): whole workload for both legs up to config-3 size,
+    # a contiguous slab of cells beyond
+    ns = min(mesh.ncells, 160000)
     res = {}
     for name, threads, ncell, reps in (("omp", ncores, mesh.ncells, reps_omp), ("serial", 1, ns, reps_serial)):
         O.stiffness_apply(P, pb["D"], pb["x"], pb["cc"][:ncell], y, pb["G"][:ncell], mesh.dofmap[:ncell], threads=threads)
@@ -330,7 +331,7 @@ def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
             O.stiffness_apply(P, pb["D"], pb["x"], pb["cc"][:ncell], y, pb["G"][:ncell], mesh.dofmap[:ncell], threads=threads)
             ts.append(time.perf_counter() - t0)
         dofs = ncell * P**3  # asymptotic dofs per cell, so slabs compare with the full box
-        res[name] = dict(t=float(np.mean(ts)), dof_per_s=dofs / float(np.mean(ts)), ncell=int(ncell), threads=int(threads))
+        res[name] = dict(t=float(np.mean(ts)), std=float(np.std(ts)), dof_per_s=dofs / float(np.mean(ts)), ncell=int(ncell), threads=int(threads))
     return {
         "value": res["omp"]["dof_per_s"],
         "unit": "DOF/s",
@@ -340,6 +341,7 @@ def cpu_baseline(P, pb, reps_omp=5, reps_serial=2):
         f"serial leg: {res['serial']['ncell']} cells x {reps_serial} reps",
         "single_thread_value": res["serial"]["dof_per_s"],
         "ms_per_apply": res["omp"]["t"] * 1e3,
+        "ms_per_apply_std": res["omp"]["std"] * 1e3,
         "impl": "oracle/fus_oracle.c (C restatement of numba-cpu/operators.py, -O3 -ffast-math -march=native)",
     }
 
