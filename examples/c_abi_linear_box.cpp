@@ -1,0 +1,419 @@
+// The demo_linear_box time loop as a plain C++ host over the C ABI (include/fus_gpu.h + libfusgpu.so +
+// the HIP runtime): no Python, no torch.  Class shape as the reference's C++ flavour,
+// cpp/common/Linear.hpp:52-348 (LinearSpectral3D: constructor = set-up, init(), rk4(start, final, dt),
+// u_sol()), with everything dolfinx does there (mesh, forms, assembly) replaced by a structured box
+// built here and by the library's device routines:
+//   geometry factors            fus_geometry_factors_*, fus_facet_jacobian_*   (numba-cpu/precompute.py)
+//   lumped mass  m = M(1/rho c^2) 1     fus_mass_apply_*                       (cuda/demo_linear_box.py:421-428)
+//   stage operator  b += K(-1/rho) u_n + facet terms                           (cuda/demo_linear_box.py:537-553)
+//        geometry 0: affine cells, constant-G fast path    fus_stiffness_apply_planned_affine_*
+//        geometry 1: general per-quadrature-point G        fus_stiffness_apply_planned_*
+//        geometry 2: G formed in the kernel                fus_stiffness_apply_planned_geom_*
+//   stage vector update (12 launches of the reference in one)   fus_rk4_stage_*  (cuda/demo_linear_box.py:491-563)
+// Time-step rule cuda/demo_linear_box.py:115-122; source window evaluated at the stage time as
+// cpp/common/Linear.hpp:179-187,317.
+//
+//   c_abi_linear_box P N steps geometry warp out.bin
+//     P degree, N cells per direction, steps RK4 steps (0: run to the final time), geometry 0|1|2,
+//     warp 0|1 (1: smooth non-affine displacement of the vertices), out.bin: final u as raw float64
+// tests/test_abi.py runs it and compares the field with the Python driver's (linear_solver.py).
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "fus_gpu.h"
+
+static void hip_ok(hipError_t e, int line) {
+  if (e != hipSuccess) throw std::runtime_error(std::string("HIP: ") + hipGetErrorString(e) + " at line " + std::to_string(line));
+}
+static void fus_ok(int rc, int line) {
+  if (rc != FUS_OK) throw std::runtime_error(std::string("fus: ") + fus_error_string(rc) + " at line " + std::to_string(line));
+}
+#define HIP_OK(e) hip_ok((e), __LINE__)
+#define FUS_CHECK(e) fus_ok((e), __LINE__)
+
+template <typename T>
+struct DeviceArray {  // caller-owned device buffer (the library never allocates per call)
+  T* p = nullptr;
+  size_t n = 0;
+  DeviceArray() = default;
+  explicit DeviceArray(size_t count) { alloc(count); }
+  explicit DeviceArray(const std::vector<T>& h) {
+    alloc(h.size());
+    if (n) HIP_OK(hipMemcpy(p, h.data(), n * sizeof(T), hipMemcpyHostToDevice));
+  }
+  DeviceArray(const DeviceArray&) = delete;
+  DeviceArray& operator=(const DeviceArray&) = delete;
+  ~DeviceArray() {
+    if (p) (void)hipFree(p);
+  }
+  void alloc(size_t count) {
+    n = count;
+    if (n) HIP_OK(hipMalloc(&p, n * sizeof(T)));
+  }
+  std::vector<T> host() const {
+    std::vector<T> h(n);
+    if (n) HIP_OK(hipMemcpy(h.data(), p, n * sizeof(T), hipMemcpyDeviceToHost));
+    return h;
+  }
+};
+
+// ---- GLL tables on [0, 1] (the reference takes them from basix: numba-cpu/time_operators.py:205-213)
+static double legendre(int P, double x, double* dp, double* d2p) {
+  double p0 = 1.0, p1 = x;
+  if (P == 0) p1 = 1.0;
+  for (int k = 2; k <= P; ++k) {
+    const double pk = ((2 * k - 1) * x * p1 - (k - 1) * p0) / k;
+    p0 = p1;
+    p1 = pk;
+  }
+  // P'_P and P''_P from the standard identities (x != +-1)
+  const double d = P * (p0 - x * p1) / (1.0 - x * x);
+  if (dp) *dp = d;
+  if (d2p) *d2p = (2.0 * x * d - P * (P + 1) * p1) / (1.0 - x * x);
+  return p1;
+}
+
+static void gll_tables(int P, std::vector<double>& pts, std::vector<double>& wts, std::vector<double>& D) {
+  const int n = P + 1;
+  std::vector<double> x(n);
+  x[0] = -1.0;
+  x[P] = 1.0;
+  for (int i = 1; i < P; ++i) {  // roots of P'_P: Newton from the Chebyshev-Gauss-Lobatto guess
+    double xi = -std::cos(M_PI * i / P);
+    for (int it = 0; it < 100; ++it) {
+      double dp, d2p;
+      legendre(P, xi, &dp, &d2p);
+      const double dx = dp / d2p;
+      xi -= dx;
+      if (std::fabs(dx) < 1e-16) break;
+    }
+    x[i] = xi;
+  }
+  pts.resize(n);
+  wts.resize(n);
+  for (int i = 0; i < n; ++i) {
+    const double lp = legendre(P, x[i], nullptr, nullptr);
+    pts[i] = 0.5 * (x[i] + 1.0);
+    wts[i] = 0.5 * 2.0 / (P * n * lp * lp);
+  }
+  for (int i = 0; i < n / 2; ++i) {  // symmetrise against round-off
+    const double p = 0.5 * (pts[i] + (1.0 - pts[P - i])), w = 0.5 * (wts[i] + wts[P - i]);
+    pts[i] = p;
+    pts[P - i] = 1.0 - p;
+    wts[i] = wts[P - i] = w;
+  }
+  if (n % 2) pts[P / 2] = 0.5;
+  // D[q][i] = l_i'(pts[q]), barycentric form, rows sum to zero
+  std::vector<double> bw(n, 1.0);
+  for (int i = 0; i < n; ++i)
+    for (int j = 0; j < n; ++j)
+      if (j != i) bw[i] /= (pts[i] - pts[j]);
+  D.assign(n * n, 0.0);
+  for (int q = 0; q < n; ++q) {
+    double s = 0.0;
+    for (int i = 0; i < n; ++i)
+      if (i != q) {
+        D[q * n + i] = (bw[i] / bw[q]) / (pts[q] - pts[i]);
+        s += D[q * n + i];
+      }
+    D[q * n + q] = -s;
+  }
+}
+
+// gradients of the 8 trilinear shape functions at points X[nq][3]: dphi[3][nq][8], vertex v = vx + 2 vy + 4 vz
+static void hex_p1_gradients(const std::vector<double>& X, int nq, double* out) {
+  for (int q = 0; q < nq; ++q)
+    for (int v = 0; v < 8; ++v) {
+      double f[3], df[3];
+      for (int a = 0; a < 3; ++a) {
+        const int b = (v >> a) & 1;
+        f[a] = b ? X[3 * q + a] : 1.0 - X[3 * q + a];
+        df[a] = b ? 1.0 : -1.0;
+      }
+      out[(0 * nq + q) * 8 + v] = df[0] * f[1] * f[2];
+      out[(1 * nq + q) * 8 + v] = f[0] * df[1] * f[2];
+      out[(2 * nq + q) * 8 + v] = f[0] * f[1] * df[2];
+    }
+}
+
+class LinearSpectral3D {
+public:
+  LinearSpectral3D(int P_, int N_, int geometry_, bool warp, double speedOfSound = 1500.0, double density = 1000.0,
+                   double sourceFrequency = 0.5e6, double sourceAmplitude = 60000.0, double length = 0.12)
+      : P(P_), N(N_), n(P_ + 1), Nd(n * n * n), geometry(geometry_), c0(speedOfSound), rho0(density),
+        freq(sourceFrequency), w0(2.0 * M_PI * sourceFrequency), p0(sourceAmplitude), L(length) {
+    if (geometry == 0 && warp) throw std::runtime_error("geometry 0 (affine fast path) needs unwarped cells");
+    const int M = P * N + 1, vd = N + 1;
+    ncell = (int64_t)N * N * N;
+    ndofs = (int64_t)M * M * M;
+    gll_tables(P, pts, wts, D);
+
+    // ---- mesh: lexicographic dofs (x slowest), P1 geometry, cells in lexicographic order --------------
+    const double h = L / N;
+    std::vector<double> xg((size_t)vd * vd * vd * 3);
+    for (int i = 0; i < vd; ++i)
+      for (int j = 0; j < vd; ++j)
+        for (int k = 0; k < vd; ++k) {
+          double* p = &xg[(((size_t)i * vd + j) * vd + k) * 3];
+          p[0] = i * h, p[1] = j * h, p[2] = k * h;
+          if (warp) {  // smooth, vanishing on x = 0 and x = L: the source / absorbing planes stay planes
+            const double s = std::sin(M_PI * p[0] / L);
+            const double y = p[1] / L, z = p[2] / L;
+            p[0] += 0.15 * h * s * std::sin(2.0 * M_PI * y) * std::cos(2.0 * M_PI * z);
+            p[1] += 0.10 * h * s * std::cos(2.0 * M_PI * z);
+            p[2] += 0.10 * h * s * std::sin(2.0 * M_PI * y);
+          }
+        }
+    std::vector<int32_t> dofmap((size_t)ncell * Nd), xdofs((size_t)ncell * 8), bd1, bd2, fdm1, fdm2;
+    mesh_size = 1e300;
+    for (int cx = 0; cx < N; ++cx)
+      for (int cy = 0; cy < N; ++cy)
+        for (int cz = 0; cz < N; ++cz) {
+          const int64_t c = ((int64_t)cx * N + cy) * N + cz;
+          for (int i = 0; i < n; ++i)
+            for (int j = 0; j < n; ++j)
+              for (int k = 0; k < n; ++k)
+                dofmap[c * Nd + (i * n + j) * n + k] = (int32_t)((((int64_t)cx * P + i) * M + (cy * P + j)) * M + (cz * P + k));
+          for (int v = 0; v < 8; ++v)
+            xdofs[c * 8 + v] = (int32_t)((((int64_t)cx + (v & 1)) * vd + (cy + ((v >> 1) & 1))) * vd + (cz + ((v >> 2) & 1)));
+          double diam = 0.0;  // dolfinx cpp.mesh.h: largest vertex-vertex distance
+          for (int a = 0; a < 8; ++a)
+            for (int b = a + 1; b < 8; ++b) {
+              const double* pa = &xg[(size_t)xdofs[c * 8 + a] * 3];
+              const double* pb = &xg[(size_t)xdofs[c * 8 + b] * 3];
+              diam = std::max(diam, std::sqrt((pa[0] - pb[0]) * (pa[0] - pb[0]) + (pa[1] - pb[1]) * (pa[1] - pb[1]) +
+                                              (pa[2] - pb[2]) * (pa[2] - pb[2])));
+            }
+          mesh_size = std::min(mesh_size, diam);
+          if (cx == 0 || cx == N - 1) {  // local facet 2 (x = 0): source; local facet 3 (x = 1): absorbing
+            for (int side = 0; side < 2; ++side) {
+              if ((side == 0 && cx != 0) || (side == 1 && cx != N - 1)) continue;
+              auto& bd = side == 0 ? bd1 : bd2;
+              auto& fd = side == 0 ? fdm1 : fdm2;
+              bd.push_back((int32_t)c);
+              bd.push_back(2 + side);
+              for (int j = 0; j < n; ++j)
+                for (int k = 0; k < n; ++k) fd.push_back(dofmap[c * Nd + (side * P * n + j) * n + k]);
+            }
+          }
+        }
+    nf1 = (int64_t)bd1.size() / 2;
+    nf2 = (int64_t)bd2.size() / 2;
+
+    // ---- tables for the device precompute -------------------------------------------------------------
+    std::vector<double> X3((size_t)Nd * 3), w3(Nd), w2(n * n), wratio(Nd);
+    for (int i = 0; i < n; ++i)
+      for (int j = 0; j < n; ++j)
+        for (int k = 0; k < n; ++k) {
+          const int q = (i * n + j) * n + k;
+          X3[3 * q] = pts[i], X3[3 * q + 1] = pts[j], X3[3 * q + 2] = pts[k];
+          w3[q] = wts[i] * wts[j] * wts[k];
+        }
+    for (int q = 0; q < Nd; ++q) wratio[q] = w3[q] / w3[0];
+    std::vector<double> dphi_g((size_t)3 * Nd * 8), dphi_f((size_t)6 * 3 * n * n * 8, 0.0);
+    hex_p1_gradients(X3, Nd, dphi_g.data());
+    const int fax[6] = {2, 1, 0, 0, 1, 2}, fside[6] = {0, 0, 0, 1, 1, 1};  // numba-cpu/precompute.py:49-59
+    for (int f = 0; f < 6; ++f) {
+      std::vector<double> Xf((size_t)n * n * 3);
+      int fr[2], m = 0;
+      for (int a = 0; a < 3; ++a)
+        if (a != fax[f]) fr[m++] = a;
+      for (int a = 0; a < n; ++a)
+        for (int b = 0; b < n; ++b) {
+          double* p = &Xf[(size_t)(a * n + b) * 3];
+          p[fr[0]] = pts[a], p[fr[1]] = pts[b], p[fax[f]] = fside[f];
+        }
+      hex_p1_gradients(Xf, n * n, &dphi_f[(size_t)f * 3 * n * n * 8]);
+    }
+    for (int a = 0; a < n; ++a)
+      for (int b = 0; b < n; ++b) w2[a * n + b] = wts[a] * wts[b];
+
+    // ---- device arrays (reference layouts) ----------------------------------------------------------
+    d_dofmap = new DeviceArray<int32_t>(dofmap);
+    d_xdofs = new DeviceArray<int32_t>(xdofs);
+    d_xg = new DeviceArray<double>(xg);
+    d_D = new DeviceArray<double>(D);
+    d_pts = new DeviceArray<double>(pts);
+    d_wts = new DeviceArray<double>(wts);
+    d_wratio = new DeviceArray<double>(wratio);
+    d_fdm1 = new DeviceArray<int32_t>(fdm1);
+    d_fdm2 = new DeviceArray<int32_t>(fdm2);
+    d_detJ_f1 = new DeviceArray<double>((size_t)nf1 * n * n);
+    d_detJ_f2 = new DeviceArray<double>((size_t)nf2 * n * n);
+    DeviceArray<double> d_dphi_g(dphi_g), d_dphi_f(dphi_f), d_w3(w3), d_w2(w2), d_detJ((size_t)ncell * Nd);
+    DeviceArray<int32_t> d_bd1(bd1), d_bd2(bd2);
+    if (geometry != 2) d_G = new DeviceArray<double>((size_t)ncell * Nd * 6);
+    FUS_CHECK(fus_geometry_factors_f64(d_xg->p, d_xdofs->p, d_dphi_g.p, d_w3.p, Nd, ncell, d_G ? d_G->p : nullptr, d_detJ.p, nullptr));
+    FUS_CHECK(fus_facet_jacobian_f64(d_xg->p, d_xdofs->p, d_bd1.p, d_dphi_f.p, d_w2.p, n * n, nf1, d_detJ_f1->p, nullptr));
+    FUS_CHECK(fus_facet_jacobian_f64(d_xg->p, d_xdofs->p, d_bd2.p, d_dphi_f.p, d_w2.p, n * n, nf2, d_detJ_f2->p, nullptr));
+
+    // material coefficients (homogeneous; cuda/demo_linear_box.py:336-345)
+    d_cell_coeff2 = new DeviceArray<double>(std::vector<double>((size_t)ncell, -1.0 / rho0));
+    d_facet_coeff1 = new DeviceArray<double>(std::vector<double>((size_t)nf1, 1.0 / rho0));
+    d_facet_coeff2 = new DeviceArray<double>(std::vector<double>((size_t)nf2, -1.0 / rho0 / c0));
+    DeviceArray<double> d_cell_coeff1(std::vector<double>((size_t)ncell, 1.0 / rho0 / c0 / c0));
+
+    // batch plan of the cell dofmap: built once, reused by every apply
+    const int64_t nbytes = fus_stiffness_plan_bytes(P, ncell);
+    if (nbytes < 0) FUS_CHECK((int)nbytes);
+    d_plan = new DeviceArray<unsigned char>((size_t)nbytes);
+    FUS_CHECK(fus_stiffness_plan_build(d_dofmap->p, P, ncell, d_plan->p, nbytes, nullptr));
+
+    for (DeviceArray<double>** v : {&d_u, &d_v, &d_u0, &d_v0, &d_un, &d_ku, &d_b, &d_minv}) {
+      *v = new DeviceArray<double>((size_t)ndofs);
+      FUS_CHECK(fus_fill_f64(0.0, (*v)->p, ndofs, nullptr));
+    }
+    // lumped mass m = M(1/(rho c^2)) 1, then 1/m (one rank: no reverse scatter)
+    DeviceArray<double> ones((size_t)ndofs), m((size_t)ndofs);
+    FUS_CHECK(fus_fill_f64(1.0, ones.p, ndofs, nullptr));
+    FUS_CHECK(fus_fill_f64(0.0, m.p, ndofs, nullptr));
+    FUS_CHECK(fus_mass_apply_f64(ones.p, d_cell_coeff1.p, m.p, d_detJ.p, d_dofmap->p, Nd, ncell, nullptr));
+    FUS_CHECK(fus_pointwise_divide_f64(ones.p, m.p, d_minv->p, ndofs, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+  }
+
+  ~LinearSpectral3D() {
+    if (d_plan) fus_plan_release(d_plan->p);
+    delete d_plan;
+    for (auto* a : {d_dofmap, d_xdofs, d_fdm1, d_fdm2}) delete a;
+    for (auto* a : {d_xg, d_D, d_pts, d_wts, d_wratio, d_detJ_f1, d_detJ_f2, d_G, d_cell_coeff2, d_facet_coeff1,
+                    d_facet_coeff2, d_u, d_v, d_u0, d_v0, d_un, d_ku, d_b, d_minv})
+      delete a;
+  }
+
+  /// u = v = 0 (cpp/common/Linear.hpp:154-157)
+  void init() {
+    FUS_CHECK(fus_fill_f64(0.0, d_u->p, ndofs, nullptr));
+    FUS_CHECK(fus_fill_f64(0.0, d_v->p, ndofs, nullptr));
+  }
+
+  /// window * p0 w0 / c0 * cos(w0 t) (cpp/common/Linear.hpp:179-187)
+  double source_value(double t) const {
+    const double period = 1.0 / freq, window_length = 4.0;
+    const double window = t < period * window_length ? 0.5 * (1.0 - std::cos(freq * M_PI * t / window_length)) : 1.0;
+    return window * p0 * w0 / c0 * std::cos(w0 * t);
+  }
+
+  /// cuda/demo_linear_box.py:115-122
+  void time_step(double& dt, double& final_time) const {
+    const double period = 1.0 / freq, CFL = 0.65;
+    dt = CFL * mesh_size / (c0 * P * P);
+    const int step_per_period = (int)(period / dt) + 1;
+    dt = period / step_per_period;
+    final_time = L / c0 + 2.0 / freq;
+  }
+
+  /// b += K(-1/rho) u_n + M_f1(g / rho) 1 + M_f2(-1/(rho c)) v_n
+  void apply_operator(double tn, const double* u_n, const double* v_n) {
+    switch (geometry) {
+      case 0:
+        FUS_CHECK(fus_stiffness_apply_planned_affine_f64(u_n, d_cell_coeff2->p, d_b->p, d_G->p, d_wratio->p, d_plan->p, d_D->p, P,
+                                                         ncell, nullptr));
+        break;
+      case 1:
+        FUS_CHECK(fus_stiffness_apply_planned_f64(u_n, d_cell_coeff2->p, d_b->p, d_G->p, d_plan->p, d_D->p, P, ncell, nullptr));
+        break;
+      default:
+        FUS_CHECK(fus_stiffness_apply_planned_geom_f64(u_n, d_cell_coeff2->p, d_b->p, d_xg->p, d_xdofs->p, d_pts->p, d_wts->p,
+                                                       d_plan->p, d_D->p, P, ncell, nullptr));
+    }
+    FUS_CHECK(fus_facet_terms_f64(d_b->p, d_facet_coeff1->p, source_value(tn), nullptr, 0.0, d_detJ_f1->p, d_fdm1->p, nf1, v_n,
+                                  d_facet_coeff2->p, d_detJ_f2->p, d_fdm2->p, nf2, n * n, nullptr));
+  }
+
+  /// Runge-Kutta 4 (cpp/common/Linear.hpp:241-348); returns the number of steps taken
+  int rk4(double startTime, double finalTime, double timeStep, int max_steps = 0) {
+    const double a_runge[4] = {0.0, 0.5, 0.5, 1.0}, b_runge[4] = {1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0};
+    const double c_runge[4] = {0.0, 0.5, 0.5, 1.0};
+    double t = startTime, dt = timeStep;
+    int step = 0;
+    // between steps the solution lives in (u0, v0) (stage kinds 2, 0, 0, 3 of fus_rk4_stage_*)
+    FUS_CHECK(fus_fill_f64(0.0, d_b->p, ndofs, nullptr));
+    FUS_CHECK(fus_copy_f64(d_u->p, d_u0->p, ndofs, nullptr));
+    FUS_CHECK(fus_copy_f64(d_v->p, d_v0->p, ndofs, nullptr));
+    while (t < finalTime && (max_steps == 0 || step < max_steps)) {
+      dt = std::min(dt, finalTime - t);
+      for (int i = 0; i < 4; ++i) {
+        const double tn = t + c_runge[i] * dt;
+        if (i == 0)
+          apply_operator(tn, d_u0->p, d_v0->p);
+        else
+          apply_operator(tn, d_un->p, d_ku->p);
+        const bool last = i == 3;
+        FUS_CHECK(fus_rk4_stage_f64(b_runge[i] * dt, last ? 0.0 : a_runge[i + 1] * dt, last ? 3 : (i == 0 ? 2 : 0), d_minv->p,
+                                    d_b->p, d_u->p, d_v->p, d_u0->p, d_v0->p, d_ku->p, d_un->p, ndofs, ndofs, nullptr));
+      }
+      t += dt;
+      ++step;
+    }
+    FUS_CHECK(fus_copy_f64(d_u0->p, d_u->p, ndofs, nullptr));
+    FUS_CHECK(fus_copy_f64(d_v0->p, d_v->p, ndofs, nullptr));
+    HIP_OK(hipDeviceSynchronize());
+    return step;
+  }
+
+  std::vector<double> u_sol() const { return d_u->host(); }
+
+  int P, N, n, Nd, geometry;
+  int64_t ncell = 0, ndofs = 0, nf1 = 0, nf2 = 0;
+  double c0, rho0, freq, w0, p0, L, mesh_size = 0.0;
+  std::vector<double> pts, wts, D;
+
+private:
+  DeviceArray<int32_t>*d_dofmap = nullptr, *d_xdofs = nullptr, *d_fdm1 = nullptr, *d_fdm2 = nullptr;
+  DeviceArray<double>*d_xg = nullptr, *d_D = nullptr, *d_pts = nullptr, *d_wts = nullptr, *d_wratio = nullptr;
+  DeviceArray<double>*d_detJ_f1 = nullptr, *d_detJ_f2 = nullptr, *d_G = nullptr;
+  DeviceArray<double>*d_cell_coeff2 = nullptr, *d_facet_coeff1 = nullptr, *d_facet_coeff2 = nullptr;
+  DeviceArray<double>*d_u = nullptr, *d_v = nullptr, *d_u0 = nullptr, *d_v0 = nullptr, *d_un = nullptr, *d_ku = nullptr;
+  DeviceArray<double>*d_b = nullptr, *d_minv = nullptr;
+  DeviceArray<unsigned char>* d_plan = nullptr;
+};
+
+int main(int argc, char** argv) {
+  if (argc < 6) {
+    std::fprintf(stderr, "usage: %s P N steps geometry(0 affine|1 general G|2 in-kernel) warp(0|1) [out.bin]\n", argv[0]);
+    return 64;
+  }
+  const int P = std::atoi(argv[1]), N = std::atoi(argv[2]), steps = std::atoi(argv[3]), geometry = std::atoi(argv[4]);
+  const bool warp = std::atoi(argv[5]) != 0;
+  try {
+    LinearSpectral3D solver(P, N, geometry, warp);
+    double dt, tf;
+    solver.time_step(dt, tf);
+    solver.init();
+    hipEvent_t e0, e1;
+    HIP_OK(hipEventCreate(&e0));
+    HIP_OK(hipEventCreate(&e1));
+    HIP_OK(hipEventRecord(e0, nullptr));
+    const int done = solver.rk4(0.0, tf, dt, steps);
+    HIP_OK(hipEventRecord(e1, nullptr));
+    HIP_OK(hipEventSynchronize(e1));
+    float ms = 0.f;
+    HIP_OK(hipEventElapsedTime(&ms, e0, e1));
+    const std::vector<double> u = solver.u_sol();
+    double amax = 0.0, sum = 0.0;
+    for (double x : u) {
+      if (!std::isfinite(x)) throw std::runtime_error("non-finite pressure");
+      amax = std::max(amax, std::fabs(x));
+      sum += x;
+    }
+    std::printf("P=%d N=%d dofs=%lld geometry=%d warp=%d dt=%.17g final_time=%.17g steps=%d ms_per_step=%.4f max|u|=%.17g sum(u)=%.17g\n",
+                P, N, (long long)solver.ndofs, geometry, (int)warp, dt, tf, done, ms / std::max(done, 1), amax, sum);
+    if (argc > 6) {
+      FILE* f = std::fopen(argv[6], "wb");
+      if (!f || std::fwrite(u.data(), sizeof(double), u.size(), f) != u.size()) throw std::runtime_error("cannot write the field");
+      std::fclose(f);
+    }
+  } catch (const std::exception& e) {
+    std::fprintf(stderr, "c_abi_linear_box: %s\n", e.what());
+    return 1;
+  }
+  return 0;
+}

@@ -128,3 +128,54 @@ def test_c_abi_golden_plain_cpp_host():
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "ops_P4_2x2x2_pert_float64.bin")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C_ABI_GOLDEN_OK" in r.stdout, r.stdout + r.stderr
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("geometry,warp", [(0, 0), (1, 0), (1, 1), (2, 1)], ids=["affine", "generalG", "generalG-warped", "in-kernel-warped"])
+def test_c_abi_linear_box_plain_cpp_host(tmp_path, geometry, warp):
+    """examples/c_abi_linear_box.cpp: the demo_linear_box RK4 loop as a C++ host over the C ABI alone (class shape
+    of cpp/common/Linear.hpp), on a box it builds itself (GLL tables, mesh, facets, time-step rule in C++).
+    Same pressure field as the Python driver (linear_solver.LinearSpectral3D) on the same box."""
+    import subprocess
+    import sys
+
+    import numpy as np
+
+    sys.path.insert(0, ROOT)
+    import fusgpu_loader
+
+    exe = os.path.join(ROOT, "examples", "c_abi_linear_box")
+    if not os.path.exists(exe):
+        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    P, N, steps, L = 4, 6, 30, 0.12
+    out = str(tmp_path / "u.bin")
+    r = subprocess.run([exe, str(P), str(N), str(steps), str(geometry), str(warp), out], capture_output=True, text=True, timeout=300)
+    assert r.returncode == 0, r.stdout + r.stderr
+    u_cpp = np.fromfile(out, dtype=np.float64)
+
+    boxmesh, ls = fusgpu_loader.submodule("boxmesh"), fusgpu_loader.submodule("linear_solver")
+    h = L / N
+
+    def warp_fn(xg):  # the displacement examples/c_abi_linear_box.cpp applies
+        o = xg.copy()
+        s = np.sin(np.pi * xg[:, 0] / L)
+        y, z = xg[:, 1] / L, xg[:, 2] / L
+        o[:, 0] += 0.15 * h * s * np.sin(2 * np.pi * y) * np.cos(2 * np.pi * z)
+        o[:, 1] += 0.10 * h * s * np.cos(2 * np.pi * z)
+        o[:, 2] += 0.10 * h * s * np.sin(2 * np.pi * y)
+        return o
+
+    mesh = boxmesh.BoxMesh(P, N, length=L, warp=warp_fn if warp else None)
+    solver = ls.LinearSpectral3D(mesh, np.float64, in_kernel_geometry=(geometry == 2))
+    assert solver.affine == (warp == 0)
+    hmin = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(hmin, P, 1500.0, 0.5e6, L)
+    dt_cpp = float(r.stdout.split("dt=")[1].split()[0])
+    assert abs(dt_cpp - dt) <= 1e-14 * dt, (dt_cpp, dt)
+    solver.init()
+    _, done = solver.rk4(0.0, tf, dt, max_steps=steps)
+    assert done == steps and f"steps={steps} " in r.stdout
+    u_py = solver.u_sol()
+    assert u_cpp.shape == u_py.shape
+    scale = np.max(np.abs(u_py))
+    assert scale > 0 and np.max(np.abs(u_cpp - u_py)) < 1e-10 * scale, np.max(np.abs(u_cpp - u_py)) / scale
