@@ -65,6 +65,7 @@ def _signatures():
         sig[f"fus_mass_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _int, _i64, _vp]
         sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_facet_terms_{suf}"] = [_vp, _vp, ct, _vp, ct, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _vp]
+        sig[f"fus_facet_terms_dev_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _vp]
         sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]
         sig[f"fus_scale_{suf}"] = [ct, _vp, _vp, _i64, _vp]
         sig[f"fus_copy_{suf}"] = [_vp, _vp, _i64, _vp]

@@ -495,6 +495,15 @@ int fus_mass_apply_f32(const float* x, const float* c, float* y, const float* de
     if (nentB > 0 && (!xB || !cB || !detJB || !dmB)) return FUS_ERR_INVALID_ARGUMENT;                             \
     return hip_rc(fus::launch_facet_terms<T>(y, cA1, sA1, cA2, sA2, detJA, dmA, nentA, xB, cB, detJB, dmB, nentB, \
                                              N, static_cast<hipStream_t>(s)));                                    \
+  }                                                                                                               \
+  int fus_facet_terms_dev_##SUF(T* y, const T* cA1, const T* cA2, const T* scalars, const T* detJA,               \
+                                const int32_t* dmA, int64_t nentA, const T* xB, const T* cB, const T* detJB,      \
+                                const int32_t* dmB, int64_t nentB, int N, void* s) {                              \
+    if (nentA < 0 || nentB < 0 || N < 1 || !y || !scalars) return FUS_ERR_INVALID_ARGUMENT;                       \
+    if (nentA > 0 && (!cA1 || !detJA || !dmA)) return FUS_ERR_INVALID_ARGUMENT;                                   \
+    if (nentB > 0 && (!xB || !cB || !detJB || !dmB)) return FUS_ERR_INVALID_ARGUMENT;                             \
+    return hip_rc(fus::launch_facet_terms<T>(y, cA1, T(0), cA2, T(0), detJA, dmA, nentA, xB, cB, detJB, dmB,      \
+                                             nentB, N, static_cast<hipStream_t>(s), scalars));                    \
   }
 FUS_FACET(double, f64)
 FUS_FACET(float, f32)

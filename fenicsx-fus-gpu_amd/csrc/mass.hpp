@@ -52,12 +52,18 @@ inline hipError_t launch_mass(const T* x, const T* consts, T* y, const T* detJ, 
 //   set A (x = 1):  y[dmA[e][i]] += (sA1 cA1[e] + sA2 cA2[e]) detJA[e][i]          (sA* = g(t), dg(t))
 //   set B:          y[dmB[e][i]] += xB[dmB[e][i]] cB[e] detJB[e][i]
 // a few thousand facets: launch-latency-bound, so one launch instead of three to five matters.
+// ``sdev`` != nullptr: (sA1, sA2) are read from device memory instead of the launch arguments, so that a
+// time loop captured in a hipGraph can be replayed with new source values (fus_facet_terms_dev_*).
 template <typename T>
 __global__ void __launch_bounds__(256)
     facet_terms_kernel(T* __restrict__ y, const T* __restrict__ cA1, T sA1, const T* __restrict__ cA2, T sA2,
                        const T* __restrict__ detJA, const int32_t* __restrict__ dmA, int64_t totalA,
                        const T* __restrict__ xB, const T* __restrict__ cB, const T* __restrict__ detJB,
-                       const int32_t* __restrict__ dmB, int64_t totalB, int N) {
+                       const int32_t* __restrict__ dmB, int64_t totalB, int N, const T* __restrict__ sdev) {
+  if (sdev != nullptr) {
+    sA1 = sdev[0];
+    sA2 = sdev[1];
+  }
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x; idx < totalA + totalB; idx += stride) {
     if (idx < totalA) {
@@ -77,13 +83,13 @@ __global__ void __launch_bounds__(256)
 template <typename T>
 inline hipError_t launch_facet_terms(T* y, const T* cA1, T sA1, const T* cA2, T sA2, const T* detJA, const int32_t* dmA,
                                      int64_t nentA, const T* xB, const T* cB, const T* detJB, const int32_t* dmB,
-                                     int64_t nentB, int N, hipStream_t stream) {
+                                     int64_t nentB, int N, hipStream_t stream, const T* sdev = nullptr) {
   const int64_t total = (nentA + nentB) * (int64_t)N;
   if (total <= 0) return hipSuccess;
   int64_t nblocks = (total + 255) / 256;
   if (nblocks > 4096) nblocks = 4096;
   hipLaunchKernelGGL((facet_terms_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, stream, y, cA1, sA1, cA2, sA2, detJA,
-                     dmA, nentA * (int64_t)N, xB, cB, detJB, dmB, nentB * (int64_t)N, N);
+                     dmA, nentA * (int64_t)N, xB, cB, detJB, dmB, nentB * (int64_t)N, N, sdev);
   return hipGetLastError();
 }
 

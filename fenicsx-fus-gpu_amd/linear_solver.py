@@ -31,6 +31,7 @@ import torch
 from . import _lib
 from . import operators as ops
 from .gll import gll_points_weights, tabulate_1d, tensor_points_3d, tensor_weights_2d, tensor_weights_3d
+from .step_graph import StepGraphMixin
 from .precompute import (
     compute_boundary_facets_scaled_jacobian_determinant_device,
     compute_scaled_geometrical_factor_device,
@@ -88,7 +89,7 @@ def snap_time_step(mesh_size, P, speed_of_sound, source_frequency, domain_length
     return dt, final_time, int((final_time - 0.0) / dt) + 1
 
 
-class LinearSpectral3D:
+class LinearSpectral3D(StepGraphMixin):
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1500.0, density=1000.0,
                  source_frequency=0.5e6, source_amplitude=60000.0, comm=None, fused=True,
                  source_time="tn", overlap=True, halo_kernels=None, affine="auto", in_kernel_geometry=False,
@@ -96,6 +97,7 @@ class LinearSpectral3D:
         self.mesh, self.P = mesh, mesh.P
         self.dt_np = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(float_type)
+        self.tdt_np = self.dt_np
         self.c0, self.rho0 = float(speed_of_sound), float(density)
         self.f0, self.p0 = float(source_frequency), float(source_amplitude)
         self.w0 = 2.0 * np.pi * self.f0
@@ -231,16 +233,17 @@ class LinearSpectral3D:
             "fus_rk4_stage",
         )
 
-    def _operator_fused(self, tn_or_t, u_n=None, v_n=None):
+    def _operator_fused(self, tn_or_t, u_n=None, v_n=None, scalars=None):
         """b += K(c2) u_n + facet terms; (u_n, v_n) default to the stage buffers (un, ku == v_n); the
-        first stage of a step passes (u0, v0) themselves."""
+        first stage of a step passes (u0, v0) themselves.  ``scalars``: device tensor the source value is read
+        from instead of being evaluated at ``tn_or_t`` (graph capture)."""
         u_n = self.un if u_n is None else u_n
         v_n = self.ku if v_n is None else v_n
-        gval = self.source_value(tn_or_t)
+        gval = 0.0 if scalars is not None else self.source_value(tn_or_t)
 
         def facets():  # M_f1(g c1) 1 + M_f2(c2) v_n in one launch (the reference fills g into a vector)
             ops.facet_terms(self.b, (self.facet_coeff1, gval, None, 0.0, self.detJ_f1, self.fdm1),
-                            (v_n, self.facet_coeff2, self.detJ_f2, self.fdm2))
+                            (v_n, self.facet_coeff2, self.detJ_f2, self.fdm2), scalars=scalars)
 
         if self.halo is None:
             self.stiff(u_n, self.cell_coeff2, self.b, self.G, self.dofmap)
@@ -293,6 +296,31 @@ class LinearSpectral3D:
             ops.copy(self.u0, self.u)
             ops.copy(self.v0, self.v)
         return t, step
+
+    # -- hipGraph replay (launch-bound meshes): step_graph.StepGraphMixin.rk4_graph ---------------------
+    def _graph_state(self):
+        return (self.u, self.v, self.u0, self.v0, self.ku, self.un, self.b)
+
+    def _graph_scalars(self, t):
+        return (self.source_value(t), 0.0)
+
+    def _graph_enter(self):
+        ops.fill(0.0, self.b)
+        ops.copy(self.u, self.u0)
+        ops.copy(self.v, self.v0)
+
+    def _graph_exit(self):
+        ops.copy(self.u0, self.u)
+        ops.copy(self.v0, self.v)
+
+    def _graph_step_body(self, dt):
+        """The 8 launches of one fused RK4 step with every argument a fixed pointer or a constant: the four
+        source values are read from ``self._scal[i]``."""
+        for i in range(4):
+            first, last = i == 0, i == 3
+            for _ in self._operator_fused(None, self.u0 if first else None, self.v0 if first else None, scalars=self._scal[i]):
+                pass
+            self._rk4_stage_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if first else 0))
 
     def u_sol(self):
         """Owned part of the pressure field on the host."""

@@ -20,6 +20,7 @@ from . import _lib
 from . import operators as ops
 from .linear_solver import A_RUNGE, B_RUNGE, C_RUNGE
 from .linear_solver import device_geometry
+from .step_graph import StepGraphMixin
 
 
 def compute_diffusivity_of_sound(frequency, speed, attenuationdB):
@@ -28,7 +29,7 @@ def compute_diffusivity_of_sound(frequency, speed, attenuationdB):
     return 2 * attenuationNp * speed**3 / frequency / frequency
 
 
-class WesterveltSpectral3D:
+class WesterveltSpectral3D(StepGraphMixin):
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
                  source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
                  attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False,
@@ -46,6 +47,7 @@ class WesterveltSpectral3D:
         self.fused = bool(fused)
         P, n = self.P, self.P + 1
         dev = torch.device("cuda", torch.cuda.current_device())
+        self.dev = dev
         nc = mesh.ncells
         bd1, bd2 = mesh.boundary_facets([2]), mesh.boundary_facets([3])
         D, G_d, detJ_d, (dF1_d, dF2_d) = device_geometry(mesh, P, ft, dev, (bd1, bd2))
@@ -152,10 +154,10 @@ class WesterveltSpectral3D:
             "fus_rk4_stage_nl2",
         )
 
-    def _operator_fused(self, ts, u_n=None, v_n=None):
+    def _operator_fused(self, ts, u_n=None, v_n=None, scalars=None):
         u_n = self.un if u_n is None else u_n
         v_n = self.ku if v_n is None else v_n  # ku == v_n
-        gv, dgv = self.source_values(ts)
+        gv, dgv = (0.0, 0.0) if scalars is not None else self.source_values(ts)  # scalars: (g, dg) in device memory
 
         single = self.kappa is not None  # one gather: the cell pass is K(c3) w, w = u_n + kappa v_n
         w_n = self.w
@@ -167,7 +169,8 @@ class WesterveltSpectral3D:
                 self.cell_fused.stiffness_only(u_n, v_n, c3, c4, self.b, G_, dm_)
 
         def facets():  # M_f1(fc1_1 g + fc2_1 dg) 1 + M_f2(fc2_2) v_n in one launch
-            ops.facet_terms(self.b, (self.fc1_1, gv, self.fc2_1, dgv, self.dF1, self.fdm1), (v_n, self.fc2_2, self.dF2, self.fdm2))
+            ops.facet_terms(self.b, (self.fc1_1, gv, self.fc2_1, dgv, self.dF1, self.fdm1), (v_n, self.fc2_2, self.dF2, self.fdm2),
+                            scalars=scalars)
 
         percell = (self.cc3, self.cc4, self.G, self.dofmap)
         if self.in_kernel_geometry:
@@ -235,6 +238,33 @@ class WesterveltSpectral3D:
         ops.pointwise_divide(self.b, self.m, self.kv)
         axpy(B_RUNGE[i] * dt, self.ku, self.u)
         axpy(B_RUNGE[i] * dt, self.kv, self.v)
+
+    # -- hipGraph replay (launch-bound meshes): step_graph.StepGraphMixin.rk4_graph ---------------------
+    def _graph_state(self):
+        return (self.u, self.v, self.u0, self.v0, self.ku, self.un, self.b) + ((self.w,) if self.w is not None else ())
+
+    def _graph_scalars(self, t):
+        return self.source_values(t)
+
+    def _graph_enter(self):
+        ops.fill(1.0, self.g)
+        ops.fill(0.0, self.b)
+        ops.copy(self.u, self.u0)
+        ops.copy(self.v, self.v0)
+        if self.kappa is not None:
+            ops.copy(self.u0, self.w)
+            self.axpy(self.kappa, self.v0, self.w)
+
+    def _graph_exit(self):
+        ops.copy(self.u0, self.u)
+        ops.copy(self.v0, self.v)
+
+    def _graph_step_body(self, dt):
+        for i in range(4):
+            first, last = i == 0, i == 3
+            for _ in self._operator_fused(None, self.u0 if first else None, self.v0 if first else None, scalars=self._scal[i]):
+                pass
+            self._stage_vector_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if first else 0))
 
     def rk4(self, start_time, final_time, dt, max_steps=None):
         gen = self.rk4_schedule(start_time, final_time, dt, max_steps)

@@ -187,11 +187,15 @@ class _MassOperator(_Launchable):
 mass_operator = _MassOperator()
 
 
-def facet_terms(y, source, field):
+def facet_terms(y, source, field, scalars=None):
     """The boundary-facet terms of one RK4 stage in one launch (csrc/mass.hpp, ``fus_facet_terms_*``):
 
         source = (c1, s1, c2, s2, detJ_f, facet_dofmap)   y += M_f(s1 c1 + s2 c2) 1      (c2 may be None)
         field  = (x, c, detJ_f, facet_dofmap)             y += M_f(c) x
+
+    ``scalars``: device tensor holding (s1, s2) -- they are then read from device memory by the kernel
+    (``fus_facet_terms_dev_*``; the s1, s2 of ``source`` are ignored), which is what lets a captured time
+    step be replayed as a hipGraph with new source values.
 
     i.e. ``mass_operator(g, facet_coeff1, b, ...)`` [+ the dg term] and ``mass_operator(v_n, facet_coeff2, b, ...)``
     of cuda/demo_linear_box.py:546-549 / cuda/demo_nonlinear_bowl.py:633-641 without filling g into a vector."""
@@ -212,6 +216,19 @@ def facet_terms(y, source, field):
     if nA and nB and dmA.shape[1] != dmB.shape[1]:
         raise ValueError("both facet sets must have the same number of dofs per facet")
     if nA + nB == 0:
+        return
+    if scalars is not None:
+        _req(scalars, dt, "scalars")
+        if scalars.numel() < 2:
+            raise ValueError("scalars must hold (s1, s2)")
+        fn = getattr(_lib.load(), f"fus_facet_terms_dev_{_lib.suffix(dt)}")
+        _lib.check(
+            fn(y.data_ptr(), c1.data_ptr() if nA else None, c2.data_ptr() if (nA and c2 is not None) else None, scalars.data_ptr(),
+               dA.data_ptr() if nA else None, dmA.data_ptr() if nA else None, int(nA), xB.data_ptr() if nB else None,
+               cB.data_ptr() if nB else None, dB.data_ptr() if nB else None, dmB.data_ptr() if nB else None, int(nB), int(N),
+               _lib.stream_ptr()),
+            "fus_facet_terms_dev",
+        )
         return
     fn = getattr(_lib.load(), f"fus_facet_terms_{_lib.suffix(dt)}")
     _lib.check(

@@ -110,6 +110,18 @@ int fus_facet_terms_f64(double* y, const double* cA1, double sA1, const double* 
 int fus_facet_terms_f32(float* y, const float* cA1, float sA1, const float* cA2, float sA2, const float* detJA,
                         const int32_t* dmA, int64_t nentA, const float* xB, const float* cB, const float* detJB,
                         const int32_t* dmB, int64_t nentB, int ndof_per_entity, void* stream);
+/*
+ * The same launch with (sA1, sA2) = scalars[0], scalars[1] read from DEVICE memory: every argument of a time
+ * step is then a fixed pointer or a constant, so the launches of a step can be captured once in a hipGraph
+ * (hipStreamBeginCapture on ``stream``; all entry points only enqueue on ``stream``) and replayed with new
+ * source values g(t), dg/dt written to ``scalars`` -- for meshes small enough to be launch-bound.
+ */
+int fus_facet_terms_dev_f64(double* y, const double* cA1, const double* cA2, const double* scalars, const double* detJA,
+                            const int32_t* dmA, int64_t nentA, const double* xB, const double* cB, const double* detJB,
+                            const int32_t* dmB, int64_t nentB, int ndof_per_entity, void* stream);
+int fus_facet_terms_dev_f32(float* y, const float* cA1, const float* cA2, const float* scalars, const float* detJA,
+                            const int32_t* dmA, int64_t nentA, const float* xB, const float* cB, const float* detJB,
+                            const int32_t* dmB, int64_t nentB, int ndof_per_entity, void* stream);
 
 /*
  * Opt-in fast path for AFFINE cells (reported separately from the headline, whose

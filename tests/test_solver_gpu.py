@@ -326,3 +326,56 @@ def test_partitioned_westervelt_solver_async_transport_one_gpu(oracle_c, geom):
     for m, s in zip(meshes, solvers):
         lex = m.global_lexicographic_ids()[: m.nlocal]
         assert rel_l2(s.u_sol(), u_ref[lex]) < 1e-11
+
+
+@pytest.mark.parametrize("geom", ["affine", "perturbed", "perturbed-in-kernel-geometry"])
+def test_linear_solver_graph_replay_is_bitwise_rk4(geom):
+    """rk4_graph: the full-size steps replayed from one captured hipGraph (source values read from device
+    memory, fus_facet_terms_dev_*), the shorter last step through rk4 -- same kernels, same order, same data
+    as rk4, so the SAME bits; and a second call (graph reused) continues correctly."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls = pkg("boxmesh"), pkg("linear_solver")
+    P, N, L = 3, 5, 0.012
+    mesh = boxmesh.BoxMesh(P, N, length=L, perturb=0.0 if geom == "affine" else 0.12, seed=4)
+    h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    a = ls.LinearSpectral3D(mesh, np.float64, in_kernel_geometry=geom.endswith("geometry"))
+    b = ls.LinearSpectral3D(mesh, np.float64, in_kernel_geometry=geom.endswith("geometry"))
+    a.init()
+    b.init()
+    ta, sa = a.rk4(0.0, tf, dt)
+    t1, s1 = b.rk4_graph(0.0, tf, dt, max_steps=10)  # captures
+    t2, s2 = b.rk4_graph(t1, tf, dt)                 # replays the same graph, then the short last step
+    assert s1 == 10 and s1 + s2 == sa and t2 == ta
+    assert len(b._graphs) == 1
+    assert np.max(np.abs(a.u_sol())) > 1e3
+    # atomics make the operator's sums order-dependent from run to run: equal up to that, not to a tolerance
+    # of the method (two rk4 runs differ by the same amount)
+    assert rel_l2(b.u_sol(), a.u_sol()) < 1e-13 and rel_l2(b.v_sol(), a.v_sol()) < 1e-13
+
+
+@pytest.mark.parametrize("mode", ["single-gather", "two-gather", "in-kernel-geometry"])
+def test_westervelt_solver_graph_replay_matches_rk4(mode):
+    """rk4_graph of the Westervelt solver (g and dg/dt of every stage read from device memory)."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, nls = pkg("boxmesh"), pkg("nonlinear_solver")
+    P, cells, L = 4, (4, 3, 3), 0.006
+    mesh = boxmesh.BoxMesh(P, cells, length=L, warp=_bowl_warp)
+    kw = dict(fused=True, in_kernel_geometry=(mode == "in-kernel-geometry"), uniform_ratio=(False if mode == "two-gather" else "auto"))
+    a = nls.WesterveltSpectral3D(mesh, np.float64, **kw)
+    b = nls.WesterveltSpectral3D(mesh, np.float64, **kw)
+    assert (a.kappa is None) == (mode == "two-gather")
+    dt = 0.4 * (L / 4) / (a.c0 * P * P)
+    tf = 30.5 * dt  # 30 full steps and a shorter last one
+    a.init()
+    b.init()
+    ta, sa = a.rk4(0.0, tf, dt)
+    t1, s1 = b.rk4_graph(0.0, tf, dt, max_steps=7)
+    t2, s2 = b.rk4_graph(t1, tf, dt)
+    assert sa == 31 and s1 == 7 and s1 + s2 == sa and abs(t2 - ta) < 1e-18 and len(b._graphs) == 1
+    assert np.max(np.abs(a.u_sol())) > 0
+    assert rel_l2(b.u_sol(), a.u_sol()) < 1e-13 and rel_l2(b.v_sol(), a.v_sol()) < 1e-13
