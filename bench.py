@@ -266,6 +266,43 @@ def dry_run(args, rank, world):
     return 0 if ok.item() == 1.0 else 1
 
 
+def coll_device(device):
+    """Where the tensors of bench.py's own collectives (barrier flags, max-over-ranks time) live."""
+    import torch
+
+    return torch.device("cpu") if rehearsal() else device
+
+
+def rehearsal():
+    """FUS_BENCH_REHEARSAL=1: the N-rank code path of THIS script with real HIP kernels and real processes
+    where only one GPU exists -- every rank on the visible GPU(s) modulo their count, torch.distributed over
+    gloo, the exchange staged through the host.  The line is marked invalid: not a measurement."""
+    return os.environ.get("FUS_BENCH_REHEARSAL", "0") == "1"
+
+
+class _StagedGlooComm:
+    """Exchange of device tensors over gloo, staged through the host -- rehearsal only."""
+
+    def __init__(self, inner):
+        self.inner = inner
+        self.rank, self.size, self.backend = inner.rank, inner.size, inner.backend
+
+    def alltoallv(self, send, send_counts, recv, recv_counts, async_op=False):
+        import torch
+
+        torch.cuda.synchronize()
+        s, r = send.cpu(), torch.empty(recv.shape, dtype=recv.dtype)
+        self.inner.alltoallv(s, send_counts, r, recv_counts)
+        recv.copy_(r)
+        return None
+
+    def alltoallv_int64(self, *a):
+        return self.inner.alltoallv_int64(*a)
+
+    def barrier(self):
+        self.inner.barrier()
+
+
 def make_comm(args, scat, world, device):
     """The halo transport of this run, decided COLLECTIVELY: the native communicator (libfusgpu.so issues
     the RCCL calls) unless --halo torch; if its creation fails on ANY rank, every rank falls back to
@@ -273,6 +310,8 @@ def make_comm(args, scat, world, device):
     import torch
     import torch.distributed as dist
 
+    if rehearsal():
+        return _StagedGlooComm(scat.TorchComm()), "torch, REHEARSAL over gloo with host staging"
     if args.halo != "native":
         return scat.TorchComm(), "torch"
     comm, ok = None, 1.0
@@ -282,7 +321,7 @@ def make_comm(args, scat, world, device):
         log(f"native communicator failed on rank {dist.get_rank() if dist.is_initialized() else 0}: {e!r}")
         ok = 0.0
     if world > 1:
-        flag = torch.tensor([ok], dtype=torch.float64, device=device)
+        flag = torch.tensor([ok], dtype=torch.float64, device=coll_device(device))
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         ok = float(flag.item())
     if ok == 1.0:
@@ -409,7 +448,7 @@ def bench_rk4(args, rank, world, device):
     mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, length=tuple(L * g for g in grid), dtype=dt_np)
     h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L * grid[0])
     if world > 1:  # comm.Allreduce(hmin, mesh_size, op=MPI.MIN), cuda/demo_linear_box.py:108
-        hm = torch.tensor([h], dtype=torch.float64, device=device)
+        hm = torch.tensor([h], dtype=torch.float64, device=coll_device(device))
         dist.all_reduce(hm, op=dist.ReduceOp.MIN)
         h = float(hm.item())
     dts, tf, nstep = ls.snap_time_step(h, P, 1500.0, 0.5e6, L * grid[0])  # the wave crosses the whole (partitioned) box
@@ -448,7 +487,7 @@ def bench_rk4(args, rank, world, device):
         dist.barrier()
     el = time.perf_counter() - t0
     if world > 1:
-        tt = torch.tensor([el], dtype=torch.float64, device=device)
+        tt = torch.tensor([el], dtype=torch.float64, device=coll_device(device))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
     out = {
@@ -466,6 +505,8 @@ def bench_rk4(args, rank, world, device):
                          if getattr(solver, "in_kernel_geometry", False) else "general per-quadrature-point G")},
         "roofline": None, "cpu_baseline": None,
     }
+    if rehearsal():
+        out.update(valid=False, rehearsal="ranks share the visible GPU(s), gloo with host-staged exchange: NOT a measurement")
     if rank == 0:
         emit(out)
     if world > 1:
@@ -531,12 +572,15 @@ def main():
         os.environ.setdefault("MASTER_PORT", "29511")
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
-        opts = None
-        try:  # comm kernels must get CUs while a chip-filling operator kernel runs
-            opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
-        except Exception:
-            pass
-        dist.init_process_group("nccl", device_id=device, pg_options=opts)
+        if rehearsal():
+            dist.init_process_group("gloo")
+        else:
+            opts = None
+            try:  # comm kernels must get CUs while a chip-filling operator kernel runs
+                opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+            except Exception:
+                pass
+            dist.init_process_group("nccl", device_id=device, pg_options=opts)
 
     lib = fusgpu_loader.submodule("_lib")
     ops = fusgpu_loader.submodule("operators")
@@ -647,7 +691,7 @@ def main():
         dist.barrier()
     elapsed = time.perf_counter() - t_start
     if use_dist:
-        tt = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        tt = torch.tensor([elapsed], dtype=torch.float64, device=coll_device(device))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
@@ -777,6 +821,8 @@ def main():
             "measured_read_gbs": read_gbs,   # 1 GiB read-only reduction (torch.sum)
         },
     }
+    if rehearsal():
+        out.update(valid=False, rehearsal="ranks share the visible GPU(s), gloo with host-staged exchange: NOT a measurement")
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline and mass:
             try:

@@ -107,3 +107,24 @@ def test_mass_mode_line(dist_path):
     assert out["roofline"]["algorithmic_bytes_per_cell"] == 3044 and "mass" in out["roofline"]["kernel"]
     if not dist_path:
         assert out["cpu_baseline"]["cores"] == 1 and out["cpu_baseline"]["value"] > 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("n,mode", [(2, "stiffness"), (2, "mass"), (2, "rk4"), (4, "stiffness"), (4, "westervelt")])
+def test_multi_rank_rehearsal_on_one_gpu(n, mode):
+    """bench.py's own N = 2 / N = 4 path end to end with real processes and real HIP kernels on the one-GPU box:
+    self-spawned ranks share the GPU, torch.distributed over gloo, exchange staged through the host
+    (FUS_BENCH_REHEARSAL=1; the line is marked invalid).  Covers what the N = 1 forced-dist run cannot: real
+    neighbours inside the timed loop, the max-over-ranks reduction, rank 0 printing for the whole job."""
+    cmd = [sys.executable, BENCH, "--gpus", str(n), "--mode", mode, "--steps", "3", "--warmup", "1", "--cells", "10", "--no-cpu-baseline"]
+    if mode == "westervelt":
+        cmd += ["--degree", "6", "--cells", "4"]
+    r = subprocess.run(cmd, env=_env(FUS_BENCH_REHEARSAL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["n_gpus"] == n and out["valid"] is False and "rehearsal" in out and out["value"] > 0
+    if mode in ("stiffness", "mass"):
+        cfg = out["config"]
+        gy = n // 2
+        assert cfg["ranks"] == n and cfg["partition"] == f"2x{gy}x1 blocks" and cfg["halo"] == "overlapped"
+        assert cfg["global_dofs"] == (4 * 20 + 1) * (4 * 10 * gy + 1) * 41 and cfg["cells_per_gpu"] == 1000
