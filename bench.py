@@ -790,6 +790,7 @@ def main():
             "stiffness_kernel": None if mass else ("planned (batch plan, LDS pre-reduction)" if ops._USE_PLAN else f"plan-free variant {lib.get_tuning(lib.TUNE_STIFFNESS_VARIANT)}"),
             "xcd_remap": lib.get_tuning(lib.TUNE_XCD_REMAP),
             "halo": None if halo is None else ("overlapped" if halo.overlap else "sequential"),
+            "halo_lead_cells": None if halo is None else halo.lead_cells,
             "halo_transport": None if halo is None else (
                 "libfusgpu.so: grouped ncclSend/ncclRecv on a library-owned stream" if transport == "native"
                 else f"torch.distributed.all_to_all_single (RCCL) [{transport}]"),

@@ -341,18 +341,25 @@ class HaloApply:
     """Distributed operator apply  y += K x  on a partitioned mesh, with the
     halo exchange overlapped with interior-cell work (one process per GPU):
 
-        fwd.begin(x) | apply(interior half 1) | fwd.end(x)
+        fwd.begin(x) | apply(lead slice) apply(interior half 1) | fwd.end(x)
         apply(boundary cells)                               # the only cells touching ghost dofs
-        rev.begin(y) | apply(interior half 2) | rev.end(y)
+        rev.begin(y) | apply(lead slice) apply(interior half 2) | rev.end(y)
 
     This is the reference's per-stage sequence scatter_fwd -> stiffness ->
     scatter_rev (cuda/demo_linear_box.py:537-553) with its host syncs removed
     and the cells split so that both exchanges hide behind interior work.
     ``mesh.dofmap`` must list the ghost-touching cells first
     (``mesh.num_boundary_cells``), as ``BoxMesh`` does.
+
+    Lead slices (``lead_cells``; profiles/r02z_overlap_*.log): the operator kernels hold every vector
+    register of every CU (4 workgroups x 128 VGPRs per SIMD lane), and RCCL's send/recv kernel needs 264 per
+    wave, so a kernel posted next to a chip-filling launch is not scheduled until that launch drains -- the
+    exchange would run AFTER the interior cells, not under them.  Each overlapped region therefore starts
+    with a launch too small to fill the chip (about 0.6 of the resident-workgroup slots): the exchange kernels
+    become resident next to it and stay resident under the large launch that follows.
     """
 
-    def __init__(self, mesh, op, comm, float_type, overlap=True, kernels=None, apply_fn=None, plan=None):
+    def __init__(self, mesh, op, comm, float_type, overlap=True, kernels=None, apply_fn=None, plan=None, lead_cells="auto"):
         from .utils import compute_scatterer_data_flat
 
         self.mesh = mesh
@@ -367,7 +374,18 @@ class HaloApply:
         self.overlap = overlap
         nb, nc = mesh.num_boundary_cells, mesh.ncells
         mid = nb + (nc - nb) // 2
-        self.ranges = {"boundary": (0, nb), "interior1": (nb, mid), "interior2": (mid, nc)}
+        has_neighbours = (len(self.neighbour_ranks()) > 0)
+        if lead_cells == "auto":
+            lead = self._auto_lead_cells(mesh)
+            if (nc - nb) < 8 * lead:  # mesh too small to slice
+                lead = 0
+        else:
+            lead = max(0, min(int(lead_cells or 0), mid - nb, nc - mid))
+        if not overlap or not has_neighbours:  # nothing to hide
+            lead = 0
+        self.lead_cells = lead
+        self.ranges = {"boundary": (0, nb), "lead1": (nb, nb + lead), "interior1": (nb + lead, mid),
+                       "lead2": (mid, mid + lead), "interior2": (mid + lead, nc)}
         self._views_cache = {}
         self._apply_fn = apply_fn  # tests: CPU stand-in for the operator
         import os
@@ -378,6 +396,23 @@ class HaloApply:
         # stream on a real partition (profiles/r01f_host_overhead.log); to be re-measured on 8 GPUs.
         self.side_stream = os.environ.get("FUS_HALO_SIDE_STREAM", "0") == "1"
         self._hs = None
+
+    def neighbour_ranks(self):
+        """Neighbour ranks of this rank (either direction)."""
+        od, gd = self.owners_data, self.ghosts_data
+        return [int(r) for r in list(np.asarray(od[-1]).reshape(-1)) + list(np.asarray(gd[-1]).reshape(-1))]
+
+    @staticmethod
+    def _auto_lead_cells(mesh):
+        """Cells of a launch that fills about 0.6 of the chip's resident-workgroup slots (4 workgroups per
+        CU up to P = 5, 3 above: tools/resource_usage.py)."""
+        try:
+            ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
+            lib = _lib.load()
+            epb = int(lib.fus_plan_entities_per_batch((mesh.P + 1) ** 3))
+        except Exception:
+            return 0
+        return int(0.6 * ncu * (4 if mesh.P <= 5 else 3)) * max(epb, 1)
 
     def _halo_stream(self):
         if self._hs is None:
@@ -418,7 +453,7 @@ class HaloApply:
             yield "forward"
             for sc, vec, wk in fw:
                 sc.end(vec, wk)
-            for name in ("boundary", "interior1", "interior2"):
+            for name in ("boundary", "lead1", "interior1", "lead2", "interior2"):
                 part(name)
             if boundary_terms is not None:
                 boundary_terms()
@@ -434,6 +469,7 @@ class HaloApply:
             # enqueued here, the collective on RCCL's stream, the unpack in end().
             fw = begin_all(forward)
             yield "forward"
+            part("lead1")
             part("interior1")
             for sc, vec, wk in fw:
                 sc.end(vec, wk)
@@ -442,6 +478,7 @@ class HaloApply:
                 boundary_terms()
             rv = begin_all(reverse)
             yield "reverse"
+            part("lead2")
             part("interior2")
             for sc, vec, wk in rv:
                 sc.end(vec, wk)
@@ -464,6 +501,7 @@ class HaloApply:
                 sc.end(vec, wk)
             ev_fwd = torch.cuda.Event()
             ev_fwd.record(hs)
+        part("lead1")
         part("interior1")
         main.wait_event(ev_fwd)
         part("boundary")
@@ -478,6 +516,7 @@ class HaloApply:
                 sc.end(vec, wk)
             ev_rev = torch.cuda.Event()
             ev_rev.record(hs)
+        part("lead2")
         part("interior2")
         main.wait_event(ev_rev)
 
@@ -498,7 +537,7 @@ class HaloApply:
         communicator up (RCCL creates its channels on first use) with two no-effect exchanges --
         a forward scatter of x (ghosts receive their owners' values) and a reverse scatter of a
         zero vector."""
-        for name in ("interior1", "boundary", "interior2"):
+        for name in ("lead1", "interior1", "boundary", "lead2", "interior2"):
             a, b = self.ranges[name]
             if b > a and self.op is not None and hasattr(self.op, "prepare"):
                 self.op.prepare(self._views(name, (cell_constants, G, dofmap))[2])
@@ -508,7 +547,7 @@ class HaloApply:
     def apply_local_only(self, x, cell_constants, y, G, dofmap):
         """The three kernel launches without any exchange (bench: kernel time at N > 1)."""
         fn = self._apply_fn if self._apply_fn is not None else self.op
-        for name in ("interior1", "boundary", "interior2"):
+        for name in ("lead1", "interior1", "boundary", "lead2", "interior2"):
             a, b = self.ranges[name]
             if b > a:
                 c_, G_, d_ = self._views(name, (cell_constants, G, dofmap))

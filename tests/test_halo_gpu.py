@@ -216,7 +216,11 @@ def test_partitioned_apply_async_transport_one_gpu(gpu, oracle_c, P, cells, grid
     halos = []
     for r, rk in enumerate(ranks):
         comm = scat.NativeComm(local=(wid, R, r))
-        halos.append(scat.HaloApply(rk["mesh"], op, comm, np.float64, overlap=overlap, plan=(od[r], gd[r])))
+        # lead slices (the small launches that open each overlapped region) forced on every other rank
+        halos.append(scat.HaloApply(rk["mesh"], op, comm, np.float64, overlap=overlap, plan=(od[r], gd[r]),
+                                    lead_cells=(2 if r % 2 == 0 else 0)))
+        assert halos[-1].lead_cells in ((0, 1, 2) if (r % 2 == 0 and overlap) else (0,))  # clamped to half the interior
+    assert halos[0].lead_cells == (2 if overlap else 0)  # rank 0 of these partitions has >= 4 interior cells
     for rep in range(2):  # second apply: buffers / events reused while the first may still be in flight
         for rk in ranks:
             rk["y"].zero_()

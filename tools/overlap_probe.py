@@ -1,0 +1,192 @@
+#!/usr/bin/env python3
+"""Does an exchange posted before a chip-filling operator launch really run UNDER it?
+
+One GPU, 1-rank world whose rank is its own neighbour (RCCL runs its send/recv kernel for a message to
+self), halo plan of BASELINE config-4 size (3 faces + 3 edges + 1 corner of a 2x2x2 partition, 1.14 MB per
+direction).  Per transport (native: libfusgpu.so's grouped ncclSend/ncclRecv on its high-priority stream;
+torch: all_to_all_single) the probe times K repetitions of
+
+    A   op                                   the config-3 stiffness apply alone
+    B   begin(exchange of w) ; op ; end      what HaloApply does around interior cells (w: another vector)
+    C   begin ; end ; op                     the same exchange NOT overlapped
+
+B - A is the exposed cost of the exchange, C - A its full cost.  With --trace the script is meant to run
+under `rocprofv3 --kernel-trace`: the kernel timeline then shows where the RCCL kernel ran."""
+import argparse
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reps", type=int, default=50)
+    ap.add_argument("--permuted", action="store_true", help="ghosts not grouped by owner: pack/unpack kernels on both sides")
+    ap.add_argument("--reserve-cus", type=int, default=0, help="run the operator on a stream whose CU mask leaves this many CUs free")
+    ap.add_argument("--mask-style", default="high", choices=["high", "low", "spread"], help="which mask bits are cleared")
+    ap.add_argument("--max-channels", type=int, default=0, help="NCCL_MAX_NCHANNELS for the communicators created here")
+    ap.add_argument("--apply-schedules", default="", help="comma-separated lead-slice sizes (cells) for the whole-apply sequence")
+    ap.add_argument("--tail", action="store_true", help="apply schedules: also end the reverse region with a small slice")
+    ap.add_argument("--slice", default="", help="also time begin; op(slice 1); op(slice 2); ...; op(rest); end -- comma-separated cell fractions")
+    a = ap.parse_args()
+    if a.max_channels:
+        os.environ["NCCL_MAX_NCHANNELS"] = str(a.max_channels)
+        os.environ["NCCL_MIN_NCHANNELS"] = str(min(a.max_channels, 2))
+    import torch
+    import torch.distributed as dist
+
+    import fusgpu_loader
+    from conftest import build_problem
+
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", "29578")
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    opts = dist.ProcessGroupNCCL.Options(is_high_priority_stream=True)
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=dev, pg_options=opts)
+    ops, scat = fusgpu_loader.submodule("operators"), fusgpu_loader.submodule("scatterer")
+    pb = build_problem(4, 54, perturb=0.16)
+    mesh = pb["mesh"]
+    x, cc, G = (torch.from_numpy(pb[k]).to(dev) for k in ("x", "cc", "G"))
+    dm = torch.from_numpy(mesh.dofmap).to(dev)
+    y = torch.zeros(mesh.ndofs, dtype=torch.float64, device=dev)
+    w = torch.randn(mesh.ndofs, dtype=torch.float64, device=dev)
+    op = ops.stiffness_operator(4, pb["D"].flatten(), np.float64)
+    op.prepare(dm)
+    rng = np.random.default_rng(0)
+    ng = 3 * 47089 + 3 * 217 + 1
+    N = mesh.ndofs - ng
+    o_idx = rng.permutation(ng).astype(np.int64) if a.permuted else np.arange(ng, dtype=np.int64)
+    od = [o_idx, np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+    gd = [rng.choice(N, size=ng, replace=False).astype(np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+
+    if a.reserve_cus:
+        import ctypes
+
+        hip = ctypes.CDLL("libamdhip64.so")
+        ncu = torch.cuda.get_device_properties(0).multi_processor_count
+        words = (ncu + 31) // 32
+        bits = [1] * ncu
+        if a.mask_style == "high":
+            off = range(ncu - a.reserve_cus, ncu)
+        elif a.mask_style == "low":
+            off = range(a.reserve_cus)
+        else:
+            off = [int(i * ncu / a.reserve_cus) for i in range(a.reserve_cus)]
+        for i in off:
+            bits[i] = 0
+        mask = (ctypes.c_uint32 * words)(*[sum(bits[w * 32 + b] << b for b in range(32) if w * 32 + b < ncu) for w in range(words)])
+        st = ctypes.c_void_p()
+        rc = hip.hipExtStreamCreateWithCUMask(ctypes.byref(st), ctypes.c_uint32(words), mask)
+        assert rc == 0, rc
+        torch.cuda.set_stream(torch.cuda.ExternalStream(st.value))
+        print(f"operator stream: CU mask with {a.reserve_cus} of {ncu} CUs cleared ({a.mask_style})", flush=True)
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(a.reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / a.reps * 1e3
+
+    tA = timed(lambda: op(x, cc, y, G, dm))
+    print(f"A  op alone                                   {tA:8.1f} us", flush=True)
+    for name, comm in (("native", scat.NativeComm()),):
+        for dname, mk in (("forward", scat.scatter_forward), ("reverse", scat.scatter_reverse)):
+            sc = mk(comm, od, gd, N, np.float64)
+            sc(w)
+
+            def overlapped():
+                wk = sc.begin(w)
+                op(x, cc, y, G, dm)
+                sc.end(w, wk)
+
+            def serial():
+                wk = sc.begin(w)
+                sc.end(w, wk)
+                op(x, cc, y, G, dm)
+
+            tB, tC = timed(overlapped), timed(serial)
+            tX = timed(lambda: sc(w))
+            extra = ""
+            if a.slice:
+                cuts, acc = [0], 0.0
+                for f in a.slice.split(","):
+                    acc += float(f)
+                    cuts.append(int(mesh.ncells * acc) // 10 * 10)
+                cuts.append(mesh.ncells)
+                parts = [(cc[i:j], G[i:j], dm[i:j]) for i, j in zip(cuts[:-1], cuts[1:])]
+                for c_, G_, d_ in parts:
+                    op.prepare(d_)
+
+                def two():
+                    for c_, G_, d_ in parts:
+                        op(x, c_, y, G_, d_)
+
+                def sliced():
+                    wk = sc.begin(w)
+                    two()
+                    sc.end(w, wk)
+
+                tA2, tD = timed(two), timed(sliced)
+                extra = f" | D begin;op[{a.slice}];op[rest];end {tD:8.1f} us (two launches alone {tA2:6.1f}; exposed vs A {tD - tA:+6.1f})"
+            print(f"{name} {dname}: exchange alone {tX:6.1f} us | B begin;op;end {tB:8.1f} us (exposed {tB - tA:+6.1f}) | "
+                  f"C begin;end;op {tC:8.1f} us (cost {tC - tA:+6.1f}){extra}", flush=True)
+    if a.apply_schedules:
+        # the whole HaloApply sequence around one apply (forward exchange of x-like vector w, reverse exchange of
+        # y-like vector w2), with a self-neighbour plan, for several launch schedules.  Cells: boundary = the first
+        # 8 590 cells (859 batches, as a 54^3 block of a 2x2x2 partition has), interior = the rest.
+        comm = scat.NativeComm()
+        fwd, rev = scat.scatter_forward(comm, od, gd, N, np.float64), scat.scatter_reverse(comm, od, gd, N, np.float64)
+        w2 = torch.zeros_like(w)
+        nb, nc = 8590, mesh.ncells
+
+        def rng_(i, j):
+            v = (cc[i:j], G[i:j], dm[i:j])
+            op.prepare(v[2])
+            return v
+
+        def run(parts):
+            for c_, G_, d_ in parts:
+                op(x, c_, y, G_, d_)
+
+        mid = nb + (nc - nb) // 2
+        for lead in [0] + [int(v) for v in a.apply_schedules.split(",")]:
+            if lead == 0:
+                A1, B_, A2 = [rng_(nb, mid)], [rng_(0, nb)], [rng_(mid, nc)]
+                name = "interior1 | boundary | interior2 (current)"
+            else:
+                A1 = [rng_(nb, nb + lead), rng_(nb + lead, mid)]
+                B_ = [rng_(0, nb)]
+                A2 = [rng_(mid, mid + lead), rng_(mid + lead, nc - lead), rng_(nc - lead, nc)] if a.tail else [rng_(mid, mid + lead), rng_(mid + lead, nc)]
+                name = f"lead slices of {lead} cells" + (" + tail slice" if a.tail else "")
+
+            def plain():
+                run(A1), run(B_), run(A2)
+
+            def with_halo():
+                k1 = fwd.begin(w)
+                run(A1)
+                fwd.end(w, k1)
+                run(B_)
+                k2 = rev.begin(w2)
+                run(A2)
+                rev.end(w2, k2)
+
+            t0_, t1_ = timed(plain), timed(with_halo)
+            print(f"schedule {name:45s}: launches alone {t0_:7.1f} us | with both exchanges {t1_:7.1f} us | exposed {t1_ - t0_:+6.1f} "
+                  f"| vs single launch {t1_ - tA:+6.1f}", flush=True)
+    dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()
