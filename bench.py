@@ -710,7 +710,7 @@ def main():
     ev_ms = np.array([a.elapsed_time(b) for a, b in zip(ev0, ev1)])
 
     if halo is not None:
-        # kernel time at N > 1: the three sub-launches (interior / boundary / interior) without
+        # kernel time at N > 1: the sub-launches (lead / interior / boundary / lead / interior) without
         # any exchange, timed after (outside) the timed region
         reps = 10
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -810,7 +810,7 @@ def main():
             "kernel": kname,
             "kernel_ms": kern_ms,
             "kernel_ms_how": ("one HIP-event pair around the K back-to-back launches of the timed region / K" if halo is None
-                              else "event pair around 10 repetitions of the three cell sub-range launches, no exchange"),
+                              else "event pair around 10 repetitions of the cell sub-range launches (lead slice, interior half, boundary, lead slice, interior half), no exchange"),
             "isolated_launch_ms_mean": float(ev_ms.mean()),  # one event pair per launch, outside the timed region
             "isolated_launch_ms_min": float(ev_ms.min()),
             "isolated_launch_ms_std": float(ev_ms.std()),
