@@ -182,9 +182,25 @@ def main():
                 run(A2)
                 rev.end(w2, k2)
 
+            def begins_only():  # NOT a valid apply: where the time goes (no wait on the launch stream at all)
+                fwd.begin(w)
+                run(A1)
+                run(B_)
+                rev.begin(w2)
+                run(A2)
+
+            def fwd_wait_only():
+                k1 = fwd.begin(w)
+                run(A1)
+                fwd.end(w, k1)
+                run(B_)
+                rev.begin(w2)
+                run(A2)
+
             t0_, t1_ = timed(plain), timed(with_halo)
+            t2_, t3_ = timed(begins_only), timed(fwd_wait_only)
             print(f"schedule {name:45s}: launches alone {t0_:7.1f} us | with both exchanges {t1_:7.1f} us | exposed {t1_ - t0_:+6.1f} "
-                  f"| vs single launch {t1_ - tA:+6.1f}", flush=True)
+                  f"| vs single launch {t1_ - tA:+6.1f} | [diagnostic: posted, never waited for {t2_ - t0_:+6.1f}; forward wait only {t3_ - t0_:+6.1f}]", flush=True)
     dist.destroy_process_group()
 
 
