@@ -407,12 +407,15 @@ class HaloApply:
         """Cells of a launch that fills about 0.6 of the chip's resident-workgroup slots (4 workgroups per
         CU up to P = 5, 3 above: tools/resource_usage.py)."""
         try:
+            nd = int(mesh.dofmap.shape[1])
+            P = int(round(nd ** (1.0 / 3.0))) - 1
             ncu = torch.cuda.get_device_properties(torch.cuda.current_device()).multi_processor_count
-            lib = _lib.load()
-            epb = int(lib.fus_plan_entities_per_batch((mesh.P + 1) ** 3))
+            epb = int(_lib.load().fus_plan_entities_per_batch(nd))
         except Exception:
             return 0
-        return int(0.6 * ncu * (4 if mesh.P <= 5 else 3)) * max(epb, 1)
+        if epb < 1 or (P + 1) ** 3 != nd:
+            return 0
+        return int(0.6 * ncu * (4 if P <= 5 else 3)) * epb
 
     def _halo_stream(self):
         if self._hs is None:
