@@ -671,6 +671,29 @@ def main():
         halo.prepare(x_d, cc_d, G_d, dm_d)
     for _ in range(args.warmup):
         step()
+    halo_check = None
+    if halo is not None:
+        # the exchanges of THIS run, checked before anything is timed: (1) poisoned ghost entries of x come back
+        # from a forward scatter as their owners' values (x is an analytic field, the ghosts were filled from the
+        # same formula); (2) the sum of y over the OWNED dofs of all ranks equals 1^T K x = 0 (K 1 = 0, K symmetric) --
+        # for the mass operator: what the cells of all ranks contribute -- only if every ghost contribution reached
+        # its owner
+        nl = mesh.nlocal
+        expect = x_d[nl:].clone()
+        x_d[nl:] = -777.0
+        halo.fwd(x_d)
+        fwd_err = float((x_d[nl:] - expect).abs().max().item()) if expect.numel() else 0.0
+        y_d.zero_()
+        step()
+        # mass operator: the owned sum equals what the cells of all ranks contribute, sum_c sum_i x detJ c
+        ref = (x_d[dm_d.long()] * G_d * cc_d[:, None]).sum() if mass else torch.zeros((), dtype=x_d.dtype, device=device)
+        sums = torch.stack([y_d[:nl].sum(), y_d[:nl].abs().sum(), ref]).to(coll_device(device))
+        dist.all_reduce(sums)
+        rel = abs(float(sums[0].item()) - float(sums[2].item())) / max(float(sums[1].item()), 1e-300)
+        ok = (fwd_err == 0.0) and rel < (1e-9 if args.dtype == "f64" else 1e-3)
+        halo_check = {"forward_max_abs_err": fwd_err, "owned_sum_defect_over_sum_abs": rel, "ok": bool(ok)}
+        if not ok:
+            raise SystemExit(f"halo check failed on rank {rank}: {halo_check}")
     y_d.zero_()
     # Timed region: EXACTLY K steps issued back to back, bracketed by barrier + device synchronise on
     # both sides (wall clock -> value) and by ONE HIP-event pair on the launch stream (device time of
@@ -791,6 +814,7 @@ def main():
             "xcd_remap": lib.get_tuning(lib.TUNE_XCD_REMAP),
             "halo": None if halo is None else ("overlapped" if halo.overlap else "sequential"),
             "halo_lead_cells": None if halo is None else halo.lead_cells,
+            "halo_check": halo_check,
             "halo_transport": None if halo is None else (
                 "libfusgpu.so: grouped ncclSend/ncclRecv on a library-owned stream" if transport == "native"
                 else f"torch.distributed.all_to_all_single (RCCL) [{transport}]"),

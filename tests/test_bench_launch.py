@@ -92,6 +92,7 @@ def test_distributed_code_path_on_one_gpu(halo):
     assert out["n_gpus"] == 1 and cfg["ranks"] == 1 and cfg["halo"] == "overlapped"
     assert cfg["halo_exposed_ms"] is not None and out["value"] > 0
     assert ("libfusgpu" in cfg["halo_transport"]) == (halo == "native")
+    assert cfg["halo_check"]["ok"] is True and cfg["halo_check"]["forward_max_abs_err"] == 0.0
     assert out["roofline"]["kernel_ms"] > 0 and cfg["lib_sha"]
 
 
@@ -128,3 +129,5 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
         gy = n // 2
         assert cfg["ranks"] == n and cfg["partition"] == f"2x{gy}x1 blocks" and cfg["halo"] == "overlapped"
         assert cfg["global_dofs"] == (4 * 20 + 1) * (4 * 10 * gy + 1) * 41 and cfg["cells_per_gpu"] == 1000
+        # the run checks its own exchanges before timing anything (forward: exact copy; reverse: owned sums)
+        assert cfg["halo_check"]["ok"] is True and cfg["halo_check"]["owned_sum_defect_over_sum_abs"] < 1e-9
