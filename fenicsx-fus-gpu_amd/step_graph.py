@@ -1,7 +1,7 @@
 """
 hipGraph replay of the fused RK4 step (single rank) for meshes small enough that the launches, not the
 kernels, bound the step -- below roughly 0.5 M dofs when driven from Python (tools/time_rk4_graph.py:
-2.3x at 50 k dofs, 1.9x at 118 k, nothing to gain from 1 M dofs up, where consecutive stream launches
+1.7x at 50 k dofs, 1.4x at 118 k, nothing to gain from 1 M dofs up, where consecutive stream launches
 overlap their tails and graph nodes do not).
 
 Every launch of a fused step takes fixed device pointers and constants except the source values g(t),
