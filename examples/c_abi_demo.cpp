@@ -45,6 +45,10 @@ static T* upload(const std::vector<T>& h) {
 }
 
 int main() {
+  if (fus_abi_version() != FUS_ABI_VERSION) {
+    std::fprintf(stderr, "libfusgpu.so has ABI version %d, this host was built against %d\n", fus_abi_version(), FUS_ABI_VERSION);
+    return 2;
+  }
   constexpr int P = 2, n = 3, Nd = 27, N = 2;  // degree, nodes per direction, dofs per cell, cells per direction
   const double pts[n] = {0.0, 0.5, 1.0}, wts[n] = {1.0 / 6, 4.0 / 6, 1.0 / 6};
   const double D[n * n] = {-3, 4, -1, -1, 0, 1, 1, -4, 3};  // D[q][i] = l_i'(pts[q]) on [0, 1]

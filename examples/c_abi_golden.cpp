@@ -94,6 +94,10 @@ static double rel_l2(const std::vector<double>& got, const double* ref) {
 }
 
 int main(int argc, char** argv) {
+  if (fus_abi_version() != FUS_ABI_VERSION) {
+    std::fprintf(stderr, "libfusgpu.so has ABI version %d, this host was built against %d\n", fus_abi_version(), FUS_ABI_VERSION);
+    return 2;
+  }
   if (argc < 2) {
     std::fprintf(stderr, "usage: %s tests/golden/ops_P4_2x2x2_pert_float64.bin\n", argv[0]);
     return 64;

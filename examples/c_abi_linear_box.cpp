@@ -377,6 +377,10 @@ private:
 };
 
 int main(int argc, char** argv) {
+  if (fus_abi_version() != FUS_ABI_VERSION) {
+    std::fprintf(stderr, "libfusgpu.so has ABI version %d, this host was built against %d\n", fus_abi_version(), FUS_ABI_VERSION);
+    return 2;
+  }
   if (argc < 6) {
     std::fprintf(stderr, "usage: %s P N steps geometry(0 affine|1 general G|2 in-kernel) warp(0|1) [out.bin]\n", argv[0]);
     return 64;

@@ -40,6 +40,11 @@ def _signatures():
         "fus_comm_unique_id": [_vp],
         "fus_comm_create": [_vp, _int, _int, C.POINTER(_vp)],
         "fus_comm_create_local": [_int, _int, _int, C.POINTER(_vp)],
+        "fus_comm_create_peer": [_int, _int, C.POINTER(_vp)],
+        "fus_halo_ipc_blob_bytes": [_vp],
+        "fus_halo_ipc_export": [_vp, _vp],
+        "fus_halo_ipc_connect": [_vp, _int, _vp],
+        "fus_halo_ipc_status": [_vp, _vp],
         "fus_comm_rank": [_vp],
         "fus_comm_size": [_vp],
         "fus_comm_stream": [_vp],
@@ -94,6 +99,8 @@ TUNE_MASS_VARIANT = 3
 TUNE_PLAN_VARIANT = 4
 TUNE_PLAN_RUNS = 5
 
+ABI_VERSION = 2  # include/fus_gpu.h FUS_ABI_VERSION
+
 _lib = None
 
 
@@ -117,9 +124,12 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = {"fus_stiffness_plan_bytes": _i64, "fus_plan_bytes": _i64, "fus_comm_stream": _vp,
-                      "fus_comm_last_error": C.c_char_p}.get(name, _int)
+                      "fus_halo_ipc_blob_bytes": _i64, "fus_comm_last_error": C.c_char_p}.get(name, _int)
     lib.fus_error_string.argtypes = [_int]
     lib.fus_error_string.restype = C.c_char_p
+    if lib.fus_abi_version() != ABI_VERSION:
+        raise FusGpuError(f"{LIB_PATH}: ABI version {lib.fus_abi_version()}, this package needs {ABI_VERSION} "
+                          "(include/fus_gpu.h FUS_ABI_VERSION): rebuild the library")
     _lib = lib
     return lib
 

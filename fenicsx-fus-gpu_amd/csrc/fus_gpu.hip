@@ -341,7 +341,7 @@ int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const v
 
 extern "C" {
 
-int fus_abi_version(void) { return 1; }
+int fus_abi_version(void) { return FUS_ABI_VERSION; }
 
 const char* fus_error_string(int code) {
   switch (code) {
@@ -694,8 +694,25 @@ int fus_comm_create(const void* id, int nranks, int rank, fus_comm_t* out) {
   return FUS_OK;
 }
 
+int fus_comm_create_peer(int nranks, int rank, fus_comm_t* out) {
+  if (!out || nranks < 1 || rank < 0 || rank >= nranks) return FUS_ERR_INVALID_ARGUMENT;
+  auto* c = new fus_comm;
+  c->c.kind = fus::Comm::PEER;
+  c->c.rank = rank;
+  c->c.nranks = nranks;
+  hipError_t e = fus::comm_make_stream(&c->c);
+  if (e != hipSuccess) {
+    if (c->c.stream) (void)hipStreamDestroy(c->c.stream);
+    delete c;
+    return hip_rc(e);
+  }
+  *out = c;
+  return FUS_OK;
+}
+
 int fus_comm_create_local(int world_id, int nranks, int rank, fus_comm_t* out) {
   if (!out || nranks < 1 || rank < 0 || rank >= nranks) return FUS_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lock(fus::local_worlds_mutex());
   auto& worlds = fus::local_worlds();
   std::shared_ptr<fus::LocalWorld> w = worlds[world_id].lock();
   if (!w) {
@@ -729,8 +746,14 @@ const char* fus_comm_last_error(fus_comm_t comm) {
 
 int fus_comm_destroy(fus_comm_t comm) {
   if (!comm) return FUS_OK;
+  if (comm->c.nhalos > 0) {  // a halo holds a pointer to its communicator: destroy the halos first
+    comm->c.last_error = "fus_comm_destroy: " + std::to_string(comm->c.nhalos) + " halo object(s) of this communicator are still alive";
+    return FUS_ERR_COMM;
+  }
   if (comm->c.stream) (void)hipStreamSynchronize(comm->c.stream);
+  if (comm->c.stream2) (void)hipStreamSynchronize(comm->c.stream2);
   if (comm->c.nccl) (void)fus::rccl().CommDestroy(comm->c.nccl);
+  if (comm->c.stream2 && comm->c.stream2 != comm->c.stream) (void)hipStreamDestroy(comm->c.stream2);
   if (comm->c.stream) (void)hipStreamDestroy(comm->c.stream);
   delete comm;
   return FUS_OK;
@@ -770,10 +793,13 @@ int fus_halo_create(fus_comm_t comm, int elem_bytes, int64_t nlocal, int64_t ngh
   h.nlocal = nlocal;
   h.nghost = nghost;
   h.direct = direct;
+  ++comm->c.nhalos;
+  const bool peer = comm->c.kind == fus::Comm::PEER;
   hipError_t e = fus::side_init(h.owners, n_owner_ranks, owner_ranks, owner_sizes, owners_idx, comm->c.stream);
   if (e == hipSuccess) e = fus::side_init(h.ghosts, n_ghost_ranks, ghost_ranks, ghost_sizes, ghosts_idx, comm->c.stream);
-  if (e == hipSuccess && no > 0) e = hipMalloc(&h.buf_owner, no * elem_bytes);
-  if (e == hipSuccess && ng > 0) e = hipMalloc(&h.buf_ghost, ng * elem_bytes);
+  if (e == hipSuccess && no > 0 && !peer) e = hipMalloc(&h.buf_owner, no * elem_bytes);
+  if (e == hipSuccess && ng > 0 && !peer) e = hipMalloc(&h.buf_ghost, ng * elem_bytes);
+  if (e == hipSuccess && peer) e = fus::halo_ipc_create(&h);
   for (hipEvent_t* ev : {&h.ev_ready, &h.ev_done, &h.ev_packed, &h.ev_pulled})
     if (e == hipSuccess) e = hipEventCreateWithFlags(ev, hipEventDisableTiming);
   if (e == hipSuccess) e = hipStreamSynchronize(comm->c.stream);  // the index lists came from host arrays the caller may free
@@ -782,6 +808,7 @@ int fus_halo_create(fus_comm_t comm, int elem_bytes, int64_t nlocal, int64_t ngh
     return hip_rc(e);
   }
   if (comm->c.kind == fus::Comm::LOCAL) {
+    std::lock_guard<std::mutex> lock(fus::local_worlds_mutex());
     auto& mine = comm->c.world->halos[comm->c.rank];
     h.index = (int)mine.size();
     mine.push_back(&h);
@@ -794,10 +821,14 @@ int fus_halo_destroy(fus_halo_t halo) {
   if (!halo) return FUS_OK;
   fus::Halo& h = halo->h;
   if (h.comm && h.comm->stream) (void)hipStreamSynchronize(h.comm->stream);
+  if (h.comm && h.comm->stream2) (void)hipStreamSynchronize(h.comm->stream2);
   if (h.comm && h.comm->kind == fus::Comm::LOCAL && h.comm->world) {
+    std::lock_guard<std::mutex> lock(fus::local_worlds_mutex());
     auto& mine = h.comm->world->halos[h.comm->rank];
     if (h.index < (int)mine.size() && mine[h.index] == &h) mine[h.index] = nullptr;
   }
+  if (h.comm) --h.comm->nhalos;
+  fus::halo_ipc_free(&h);
   fus::side_free(h.owners);
   fus::side_free(h.ghosts);
   if (h.buf_owner) (void)hipFree(h.buf_owner);
@@ -809,6 +840,23 @@ int fus_halo_destroy(fus_halo_t halo) {
 }
 
 int fus_halo_is_direct(fus_halo_t halo) { return halo ? (halo->h.direct ? 1 : 0) : FUS_ERR_INVALID_ARGUMENT; }
+
+int64_t fus_halo_ipc_blob_bytes(fus_halo_t halo) {
+  if (!halo || halo->h.comm->kind != fus::Comm::PEER) return FUS_ERR_INVALID_ARGUMENT;
+  return fus::halo_ipc_blob_bytes(&halo->h);
+}
+int fus_halo_ipc_export(fus_halo_t halo, void* blob) {
+  if (!halo || !blob || halo->h.comm->kind != fus::Comm::PEER) return FUS_ERR_INVALID_ARGUMENT;
+  return fus::halo_ipc_export(&halo->h, blob) == 0 ? FUS_OK : FUS_ERR_COMM;
+}
+int fus_halo_ipc_connect(fus_halo_t halo, int nblobs, const void* const* blobs) {
+  if (!halo || nblobs < 0 || (nblobs > 0 && !blobs) || halo->h.comm->kind != fus::Comm::PEER) return FUS_ERR_INVALID_ARGUMENT;
+  return fus::halo_ipc_connect(&halo->h, nblobs, blobs) == 0 ? FUS_OK : FUS_ERR_COMM;
+}
+int fus_halo_ipc_status(fus_halo_t halo, int64_t* out4) {
+  if (!halo || !out4 || halo->h.comm->kind != fus::Comm::PEER) return FUS_ERR_INVALID_ARGUMENT;
+  return fus::halo_ipc_status(&halo->h, out4) == 0 ? FUS_OK : FUS_ERR_COMM;
+}
 
 #define FUS_HALO_OP(NAME, FN, DIR)                                                  \
   int NAME(fus_halo_t halo, void* buffer, void* stream) {                           \

@@ -26,11 +26,14 @@
 //          GPUs): the receiver pulls each message with hipMemcpyAsync on its comm stream, ordered
 //          by events.  Host-side contract: every rank's *_begin of an exchange is called before any
 //          rank's *_end of it.
+//   PEER   halo_ipc.hpp: the neighbours' receive arenas are mapped once (HIP IPC handles exchanged by the
+//          host's bootstrap channel); an exchange is a send kernel that stores straight into the neighbour's
+//          arena and a receive kernel that waits on a sequence flag -- two kernels of a few registers that DO
+//          run next to a chip-filling operator launch, where RCCL's 264-register kernel does not.
 #pragma once
 
 #include <dlfcn.h>
 #include <hip/hip_runtime.h>
-#include <rccl/rccl.h>
 #include <stdint.h>
 
 #include <cstring>
@@ -41,6 +44,19 @@
 #include <vector>
 
 #include "halo.hpp"
+#include "halo_ipc.hpp"
+
+// The few RCCL declarations the dlopen'ed entry points need (rccl/rccl.h is not required to build the library).
+extern "C" {
+typedef struct ncclComm* ncclComm_t;
+typedef struct {
+  char internal[128];
+} ncclUniqueId;
+typedef int ncclResult_t;    // ncclSuccess == 0
+typedef int ncclDataType_t;  // ncclFloat32 == 7, ncclFloat64 == 8 (nccl.h, stable since NCCL 2.0)
+}
+constexpr ncclResult_t ncclSuccess = 0;
+constexpr ncclDataType_t ncclFloat32 = 7, ncclFloat64 = 8;
 
 namespace fus {
 
@@ -102,15 +118,22 @@ struct LocalWorld {  // LOCAL transport: the ranks of one process
 };
 
 struct Comm {
-  enum Kind { RCCL = 0, LOCAL = 1 } kind = RCCL;
+  enum Kind { RCCL = 0, LOCAL = 1, PEER = 2 } kind = RCCL;
   int rank = 0, nranks = 1, device = 0;
   ncclComm_t nccl = nullptr;
   std::shared_ptr<LocalWorld> world;
-  hipStream_t stream = nullptr;  // high priority: small exchange kernels between big operator kernels
+  hipStream_t stream = nullptr;   // high priority: small exchange kernels between big operator kernels
+  hipStream_t stream2 = nullptr;  // PEER: the receive kernels' stream (sends never queue behind a waiting receive)
+  int nhalos = 0;                 // live halo objects: the communicator outlives them
   std::string last_error;
 };
 
-inline std::map<int, std::weak_ptr<LocalWorld>>& local_worlds() {
+inline std::mutex& local_worlds_mutex() {
+  static std::mutex m;
+  return m;
+}
+
+inline std::map<int, std::weak_ptr<LocalWorld>>& local_worlds() {  // guarded by local_worlds_mutex()
   static std::map<int, std::weak_ptr<LocalWorld>> m;
   return m;
 }
@@ -121,7 +144,18 @@ inline hipError_t comm_make_stream(Comm* c) {
   if (e != hipSuccess) return e;
   e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
   if (e != hipSuccess) return e;
-  return hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
+  e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
+  if (e == hipSuccess && c->kind == Comm::PEER) {
+    // One stream by default: send, receive and -- when the host puts them there (fus_comm_stream) -- the boundary-cell
+    // kernels between a forward and a reverse exchange follow each other in stream order, with no event edge between
+    // them.  FUS_IPC_TWO_STREAMS=1: receive kernels on a stream of their own.
+    const char* two = std::getenv("FUS_IPC_TWO_STREAMS");
+    if (two && two[0] == '1')
+      e = hipStreamCreateWithPriority(&c->stream2, hipStreamNonBlocking, hi);
+    else
+      c->stream2 = c->stream;
+  }
+  return e;
 }
 
 // ------------------------------------------------------------------------------------ halo plan
@@ -149,6 +183,7 @@ struct Halo {
   bool pulled_valid = false;
   const char* cur_send = nullptr;   // where my outgoing message lives for the exchange in flight
   int cur_dir = 0;                  // 0 forward, 1 reverse
+  IpcState ipc;                     // PEER transport state
 };
 
 inline void side_free(Side& s) {
@@ -250,6 +285,267 @@ inline hipError_t halo_wait_readers_local(Halo* h, const Side& sside) {
   return hipSuccess;
 }
 
+// ------------------------------------------------------------------------------------ PEER transport, host side
+inline void halo_ipc_free(Halo* h) {
+  IpcState& st = h->ipc;
+  for (void* p : st.opened) (void)hipIpcCloseMemHandle(p);
+  st.opened.clear();
+  ipc_role_free(st.send_fwd);
+  ipc_role_free(st.recv_fwd);
+  ipc_role_free(st.send_rev);
+  ipc_role_free(st.recv_rev);
+  if (st.arena) (void)hipFree(st.arena);
+  if (st.status) (void)hipFree(st.status);
+  if (st.ev_sent) (void)hipEventDestroy(st.ev_sent);
+  st.arena = nullptr;
+  st.status = nullptr;
+  st.ev_sent = nullptr;
+  st.connected = false;
+}
+
+// Arena layout: [flags: 4 kinds x nmax slots x 64 B][forward receive buffer: owners.total][reverse receive buffer: ghosts.total]
+inline hipError_t halo_ipc_create(Halo* h) {
+  IpcState& st = h->ipc;
+  st.nmax = (int)std::max<size_t>(1, std::max(h->owners.ranks.size(), h->ghosts.ranks.size()));
+  st.off_flags = 0;
+  st.off_recv_fwd = ipc_align(4ll * st.nmax * kIpcFlagStride, 256);
+  st.off_recv_rev = ipc_align(st.off_recv_fwd + h->owners.total * h->eb, 256);
+  const int64_t bytes = ipc_align(st.off_recv_rev + h->ghosts.total * h->eb, 256) + 256;
+  hipError_t e = ipc_arena_alloc(st, bytes);
+  if (e == hipSuccess) e = hipMalloc(&st.status, ST_WORDS * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMemset(st.status, 0, ST_WORDS * sizeof(uint64_t));
+  if (e == hipSuccess) e = ipc_role_init(st.send_fwd, h->ghosts.counts, h->ghosts.offsets);
+  if (e == hipSuccess) e = ipc_role_init(st.recv_rev, h->ghosts.counts, h->ghosts.offsets);
+  if (e == hipSuccess) e = ipc_role_init(st.recv_fwd, h->owners.counts, h->owners.offsets);
+  if (e == hipSuccess) e = ipc_role_init(st.send_rev, h->owners.counts, h->owners.offsets);
+  if (e == hipSuccess) e = hipEventCreateWithFlags(&st.ev_sent, hipEventDisableTiming);
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->comm->device);
+  double seconds = 20.0;
+  if (const char* v = std::getenv("FUS_IPC_SPIN_SECONDS")) seconds = std::atof(v) > 0 ? std::atof(v) : seconds;
+  st.budget = (uint64_t)(seconds * 1e3 * khz);
+  if (e == hipSuccess) e = hipDeviceSynchronize();  // arena zeroed before its handle can reach a peer
+  return e;
+}
+
+inline int64_t halo_ipc_blob_bytes(const Halo* h) {
+  return (int64_t)sizeof(IpcBlobHeader) + 3 * (int64_t)sizeof(int64_t) * (int64_t)(h->owners.ranks.size() + h->ghosts.ranks.size());
+}
+
+inline int halo_ipc_export(Halo* h, void* blob) {
+  Comm* c = h->comm;
+  IpcState& st = h->ipc;
+  IpcBlobHeader hd;
+  std::memset(&hd, 0, sizeof hd);
+  hd.magic = kIpcMagic;
+  hd.version = 1;
+  hd.rank = c->rank;
+  hd.elem_bytes = h->eb;
+  hd.pid = (int64_t)getpid();
+  hd.base = (uint64_t)(uintptr_t)st.arena;
+  hd.arena_bytes = st.arena_bytes;
+  hd.off_flags = st.off_flags;
+  hd.off_recv_fwd = st.off_recv_fwd;
+  hd.off_recv_rev = st.off_recv_rev;
+  hd.n_owner = (int32_t)h->owners.ranks.size();
+  hd.n_ghost = (int32_t)h->ghosts.ranks.size();
+  hd.nmax = st.nmax;
+  hd.device = c->device;
+  const hipError_t e = hipIpcGetMemHandle(&hd.handle, st.arena);
+  if (e != hipSuccess) {
+    c->last_error = std::string("hipIpcGetMemHandle: ") + hipGetErrorString(e);
+    return -1;
+  }
+  char* out = static_cast<char*>(blob);
+  std::memcpy(out, &hd, sizeof hd);
+  int64_t* t = reinterpret_cast<int64_t*>(out + sizeof hd);
+  for (const Side* s : {&h->owners, &h->ghosts})
+    for (size_t k = 0; k < s->ranks.size(); ++k) {
+      *t++ = s->ranks[k];
+      *t++ = s->counts[k];
+      *t++ = s->offsets[k];
+    }
+  return 0;
+}
+
+// ``blobs``: what fus_halo_ipc_export produced on the other ranks for THE SAME halo (same creation order), any order,
+// at least one per neighbour rank (extra ones are ignored).  Maps the neighbours' arenas and fills the device tables.
+inline int halo_ipc_connect(Halo* h, int nblobs, const void* const* blobs) {
+  Comm* c = h->comm;
+  IpcState& st = h->ipc;
+  if (st.connected) {
+    c->last_error = "halo already connected";
+    return -1;
+  }
+  struct PeerView {
+    const IpcBlobHeader* hd = nullptr;
+    const int64_t* owners = nullptr;  // (rank, count, offset) triples
+    const int64_t* ghosts = nullptr;
+    char* arena = nullptr;
+  };
+  std::map<int, PeerView> views;
+  for (int b = 0; b < nblobs; ++b) {
+    if (!blobs[b]) continue;
+    const auto* hd = static_cast<const IpcBlobHeader*>(blobs[b]);
+    if (hd->magic != kIpcMagic || hd->version != 1 || hd->elem_bytes != h->eb || hd->rank < 0 || hd->rank >= c->nranks) {
+      c->last_error = "halo connect: malformed or mismatching blob";
+      return -1;
+    }
+    PeerView v;
+    v.hd = hd;
+    v.owners = reinterpret_cast<const int64_t*>(static_cast<const char*>(blobs[b]) + sizeof(IpcBlobHeader));
+    v.ghosts = v.owners + 3 * hd->n_owner;
+    views[hd->rank] = v;
+  }
+  auto arena_of = [&](int rank, char** out) -> bool {
+    auto it = views.find(rank);
+    if (it == views.end()) {
+      c->last_error = "halo connect: no blob from neighbour rank " + std::to_string(rank);
+      return false;
+    }
+    PeerView& v = it->second;
+    if (!v.arena) {
+      if (v.hd->pid == (int64_t)getpid()) {
+        v.arena = reinterpret_cast<char*>((uintptr_t)v.hd->base);  // same address space (in-process ranks, self-neighbour)
+        if (rank != c->rank) st.defer_recv = true;
+      } else {
+        void* p = nullptr;
+        const hipError_t e = hipIpcOpenMemHandle(&p, v.hd->handle, hipIpcMemLazyEnablePeerAccess);
+        if (e != hipSuccess) {
+          c->last_error = "hipIpcOpenMemHandle (rank " + std::to_string(rank) + "): " + hipGetErrorString(e);
+          return false;
+        }
+        st.opened.push_back(p);
+        v.arena = static_cast<char*>(p);
+      }
+    }
+    *out = v.arena;
+    return true;
+  };
+  // slot of ``rank`` in a (rank, count, offset) triple list
+  auto find_slot = [](const int64_t* triples, int n, int rank) {
+    for (int k = 0; k < n; ++k)
+      if (triples[3 * k] == rank) return k;
+    return -1;
+  };
+  for (size_t i = 0; i < h->owners.ranks.size(); ++i) {  // my ghosts' owners: I receive forward, send reverse
+    if (h->owners.counts[i] == 0) continue;
+    char* pa = nullptr;
+    if (!arena_of(h->owners.ranks[i], &pa)) return -1;
+    const PeerView& v = views[h->owners.ranks[i]];
+    const int js = find_slot(v.ghosts, v.hd->n_ghost, c->rank);
+    if (js < 0 || v.ghosts[3 * js + 1] != h->owners.counts[i]) {
+      c->last_error = "halo connect: rank " + std::to_string(h->owners.ranks[i]) + " does not list this rank with the same count";
+      return -1;
+    }
+    IpcPeer& rf = st.recv_fwd.host_peers[i];
+    rf.data = st.arena + st.off_recv_fwd;
+    rf.flag_in = ipc_flag_ptr(st.arena, st.off_flags, st.nmax, ARRIVED_FWD, (int)i);
+    rf.flag_out = ipc_flag_ptr(pa, v.hd->off_flags, v.hd->nmax, CREDIT_FWD, js);
+    IpcPeer& sr = st.send_rev.host_peers[i];
+    sr.data = pa + v.hd->off_recv_rev + v.ghosts[3 * js + 2] * h->eb;
+    sr.flag_out = ipc_flag_ptr(pa, v.hd->off_flags, v.hd->nmax, ARRIVED_REV, js);
+    sr.flag_in = ipc_flag_ptr(st.arena, st.off_flags, st.nmax, CREDIT_REV, (int)i);
+  }
+  for (size_t j = 0; j < h->ghosts.ranks.size(); ++j) {  // ranks ghosting my dofs: I send forward, receive reverse
+    if (h->ghosts.counts[j] == 0) continue;
+    char* pa = nullptr;
+    if (!arena_of(h->ghosts.ranks[j], &pa)) return -1;
+    const PeerView& v = views[h->ghosts.ranks[j]];
+    const int is = find_slot(v.owners, v.hd->n_owner, c->rank);
+    if (is < 0 || v.owners[3 * is + 1] != h->ghosts.counts[j]) {
+      c->last_error = "halo connect: rank " + std::to_string(h->ghosts.ranks[j]) + " does not list this rank with the same count";
+      return -1;
+    }
+    IpcPeer& sf = st.send_fwd.host_peers[j];
+    sf.data = pa + v.hd->off_recv_fwd + v.owners[3 * is + 2] * h->eb;
+    sf.flag_out = ipc_flag_ptr(pa, v.hd->off_flags, v.hd->nmax, ARRIVED_FWD, is);
+    sf.flag_in = ipc_flag_ptr(st.arena, st.off_flags, st.nmax, CREDIT_FWD, (int)j);
+    IpcPeer& rr = st.recv_rev.host_peers[j];
+    rr.data = st.arena + st.off_recv_rev;
+    rr.flag_in = ipc_flag_ptr(st.arena, st.off_flags, st.nmax, ARRIVED_REV, (int)j);
+    rr.flag_out = ipc_flag_ptr(pa, v.hd->off_flags, v.hd->nmax, CREDIT_REV, is);
+  }
+  for (IpcRole* r : {&st.send_fwd, &st.recv_fwd, &st.send_rev, &st.recv_rev}) {
+    const hipError_t e = ipc_role_upload(*r);
+    if (e != hipSuccess) {
+      c->last_error = hipGetErrorString(e);
+      return -1;
+    }
+  }
+  st.connected = true;
+  return 0;
+}
+
+template <typename T>
+inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq) {
+  Comm* c = h->comm;
+  IpcState& st = h->ipc;
+  T* vec = reinterpret_cast<T*>(vecp);
+  const IpcRole& rr = dir == 0 ? st.recv_fwd : st.recv_rev;
+  if (rr.nchunks > 0) {
+    if (dir == 1)
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_ADD, true>), dim3(rr.nchunks), dim3(256), 0, c->stream2, vec, h->ghosts.idx_d,
+                         (int64_t)0, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
+    else if (h->direct)
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, false>), dim3(rr.nchunks), dim3(256), 0, c->stream2, vec, h->owners.idx_d,
+                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
+    else
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, true>), dim3(rr.nchunks), dim3(256), 0, c->stream2, vec, h->owners.idx_d,
+                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
+    const hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  return hipEventRecord(h->ev_done, c->stream2);
+}
+
+template <typename T>
+inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir) {
+  Comm* c = h->comm;
+  IpcState& st = h->ipc;
+  T* vec = reinterpret_cast<T*>(vecp);
+  const uint64_t seq = ++st.seq[dir];
+  const IpcRole& sr = dir == 0 ? st.send_fwd : st.send_rev;
+  if (sr.nchunks > 0) {
+    if (dir == 0)  // owned entries listed in ghosts.idx -> the ghosting ranks
+      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(256), 0, c->stream, vec, h->ghosts.idx_d, (int64_t)0,
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
+    else if (h->direct)  // ghost block, already grouped by owner -> the owners
+      hipLaunchKernelGGL((ipc_send_kernel<T, false>), dim3(sr.nchunks), dim3(256), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
+    else
+      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(256), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
+    hipError_t e = hipGetLastError();
+    if (e != hipSuccess) return e;
+  }
+  hipError_t e = hipEventRecord(st.ev_sent, c->stream);
+  if (e != hipSuccess) return e;
+  if (st.defer_recv) {  // ranks of ONE process: the receive kernel is posted by *_end (see IpcState::defer_recv)
+    st.pending[dir] = seq;
+    return hipSuccess;
+  }
+  return halo_ipc_post_recv<T>(h, vecp, dir, seq);
+}
+
+// time-outs seen by this halo's kernels (0 = healthy); synchronises the communicator's streams
+inline int halo_ipc_status(Halo* h, int64_t* out4) {
+  Comm* c = h->comm;
+  uint64_t w[ST_WORDS] = {0};
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && c->stream2) e = hipStreamSynchronize(c->stream2);
+  if (e == hipSuccess) e = hipMemcpy(w, h->ipc.status, sizeof w, hipMemcpyDeviceToHost);
+  if (e != hipSuccess) {
+    c->last_error = hipGetErrorString(e);
+    return -1;
+  }
+  out4[0] = (int64_t)w[ST_TIMEOUTS];
+  out4[1] = (int64_t)h->ipc.seq[0];
+  out4[2] = (int64_t)h->ipc.seq[1];
+  out4[3] = h->ipc.memory_kind;
+  return 0;
+}
+
 #define FUS_H(e_)                                \
   do {                                           \
     hipError_t _e = (e_);                        \
@@ -278,14 +574,34 @@ inline int halo_begin_group(Halo* const* hs, void* const* buffers, int nh, hipSt
     any = any || hs[k]->owners.total > 0 || hs[k]->ghosts.total > 0;
   }
   if (!any) return 0;  // no neighbours: nothing to order, nothing to move
-  FUS_H(hipEventRecord(hs[0]->ev_ready, stream));
-  FUS_H(hipStreamWaitEvent(c->stream, hs[0]->ev_ready, 0));
-  const char* sendbuf[8];
-  char* recvbuf[8];
   if (nh > 8) {
     c->last_error = "halo group: at most 8 vectors";
     return -1;
   }
+  if (c->kind == Comm::PEER)
+    for (int k = 0; k < nh; ++k)
+      if (!hs[k]->ipc.connected) {
+        c->last_error = "halo not connected: exchange the blobs of fus_halo_ipc_export and call fus_halo_ipc_connect first";
+        return -1;
+      }
+  if (c->kind == Comm::PEER) {
+    // the caller may BE on the communicator's stream (HaloApply's concurrent schedule): then stream order is all there is
+    if (stream != c->stream || stream != c->stream2) {
+      FUS_H(hipEventRecord(hs[0]->ev_ready, stream));
+      if (stream != c->stream) FUS_H(hipStreamWaitEvent(c->stream, hs[0]->ev_ready, 0));
+      if (stream != c->stream2 && c->stream2 != c->stream) FUS_H(hipStreamWaitEvent(c->stream2, hs[0]->ev_ready, 0));
+    }
+    for (int k = 0; k < nh; ++k) {
+      Halo* h = hs[k];
+      FUS_H(h->eb == 8 ? halo_ipc_post<double>(h, static_cast<char*>(buffers[k]), dir)
+                       : halo_ipc_post<float>(h, static_cast<char*>(buffers[k]), dir));
+    }
+    return 0;
+  }
+  FUS_H(hipEventRecord(hs[0]->ev_ready, stream));
+  FUS_H(hipStreamWaitEvent(c->stream, hs[0]->ev_ready, 0));
+  const char* sendbuf[8];
+  char* recvbuf[8];
   // ---- pack
   for (int k = 0; k < nh; ++k) {
     Halo* h = hs[k];
@@ -359,6 +675,15 @@ inline int halo_end(Halo* h, void* buffer, hipStream_t stream, int dir) {
       FUS_H(halo_kernel_any(h->eb, UNPACK_ADD, h->buf_ghost, vec, h->ghosts.idx_d, h->ghosts.total, 0, c->stream));
     }
     FUS_H(hipEventRecord(h->ev_done, c->stream));
+  }
+  if (c->kind == Comm::PEER) {
+    if (h->ipc.defer_recv && h->ipc.pending[dir]) {
+      const uint64_t seq = h->ipc.pending[dir];
+      h->ipc.pending[dir] = 0;
+      FUS_H(h->eb == 8 ? halo_ipc_post_recv<double>(h, vec, dir, seq) : halo_ipc_post_recv<float>(h, vec, dir, seq));
+    }
+    if (stream != c->stream) FUS_H(hipStreamWaitEvent(stream, h->ipc.ev_sent, 0));  // the send kernel has read the vector
+    if (stream == c->stream2) return 0;  // the caller is on the receive kernel's stream: already ordered
   }
   FUS_H(hipStreamWaitEvent(stream, h->ev_done, 0));
 #undef FUS_H

@@ -1,0 +1,289 @@
+// PEER transport of the ghost-dof halo exchange: no RCCL kernel, no copy engine call, no host in the loop.
+//
+// Replaces the same closures as halo_comm.hpp (cuda/scatterer.py:104-188 scatter_reverse, :191-277 scatter_forward:
+// pack kernel -> device synchronise -> MPI Isend/Irecv on device pointers -> wait -> unpack kernel -> synchronise).
+//
+// Why (profiles/r02z_overlap_probe.log, r03a_*): RCCL's send/recv kernel needs 264 VGPRs per lane and is not scheduled
+// next to an operator launch that holds every vector register of every CU, so an exchange posted "under" interior cells
+// ran after them (+41..46 us per apply).  hipMemcpyAsync into peer-mapped memory costs 150 us per hop on this runtime
+// (r03a_ipc_probe.log).  What does run next to the operator is a kernel of a few registers.  So each rank maps its
+// neighbours' receive arenas once (hipIpcGetMemHandle / hipIpcOpenMemHandle: xGMI stores between GPUs, plain stores
+// inside one GPU), and an exchange is two small kernels per rank:
+//
+//   send  (workgroup = 1024 message elements of ONE neighbour): wait until that neighbour has consumed the previous
+//         message (credit flag in MY arena), gather the elements from the vector and store them straight into the
+//         neighbour's receive buffer (write-through stores), wait for their acknowledgement; the last workgroup of a
+//         neighbour's segment publishes the exchange's sequence number in the neighbour's "arrived" flag;
+//   recv  wait (bounded) for the "arrived" flag of the chunk's neighbour in MY arena, read the chunk with system-scope
+//         loads, store (forward) or atomically add (reverse) it into the vector; the last workgroup of a segment
+//         returns the credit to the sender's arena.
+//
+// Flags carry sequence numbers (exchange 1, 2, ...), so nothing depends on the order in which the processes' hosts
+// issue their calls, and the hosts never synchronise with each other after the one-off exchange of the arena handles.
+// The arenas are fine-grained device memory (what RCCL's own peer-to-peer buffers are), so a reader never sees a stale
+// cache line.  Sends and receives run on two streams of the communicator: a send never waits for remote data, so
+// exchanges posted in different orders on different ranks cannot dead-lock.
+//
+// Every wait is bounded (FUS_IPC_SPIN_SECONDS, default 20 s of the device's wall clock): on a time-out the kernel records
+// it in the halo's status words, stops waiting for the rest of the run and drains; fus_halo_ipc_status() reports it.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <unistd.h>
+
+#include <algorithm>
+#include <cstdlib>
+#include <cstring>
+#include <string>
+#include <vector>
+
+#include "halo.hpp"
+
+namespace fus {
+
+constexpr int kIpcChunk = 1024;    // message elements per workgroup (256 threads x 4)
+constexpr int kIpcFlagStride = 64;  // bytes between two flags: one flag per 64-byte line
+constexpr uint32_t kIpcMagic = 0x46555349u;  // "FUSI"
+
+// flag kinds inside an arena; slot = index of the neighbour in the owners-side (kinds 0, 1) or ghosts-side (2, 3) list
+enum IpcFlag { ARRIVED_FWD = 0, CREDIT_REV = 1, ARRIVED_REV = 2, CREDIT_FWD = 3 };
+enum IpcStatus { ST_TIMEOUTS = 0, ST_DEAD = 1, ST_WORDS = 8 };
+
+struct IpcChunk {
+  int32_t nbr;    // neighbour slot on the side the kernel walks
+  int32_t count;  // elements in this chunk
+  int64_t start;  // element offset inside the side's concatenated index list
+};
+
+struct IpcPeer {       // one per neighbour slot and kernel role, in device memory
+  char* data;          // send: my segment inside the neighbour's receive buffer (mapped); recv: my receive buffer
+  uint64_t* flag_out;  // send: neighbour's "arrived" flag (mapped);  recv: neighbour's credit flag (mapped)
+  uint64_t* flag_in;   // send: my credit flag;                         recv: my "arrived" flag
+  int64_t seg_off;     // first element of the neighbour's segment in my concatenated list
+  int32_t nchunks;     // workgroups of this neighbour's segment
+  int32_t pad_;
+};
+
+// Memory ordering without fences.  A release / acquire fence at agent or system scope is an L2 write-back / invalidate on
+// gfx942 / gfx950 (buffer_wbl2 / buffer_inv): issued by every workgroup of an exchange next to an operator launch whose
+// scatter-adds keep the L2 full of dirty lines it cost +75 us per exchange (profiles/r03b_overlap.log).  Instead every
+// access to an arena is a RELAXED SYSTEM-SCOPE atomic -- a write-through store / cache-bypassing load (sc0 sc1) on memory
+// that is fine-grained anyway -- and the order "data before flag" is kept by waiting for the stores' acknowledgements
+// (s_waitcnt vmcnt(0)) before the workgroup barrier that precedes the flag store; on the reader's side the data loads
+// are issued after the barrier that follows the flag load.
+__device__ inline uint64_t ipc_load_flag(const uint64_t* f) {
+  return __hip_atomic_load(f, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+__device__ inline void ipc_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+
+// Wait until *flag >= want.  Bounded: gives up after ``budget`` wall-clock ticks, or at once if an earlier wait of this
+// halo has already timed out.
+__device__ inline int ipc_wait(const uint64_t* flag, uint64_t want, uint64_t* status, uint64_t budget) {
+  if (ipc_load_flag(flag) >= want) return 1;
+  if (__hip_atomic_load(&status[ST_DEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
+  const uint64_t t0 = wall_clock64();
+  for (;;) {
+    if (ipc_load_flag(flag) >= want) return 1;
+    __builtin_amdgcn_s_sleep(4);
+    if (wall_clock64() - t0 > budget) {
+      atomicAdd((unsigned long long*)&status[ST_TIMEOUTS], 1ull);
+      __hip_atomic_store(&status[ST_DEAD], (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 0;
+    }
+  }
+}
+
+// last workgroup of a neighbour's segment publishes ``seq`` in ``flag_out``
+__device__ inline void ipc_segment_done(unsigned* counter, int nchunks, uint64_t* flag_out, uint64_t seq) {
+  const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (done == (unsigned)nchunks - 1u) {  // every other workgroup's stores were acknowledged before it counted itself
+    __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(flag_out, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  }
+}
+
+template <typename T>
+__device__ inline T ipc_load_elem(const T* p);
+template <typename T>
+__device__ inline void ipc_store_elem(T* p, T v);
+template <>
+__device__ inline void ipc_store_elem<double>(double* p, double v) {
+  __hip_atomic_store(reinterpret_cast<uint64_t*>(p), (uint64_t)__double_as_longlong(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <>
+__device__ inline void ipc_store_elem<float>(float* p, float v) {
+  __hip_atomic_store(reinterpret_cast<uint32_t*>(p), __float_as_uint(v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+}
+template <>
+__device__ inline double ipc_load_elem<double>(const double* p) {
+  const uint64_t u = __hip_atomic_load(reinterpret_cast<const uint64_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __longlong_as_double((long long)u);
+}
+template <>
+__device__ inline float ipc_load_elem<float>(const float* p) {
+  const uint32_t u = __hip_atomic_load(reinterpret_cast<const uint32_t*>(p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+  return __uint_as_float(u);
+}
+
+// GATHER: element i of the message is vec[index[i] + offset]; otherwise vec[offset + i] (ghosts numbered owner by owner)
+template <typename T, bool GATHER>
+__global__ void __launch_bounds__(256)
+    ipc_send_kernel(const T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
+                    const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
+                    uint64_t* status, uint64_t seq, uint64_t budget) {
+  const IpcChunk c = chunks[blockIdx.x];
+  const IpcPeer p = peers[c.nbr];
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = ipc_wait(p.flag_in, seq - 1, status, budget);  // the neighbour has consumed message seq-1
+  __syncthreads();
+  if (ok) {
+    T* dst = reinterpret_cast<T*>(p.data) + (c.start - p.seg_off);
+    for (int e = threadIdx.x; e < c.count; e += 256) {
+      const int64_t i = c.start + e;
+      ipc_store_elem<T>(dst + e, vec[(GATHER ? index[i] : i) + offset]);
+    }
+  }
+  ipc_stores_done();  // my stores have reached the neighbour's memory before the flag can
+  __syncthreads();
+  if (threadIdx.x == 0) ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq);
+}
+
+// MODE: UNPACK_SET (forward: ghosts overwritten) or UNPACK_ADD (reverse: partial sums added into the owners' entries)
+template <typename T, int MODE, bool GATHER>
+__global__ void __launch_bounds__(256)
+    ipc_recv_kernel(T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
+                    const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
+                    uint64_t* status, uint64_t seq, uint64_t budget) {
+  const IpcChunk c = chunks[blockIdx.x];
+  const IpcPeer p = peers[c.nbr];
+  __shared__ int ok;
+  if (threadIdx.x == 0) ok = ipc_wait(p.flag_in, seq, status, budget);  // the neighbour's message seq is complete
+  __syncthreads();
+  if (ok) {
+    const T* src = reinterpret_cast<const T*>(p.data);
+    for (int e = threadIdx.x; e < c.count; e += 256) {
+      const int64_t i = c.start + e;
+      const T v = ipc_load_elem<T>(src + i);
+      const int64_t j = (GATHER ? index[i] : i) + offset;
+      if constexpr (MODE == UNPACK_SET)
+        vec[j] = v;
+      else
+        unsafeAtomicAdd(vec + j, v);
+    }
+  }
+  __syncthreads();  // every load of this chunk has been consumed
+  if (threadIdx.x == 0) ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq);
+}
+
+// ------------------------------------------------------------------------------------------- host side
+struct IpcSideInfo {  // what a peer needs to know about one side of my plan
+  std::vector<int32_t> ranks;
+  std::vector<int64_t> counts, offsets;
+};
+
+struct IpcRole {  // device tables of one kernel role (send or recv) over one side
+  IpcChunk* chunks = nullptr;
+  IpcPeer* peers = nullptr;
+  unsigned* counters = nullptr;
+  int nchunks = 0, nnbr = 0;
+  std::vector<IpcPeer> host_peers;
+};
+
+struct IpcBlobHeader {
+  uint32_t magic;
+  int32_t version;
+  int32_t rank;
+  int32_t elem_bytes;
+  int64_t pid;
+  uint64_t base;  // arena address in the exporting process (used directly when importer == exporter process)
+  hipIpcMemHandle_t handle;
+  int64_t arena_bytes;
+  int64_t off_flags, off_recv_fwd, off_recv_rev;
+  int32_t n_owner, n_ghost, nmax, device;
+  // followed by n_owner x (int64 rank, count, offset), then n_ghost x the same
+};
+
+struct IpcState {
+  char* arena = nullptr;  // fine-grained device memory: flags, forward receive buffer, reverse receive buffer
+  int64_t arena_bytes = 0, off_flags = 0, off_recv_fwd = 0, off_recv_rev = 0;
+  int nmax = 1;
+  uint64_t* status = nullptr;  // ST_WORDS words, ordinary device memory
+  bool connected = false;
+  std::vector<void*> opened;  // peer arenas mapped with hipIpcOpenMemHandle
+  IpcRole send_fwd, recv_fwd, send_rev, recv_rev;
+  uint64_t seq[2] = {0, 0};
+  // A receive kernel that waits occupies its hardware queue, and one process has only a few of them (4 by default) for
+  // all its streams.  One process per rank: every rank's send precedes its receive, no cycle.  Several ranks in ONE
+  // process (tests): rank A's waiting receive can sit in front of rank B's send in a shared queue.  There the receive
+  // kernel is posted by *_end, under the in-process contract of the LOCAL transport (every rank's *_begin before any
+  // rank's *_end), so it never waits for a send that has not been queued.
+  bool defer_recv = false;
+  uint64_t pending[2] = {0, 0};
+  uint64_t budget = 0;
+  hipEvent_t ev_sent = nullptr;
+  int memory_kind = 0;  // 0 fine-grained, 1 uncached, 2 ordinary
+};
+
+inline int64_t ipc_align(int64_t v, int64_t a) { return (v + a - 1) / a * a; }
+
+inline uint64_t* ipc_flag_ptr(char* arena, int64_t off_flags, int nmax, int kind, int slot) {
+  return reinterpret_cast<uint64_t*>(arena + off_flags + ((int64_t)kind * nmax + slot) * kIpcFlagStride);
+}
+
+inline void ipc_role_free(IpcRole& r) {
+  if (r.chunks) (void)hipFree(r.chunks);
+  if (r.peers) (void)hipFree(r.peers);
+  if (r.counters) (void)hipFree(r.counters);
+  r = IpcRole();
+}
+
+// chunk table of one side: every neighbour's segment cut into pieces of kIpcChunk elements
+inline hipError_t ipc_role_init(IpcRole& r, const std::vector<int64_t>& counts, const std::vector<int64_t>& offsets) {
+  std::vector<IpcChunk> ch;
+  r.nnbr = (int)counts.size();
+  r.host_peers.assign(r.nnbr, IpcPeer());
+  for (int k = 0; k < r.nnbr; ++k) {
+    int n = 0;
+    for (int64_t s = 0; s < counts[k]; s += kIpcChunk, ++n)
+      ch.push_back(IpcChunk{k, (int32_t)std::min<int64_t>(kIpcChunk, counts[k] - s), offsets[k] + s});
+    r.host_peers[k].nchunks = n;
+    r.host_peers[k].seg_off = offsets[k];
+  }
+  r.nchunks = (int)ch.size();
+  if (r.nchunks == 0) return hipSuccess;
+  hipError_t e = hipMalloc(&r.chunks, ch.size() * sizeof(IpcChunk));
+  if (e == hipSuccess) e = hipMemcpy(r.chunks, ch.data(), ch.size() * sizeof(IpcChunk), hipMemcpyHostToDevice);
+  if (e == hipSuccess) e = hipMalloc(&r.peers, r.nnbr * sizeof(IpcPeer));
+  if (e == hipSuccess) e = hipMalloc(&r.counters, r.nnbr * sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(r.counters, 0, r.nnbr * sizeof(unsigned));
+  return e;
+}
+
+inline hipError_t ipc_role_upload(IpcRole& r) {
+  if (r.nchunks == 0) return hipSuccess;
+  return hipMemcpy(r.peers, r.host_peers.data(), r.nnbr * sizeof(IpcPeer), hipMemcpyHostToDevice);
+}
+
+inline hipError_t ipc_arena_alloc(IpcState& st, int64_t bytes) {
+  const char* force = std::getenv("FUS_IPC_MEMORY");  // "finegrained" (default) | "uncached" | "coarse": experiments only
+  const int first = force ? (!std::strcmp(force, "uncached") ? 1 : !std::strcmp(force, "coarse") ? 2 : 0) : 0;
+  hipError_t e = hipErrorOutOfMemory;
+  for (int kind = first; kind < 3; ++kind) {
+    void* p = nullptr;
+    e = kind == 0   ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained)
+        : kind == 1 ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached)
+                    : hipMalloc(&p, bytes);
+    if (e == hipSuccess) {
+      st.arena = static_cast<char*>(p);
+      st.memory_kind = kind;
+      break;
+    }
+    (void)hipGetLastError();
+  }
+  if (e != hipSuccess) return e;
+  st.arena_bytes = bytes;
+  return hipMemset(st.arena, 0, bytes);
+}
+
+}  // namespace fus

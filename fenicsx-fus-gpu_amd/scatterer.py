@@ -73,6 +73,20 @@ class TorchComm:
     def barrier(self):
         dist.barrier(group=self.group)
 
+    def allgather_bytes(self, payload: bytes):
+        """Every rank's ``payload`` (host bytes of any length), as a list indexed by rank."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        n = torch.tensor([len(payload)], dtype=torch.int64, device=dev)
+        sizes = [torch.zeros_like(n) for _ in range(self.size)]
+        dist.all_gather(sizes, n, group=self.group)
+        sizes = [int(t.item()) for t in sizes]
+        mx = max(max(sizes), 1)
+        buf = torch.zeros(mx, dtype=torch.uint8)
+        buf[: len(payload)] = torch.frombuffer(bytearray(payload), dtype=torch.uint8) if payload else buf[:0]
+        out = [torch.zeros(mx, dtype=torch.uint8, device=dev) for _ in range(self.size)]
+        dist.all_gather(out, buf.to(dev), group=self.group)
+        return [bytes(t.cpu().numpy()[:sz].tobytes()) for t, sz in zip(out, sizes)]
+
 
 class NativeComm:
     """Communicator owned by libfusgpu.so (RCCL over xGMI; csrc/halo_comm.hpp).
@@ -83,26 +97,50 @@ class NativeComm:
     ``compute_scatterer_data``; in a 1-rank world no process group is needed.
     ``NativeComm(local=(world_id, nranks, rank))``: all ranks in THIS process (tests on a one-GPU
     box), transport = stream-ordered device copies; every rank's ``begin`` of an exchange must be
-    called before any rank's ``end``."""
+    called before any rank's ``end``.
 
-    def __init__(self, group=None, local=None):
+    ``transport="peer"`` (csrc/halo_ipc.hpp): no RCCL.  Each scatter closure owns a receive arena in fine-grained
+    device memory whose HIP IPC handle goes once to its neighbours (all-gathered through ``torch.distributed``, any
+    backend); an exchange is a send kernel that stores straight into the neighbours' arenas and a receive kernel that
+    waits for a sequence flag -- small kernels that run NEXT TO a chip-filling operator launch, which RCCL's
+    264-register kernel does not.  With ``local=...`` the ranks of one process use the same protocol (their arenas
+    are plain pointers to each other); the closures connect at their first exchange, when every rank has been built."""
+
+    _peer_local = {}  # (world_id, halo index) -> {rank: blob}: in-process PEER worlds
+
+    def __init__(self, group=None, local=None, transport="rccl"):
         import ctypes as C
 
+        if transport not in ("rccl", "peer"):
+            raise ValueError(f"transport must be 'rccl' or 'peer', got {transport!r}")
         lib = _lib.load()
         self._lib = lib
         self.handle = C.c_void_p()
         self._torch = None
+        self.transport = transport
+        self._stream = None
+        self._world_id = None
+        self._nhalos = 0
         if local is not None:
             world_id, self.size, self.rank = (int(v) for v in local)
-            self.backend = "local"
-            _lib.check(lib.fus_comm_create_local(world_id, self.size, self.rank, C.byref(self.handle)), "fus_comm_create_local")
+            self._world_id = world_id
+            if transport == "peer":
+                self.backend = "peer-local"
+                _lib.check(lib.fus_comm_create_peer(self.size, self.rank, C.byref(self.handle)), "fus_comm_create_peer")
+            else:
+                self.backend = "local"
+                _lib.check(lib.fus_comm_create_local(world_id, self.size, self.rank, C.byref(self.handle)), "fus_comm_create_local")
             return
-        self.backend = "rccl"
         if dist.is_available() and dist.is_initialized():
             self._torch = TorchComm(group)
             self.rank, self.size = self._torch.rank, self._torch.size
         else:
             self.rank, self.size = 0, 1
+        if transport == "peer":
+            self.backend = "peer"
+            _lib.check(lib.fus_comm_create_peer(self.size, self.rank, C.byref(self.handle)), "fus_comm_create_peer")
+            return
+        self.backend = "rccl"
         uid = torch.zeros(128, dtype=torch.uint8)
         if self.rank == 0:
             buf = C.create_string_buffer(128)
@@ -128,14 +166,58 @@ class NativeComm:
 
     def close(self):
         if self.handle:
-            self._lib.fus_comm_destroy(self.handle)
-            self.handle = None
+            if self._lib.fus_comm_destroy(self.handle) == 0:  # refused while halo objects are alive
+                self.handle = None
+        if self._world_id is not None and self.transport == "peer":
+            for key in [k for k in NativeComm._peer_local if k[0] == self._world_id]:
+                NativeComm._peer_local[key].pop(self.rank, None)
+                if not NativeComm._peer_local[key]:
+                    del NativeComm._peer_local[key]
 
     def __del__(self):
         try:
             self.close()
         except Exception:
             pass
+
+    def stream(self):
+        """The library-owned high-priority stream the exchanges run on, as a torch stream (``fus_comm_stream``)."""
+        if self._stream is None:
+            ptr = self._lib.fus_comm_stream(self.handle)
+            self._stream = torch.cuda.ExternalStream(int(ptr)) if ptr else None
+        return self._stream
+
+    # ---- PEER transport: hand a halo object's arena handle to its neighbours
+    def _peer_connect(self, halo_handle, index, lazy_ok=True):
+        """Connect halo object number ``index`` of this rank with the other ranks' object number ``index``.
+        Returns False if (in-process world) some rank has not built its object yet: retried at the first exchange."""
+        import ctypes as C
+
+        lib = self._lib
+        n = int(lib.fus_halo_ipc_blob_bytes(halo_handle))
+        if n <= 0:
+            raise _lib.FusGpuError("fus_halo_ipc_blob_bytes failed")
+        buf = C.create_string_buffer(n)
+        _lib.check(lib.fus_halo_ipc_export(halo_handle, buf), "fus_halo_ipc_export", self.handle)
+        mine = bytes(buf.raw)
+        if self._world_id is not None:
+            reg = NativeComm._peer_local.setdefault((self._world_id, index), {})
+            if self.rank in reg and reg[self.rank] != mine:  # a new world re-uses the id: drop the old world's handles
+                reg.clear()
+            reg[self.rank] = mine
+            if len(reg) < self.size:
+                if lazy_ok:
+                    return False
+                raise _lib.FusGpuError(f"PEER halo {index}: only ranks {sorted(reg)} of {self.size} have built their closure")
+            blobs = [reg[r] for r in range(self.size)]
+        elif self._torch is not None:
+            blobs = self._torch.allgather_bytes(mine)
+        else:
+            blobs = [mine]
+        keep = [C.create_string_buffer(b, len(b)) for b in blobs]
+        arr = (C.c_void_p * len(keep))(*[C.cast(k, C.c_void_p) for k in keep])
+        _lib.check(lib.fus_halo_ipc_connect(halo_handle, len(keep), arr), "fus_halo_ipc_connect", self.handle)
+        return True
 
 
 class _NativeScatter:
@@ -167,14 +249,39 @@ class _NativeScatter:
                                     len(o_ranks), keep[0][1], keep[1][1], keep[2][1],
                                     len(g_ranks), keep[3][1], keep[4][1], keep[5][1], C.byref(self.handle)),
                 "fus_halo_create", comm.handle)
+            self._index = comm._nhalos
+            comm._nhalos += 1
         self.nghost = None
         self.direct = bool(lib.fus_halo_is_direct(self.handle) == 1)
         self.active = True
         sfx = "reverse" if reverse else "forward"
         self._begin, self._end = getattr(lib, f"fus_halo_{sfx}_begin"), getattr(lib, f"fus_halo_{sfx}_end")
+        # PEER transport: map the neighbours' arenas (collective all-gather of the handles; in-process worlds connect
+        # at the first exchange, when all ranks exist)
+        self._connected = True
+        if halo is None and getattr(comm, "transport", "rccl") == "peer":
+            self._connected = comm._peer_connect(self.handle, self._index)
+
+    def _ensure_connected(self):
+        owner = self._owner if self._owner is not None else self
+        if not owner._connected:
+            owner._connected = self.comm._peer_connect(owner.handle, owner._index, lazy_ok=False)
+
+    def status(self):
+        """PEER transport: ``{"timeouts": device-side waits that gave up (0 = healthy), ...}`` (synchronises)."""
+        import ctypes as C
+
+        if getattr(self.comm, "transport", "rccl") != "peer":
+            return {"timeouts": 0}
+        out = (C.c_int64 * 4)()
+        _lib.check(self._lib.fus_halo_ipc_status(self.handle, out), "fus_halo_ipc_status", self.comm.handle)
+        return {"timeouts": int(out[0]), "forward_posted": int(out[1]), "reverse_posted": int(out[2]),
+                "arena_memory": ("fine-grained", "uncached", "ordinary")[int(out[3])]}
 
     def begin(self, buffer):
         _lib.require_device_tensor(buffer, self.dtype, "buffer")
+        if not self._connected or (self._owner is not None and not self._owner._connected):
+            self._ensure_connected()
         _lib.check(self._begin(self.handle, buffer.data_ptr(), _lib.stream_ptr()), "fus_halo_begin", self.comm.handle)
         return None
 
@@ -317,6 +424,7 @@ def begin_all(pairs):
             and len({sc.reverse for sc in native}) == 1 and len(pairs) <= 8:
         for sc, vec in pairs:
             _lib.require_device_tensor(vec, sc.dtype, "buffer")
+            sc._ensure_connected()
         halos = (C.c_void_p * len(pairs))(*[sc.handle for sc, _ in pairs])
         bufs = (C.c_void_p * len(pairs))(*[vec.data_ptr() for _, vec in pairs])
         fn = getattr(_lib.load(), "fus_halo_reverse_begin_group" if native[0].reverse else "fus_halo_forward_begin_group")
@@ -359,7 +467,8 @@ class HaloApply:
     become resident next to it and stay resident under the large launch that follows.
     """
 
-    def __init__(self, mesh, op, comm, float_type, overlap=True, kernels=None, apply_fn=None, plan=None, lead_cells="auto"):
+    def __init__(self, mesh, op, comm, float_type, overlap=True, kernels=None, apply_fn=None, plan=None, lead_cells="auto",
+                 schedule="auto"):
         from .utils import compute_scatterer_data_flat
 
         self.mesh = mesh
@@ -375,6 +484,23 @@ class HaloApply:
         nb, nc = mesh.num_boundary_cells, mesh.ncells
         mid = nb + (nc - nb) // 2
         has_neighbours = (len(self.neighbour_ranks()) > 0)
+        import os as _os
+
+        # "concurrent" (csrc/halo_ipc.hpp transports): ONE launch over all interior cells on the caller's stream; the
+        # boundary cells and both exchanges on a high-priority side stream next to it (profiles/r03a_overlap_local.log:
+        # a same-shape kernel on a second stream takes the workgroup slots the interior launch frees, so the apply is
+        # not cut into three launches).  "split": interior half | boundary | interior half on one stream, the form
+        # RCCL's kernel needs (with lead slices).
+        if schedule == "auto":
+            schedule = _os.environ.get("FUS_HALO_SCHEDULE", "auto")
+        if schedule == "auto":
+            small_kernels = isinstance(comm, NativeComm) and comm.backend in ("peer", "peer-local", "local")
+            schedule = "concurrent" if (small_kernels and apply_fn is None) else "split"
+        if schedule not in ("concurrent", "split"):
+            raise ValueError(f"schedule must be 'auto', 'concurrent' or 'split', got {schedule!r}")
+        self.schedule_kind = schedule if overlap else "sequential"
+        if schedule == "concurrent":
+            lead_cells = 0  # lead slices exist for RCCL's kernel only
         if lead_cells == "auto":
             lead = self._auto_lead_cells(mesh)
             if (nc - nb) < 8 * lead:  # mesh too small to slice
@@ -385,7 +511,8 @@ class HaloApply:
             lead = 0
         self.lead_cells = lead
         self.ranges = {"boundary": (0, nb), "lead1": (nb, nb + lead), "interior1": (nb + lead, mid),
-                       "lead2": (mid, mid + lead), "interior2": (mid + lead, nc)}
+                       "lead2": (mid, mid + lead), "interior2": (mid + lead, nc), "interior": (nb, nc)}
+        self._events = None
         self._views_cache = {}
         self._apply_fn = apply_fn  # tests: CPU stand-in for the operator
         import os
@@ -419,7 +546,9 @@ class HaloApply:
 
     def _halo_stream(self):
         if self._hs is None:
-            self._hs = torch.cuda.Stream(priority=-1)  # high priority: small kernels between big ones
+            lib_stream = self.comm.stream() if isinstance(self.comm, NativeComm) and self.comm.backend != "rccl" else None
+            # high priority: small kernels between big ones
+            self._hs = lib_stream if lib_stream is not None else torch.cuda.Stream(priority=-1)
         return self._hs
 
     def _views(self, name, percell):
@@ -464,6 +593,34 @@ class HaloApply:
             yield "reverse"
             for sc, vec, wk in rv:
                 sc.end(vec, wk)
+            return
+        if self.schedule_kind == "concurrent" and len(forward) > 0 and forward[0][1].is_cuda:
+            # main stream: ONE launch over all interior cells.  Side stream (the communicator's own high-priority stream
+            # where the library has one: send, receive and the boundary kernels then follow each other in stream order,
+            # no event edge between them): forward exchange -> boundary cells -> reverse exchange.
+            main, side = torch.cuda.current_stream(), self._halo_stream()
+            if self._events is None:
+                self._events = (torch.cuda.Event(), torch.cuda.Event())
+            ev_start, ev_side = self._events
+            ev_start.record(main)
+            side.wait_event(ev_start)
+            with torch.cuda.stream(side):
+                fw = begin_all(forward)
+            yield "forward"
+            part("interior")
+            with torch.cuda.stream(side):
+                for sc, vec, wk in fw:
+                    sc.end(vec, wk)
+                part("boundary")
+                if boundary_terms is not None:
+                    boundary_terms()
+                rv = begin_all(reverse)
+            yield "reverse"
+            with torch.cuda.stream(side):
+                for sc, vec, wk in rv:
+                    sc.end(vec, wk)
+                ev_side.record(side)
+            main.wait_event(ev_side)
             return
         on_gpu = self.side_stream and len(forward) > 0 and forward[0][1].is_cuda and not isinstance(self.comm, NativeComm)
         if not on_gpu:
@@ -540,7 +697,7 @@ class HaloApply:
         communicator up (RCCL creates its channels on first use) with two no-effect exchanges --
         a forward scatter of x (ghosts receive their owners' values) and a reverse scatter of a
         zero vector."""
-        for name in ("lead1", "interior1", "boundary", "lead2", "interior2"):
+        for name in self._launch_names():
             a, b = self.ranges[name]
             if b > a and self.op is not None and hasattr(self.op, "prepare"):
                 self.op.prepare(self._views(name, (cell_constants, G, dofmap))[2])
@@ -550,8 +707,22 @@ class HaloApply:
     def apply_local_only(self, x, cell_constants, y, G, dofmap):
         """The three kernel launches without any exchange (bench: kernel time at N > 1)."""
         fn = self._apply_fn if self._apply_fn is not None else self.op
-        for name in ("lead1", "interior1", "boundary", "lead2", "interior2"):
+        for name in self._launch_names():
             a, b = self.ranges[name]
             if b > a:
                 c_, G_, d_ = self._views(name, (cell_constants, G, dofmap))
                 fn(x, c_, y, G_, d_)
+
+    def _launch_names(self):
+        """The cell sub-ranges this schedule launches, in issue order."""
+        if self.schedule_kind == "concurrent":
+            return ("boundary", "interior")
+        return ("lead1", "interior1", "boundary", "lead2", "interior2")
+
+    def health(self):
+        """PEER transport: device-side time-outs of both closures (0 = healthy); synchronises the exchange streams."""
+        n = 0
+        for sc in (self.fwd, self.rev):
+            if hasattr(sc, "status"):
+                n += int(sc.status().get("timeouts", 0))
+        return n

@@ -41,6 +41,17 @@ extern "C" {
 #define FUS_MIN_DEGREE 1
 #define FUS_MAX_DEGREE 10 /* the reference's quadrature-degree map covers P = 2..10 */
 
+/*
+ * ABI version, bumped on every incompatible change (a host checks fus_abi_version() == FUS_ABI_VERSION at load):
+ *   1  rounds 1-2
+ *   2  FUS_TUNE_PLAN_THREADS removed, FUS_TUNE_PLAN_RUNS is an apply-time setting, the last argument of
+ *      fus_rk4_stage_* is a 4-valued stage kind, planned applies return FUS_ERR_PLAN_MISMATCH for a workspace that
+ *      was not built and registered through this library at that address, fus_comm_destroy refuses while halo
+ *      objects of the communicator are alive; new: the PEER halo transport (fus_comm_create_peer, fus_halo_ipc_*).
+ * There are deliberately NO fus_cpu_* twins of the entry points (SURVEY.md 8b proposed them): a CPU path inside the
+ * product would be a silent fallback; the CPU restatement lives in oracle/ and is test infrastructure only.
+ */
+#define FUS_ABI_VERSION 2
 /* Library / device queries. */
 int fus_abi_version(void);
 const char* fus_error_string(int code);
@@ -71,7 +82,9 @@ int fus_stiffness_apply_f32(const float* x, const float* cell_constants, float* 
 /*
  * Batch plan for the gather/scatter side (optional fast path; same numerical contract).
  * Built once per dofmap on the device into a caller-owned workspace; see csrc/plan.hpp for the
- * layout.  The reference has no counterpart: its CUDA kernel issues one atomic per (cell, dof)
+ * layout.  Workspace contract: a planned apply accepts only a workspace that was BUILT through this library AT THAT
+ * ADDRESS (host-side registry; anything else is FUS_ERR_PLAN_MISMATCH): do not copy or relocate a built workspace,
+ * and call fus_plan_release(workspace) before freeing or reusing its memory.  The reference has no counterpart: its CUDA kernel issues one atomic per (cell, dof)
  * (cuda/operators.py:190).  The planned apply reads the plan INSTEAD of ``dofmap``.
  *   fus_stiffness_plan_bytes : workspace size in bytes for (P, ncell), or a negative error code
  *   fus_stiffness_plan_build : fill ``workspace`` (256-byte aligned) from ``dofmap``; asynchronous
@@ -332,6 +345,14 @@ int fus_unpack_rev_f32(const float* in, float* out, const int64_t* index, int64_
  * fus_comm_create_local: all ranks live in one process (tests on a one-GPU box; one process driving
  * several GPUs); ranks that pass the same world_id form a world.  Host-side contract of this transport:
  * every rank's *_begin of an exchange is called before any rank's *_end of it.
+ * fus_comm_create_peer: no RCCL.  Every halo object of such a communicator owns a receive arena in fine-grained
+ * device memory; the ranks exchange the arenas' HIP IPC handles once (fus_halo_ipc_export -> any all-gather the host
+ * has -> fus_halo_ipc_connect) and an exchange is then two small kernels per rank: a send kernel that stores straight
+ * into the neighbours' arenas (xGMI stores) and publishes a sequence flag, a receive kernel that waits for the flag
+ * and stores / adds into the vector (csrc/halo_ipc.hpp).  Unlike RCCL's send/recv kernel they fit next to a
+ * chip-filling operator launch, so the exchange really runs under interior-cell work.  No host-side contract between
+ * ranks; every device-side wait is bounded (FUS_IPC_SPIN_SECONDS, default 20) and reported by fus_halo_ipc_status.
+ * fus_comm_destroy fails (FUS_ERR_COMM) while halo objects of the communicator are alive.
  */
 #define FUS_UNIQUE_ID_BYTES 128
 typedef struct fus_comm* fus_comm_t;
@@ -339,6 +360,7 @@ typedef struct fus_halo* fus_halo_t;
 int fus_comm_unique_id(void* id /* FUS_UNIQUE_ID_BYTES */);
 int fus_comm_create(const void* id, int nranks, int rank, fus_comm_t* comm);
 int fus_comm_create_local(int world_id, int nranks, int rank, fus_comm_t* comm);
+int fus_comm_create_peer(int nranks, int rank, fus_comm_t* comm);
 int fus_comm_rank(fus_comm_t comm);
 int fus_comm_size(fus_comm_t comm);
 void* fus_comm_stream(fus_comm_t comm); /* the hipStream_t the exchanges run on */
@@ -362,6 +384,19 @@ int fus_halo_create(fus_comm_t comm, int elem_bytes, int64_t nlocal, int64_t ngh
                     const int64_t* ghosts_idx, fus_halo_t* halo);
 int fus_halo_is_direct(fus_halo_t halo);
 int fus_halo_destroy(fus_halo_t halo); /* before fus_comm_destroy of its communicator */
+/*
+ * PEER transport only: connect a halo object to its neighbours' arenas.  Collective in the sense that every rank
+ * exports the blob of ITS halo object number k and connects with the blobs of the other ranks' object number k
+ * (any order; the blobs of non-neighbours are ignored; a rank that is its own neighbour passes its own blob).
+ * The blobs are plain bytes (valid on this host only: they hold HIP IPC handles).  Destroy the halo objects only
+ * after the last exchange has completed on every rank.
+ * fus_halo_ipc_status: out4 = {device-side time-outs so far (0 = healthy), forward exchanges posted, reverse
+ * exchanges posted, arena memory kind (0 fine-grained, 1 uncached, 2 ordinary)}; synchronises the communicator's streams.
+ */
+int64_t fus_halo_ipc_blob_bytes(fus_halo_t halo);
+int fus_halo_ipc_export(fus_halo_t halo, void* blob);
+int fus_halo_ipc_connect(fus_halo_t halo, int nblobs, const void* const* blobs);
+int fus_halo_ipc_status(fus_halo_t halo, int64_t* out4);
 /*
  * forward: buffer[nlocal + g] = owner's value, for every ghost g          (scatter_forward, overwrite)
  * reverse: owner's buffer[i] += every ghosting rank's partial sum of i     (scatter_reverse, add)

@@ -1,0 +1,117 @@
+"""One rank of a multi-PROCESS world that shares cuda:0 (the pool has one GPU per box; on an 8-GPU node each rank has its
+own).  Halo transport = PEER (csrc/halo_ipc.hpp): arenas mapped across processes with HIP IPC handles, exchanges made of
+the send / receive kernels only.  torch.distributed (gloo) carries nothing but the one-off bootstrap.
+
+    python tests/_peer_worker.py <mode> <rank> <world> <port> <args...>
+
+modes
+  golden <fixture.npz> <dtype>     forward (twice) and reverse scatter of the reference closures' inputs == their outputs
+  apply <P> <nx> <ny> <nz> <gx> <gy> <gz> <ghost_order> <schedule>
+                                   HaloApply (two applies) on a partitioned perturbed box == the serial C oracle
+Prints PEER_WORKER_OK <rank> on success; any failure is a non-zero exit."""
+import os
+import sys
+
+import numpy as np
+
+ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+sys.path.insert(0, ROOT)
+sys.path.insert(0, os.path.join(ROOT, "tests"))
+
+
+def main():
+    mode, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
+    args = sys.argv[5:]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
+    os.environ.setdefault("FUS_IPC_SPIN_SECONDS", "10")
+    import torch
+    import torch.distributed as dist
+
+    import fusgpu_loader
+    from conftest import build_problem, pkg, ref_field, rel_l2
+    from halo_cpu import global_cell_constants
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    scat, boxmesh, utils = pkg("scatterer"), pkg("boxmesh"), pkg("utils")
+    comm = scat.NativeComm(transport="peer")
+    assert comm.backend == "peer" and comm.size == world and comm.rank == rank
+
+    if mode == "golden":
+        d = np.load(args[0])
+        dtype = np.dtype(args[1]).type
+        P, shape, grid = int(d["P"]), tuple(int(v) for v in d["shape"]), tuple(int(v) for v in d["grid"])
+        assert int(np.prod(grid)) == world
+        meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r) for r in range(world)]
+        od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+        m = meshes[rank]
+        fwd = scat.scatter_forward(comm, od[rank], gd[rank], m.nlocal, dtype)
+        rev = scat.scatter_reverse(comm, od[rank], gd[rank], m.nlocal, dtype)
+        for kind, sc in (("fwd", fwd), ("rev", rev)):
+            buf = torch.from_numpy(d[f"in_{rank}"].astype(dtype)).to(dev)
+            for _ in range(2 if kind == "fwd" else 1):  # forward is idempotent: the second one reuses arena + credits
+                sc(buf)
+            torch.cuda.synchronize()
+            ref, got = d[f"ref_{kind}_{rank}"], buf.cpu().numpy()
+            if kind == "fwd":
+                assert np.array_equal(got, ref.astype(dtype)), f"forward, rank {rank}"
+            else:
+                assert np.allclose(got, ref, rtol=0, atol=1e-13 if dtype == np.float64 else 2e-6), f"reverse, rank {rank}"
+        # many exchanges back to back: credits and sequence flags under load
+        v = torch.from_numpy(d[f"in_{rank}"].astype(dtype)).to(dev)
+        for _ in range(50):
+            fwd(v)
+        torch.cuda.synchronize()
+        assert np.array_equal(v.cpu().numpy(), d[f"ref_fwd_{rank}"].astype(dtype))
+        assert fwd.status()["timeouts"] == 0 and rev.status()["timeouts"] == 0
+        dist.barrier()  # nobody frees an arena a neighbour may still write a credit into
+        fwd.close(), rev.close()
+    elif mode == "apply":
+        P = int(args[0])
+        cells, grid = tuple(int(v) for v in args[1:4]), tuple(int(v) for v in args[4:7])
+        ghost_order = args[7] if args[7] in ("owner", "lex") else int(args[7])
+        schedule = args[8]
+        assert int(np.prod(grid)) == world
+        from oracle.oracle_c import OracleLib
+
+        ops, gll, pre = pkg("operators"), pkg("gll"), pkg("precompute")
+        pts, wts, D = gll.tabulate_1d(P)
+        n = P + 1
+        mesh = boxmesh.BoxMesh(P, cells, grid=grid, rank=rank, perturb=0.16, seed=3, ghost_order=ghost_order)
+        G = np.zeros((mesh.ncells, n**3, 6))
+        pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), mesh.ncells,
+                                              pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts)), gll.tensor_weights_3d(wts))
+        x = ref_field(mesh.dof_coordinates())
+        x[mesh.nlocal:] = -777.0  # ghosts are stale until the forward scatter
+        x_d, y_d = torch.from_numpy(x).to(dev), torch.zeros(mesh.ndofs, dtype=torch.float64, device=dev)
+        cc_d, G_d = torch.from_numpy(global_cell_constants(mesh)).to(dev), torch.from_numpy(G).to(dev)
+        dm_d = torch.from_numpy(mesh.dofmap).to(dev)
+        op = ops.stiffness_operator(P, D.flatten(), np.float64)
+        halo = scat.HaloApply(mesh, op, comm, np.float64, schedule=schedule)  # plan: index exchange over gloo
+        assert halo.schedule_kind == schedule
+        for _ in range(2):
+            y_d.zero_()
+            halo.apply(x_d, cc_d, y_d, G_d, dm_d)
+        torch.cuda.synchronize()
+        assert halo.health() == 0
+        pb = build_problem(P, cells, perturb=0.16, seed=3)
+        ms = pb["mesh"]
+        y_ser = np.zeros(ms.ndofs)
+        OracleLib().stiffness_apply(P, pb["D"], pb["x"], global_cell_constants(ms), y_ser, pb["G"], ms.dofmap)
+        lex = mesh.global_lexicographic_ids()
+        err = rel_l2(y_d.cpu().numpy()[: mesh.nlocal], y_ser[lex[: mesh.nlocal]])
+        assert err < 1e-12, f"rank {rank}: partitioned apply vs serial oracle {err}"
+        assert np.allclose(x_d.cpu().numpy(), pb["x"][lex], rtol=0, atol=1e-12), "ghosts not refreshed"
+        dist.barrier()
+        halo.fwd.close(), halo.rev.close()
+    else:
+        raise SystemExit(f"unknown mode {mode}")
+    comm.close()
+    dist.barrier()
+    dist.destroy_process_group()
+    print(f"PEER_WORKER_OK {rank}", flush=True)
+
+
+if __name__ == "__main__":
+    main()

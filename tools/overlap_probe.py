@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--max-channels", type=int, default=0, help="NCCL_MAX_NCHANNELS for the communicators created here")
     ap.add_argument("--apply-schedules", default="", help="comma-separated lead-slice sizes (cells) for the whole-apply sequence")
     ap.add_argument("--tail", action="store_true", help="apply schedules: also end the reverse region with a small slice")
+    ap.add_argument("--transport", default="native", choices=["native", "local", "peer"],
+                    help="native: RCCL to self; local: the library's in-process transport (pack + device copy + unpack, no RCCL kernel)")
+    ap.add_argument("--two-stream", action="store_true", help="also time boundary cells on a high-priority side stream next to ONE interior launch")
     ap.add_argument("--slice", default="", help="also time begin; op(slice 1); op(slice 2); ...; op(rest); end -- comma-separated cell fractions")
     a = ap.parse_args()
     if a.max_channels:
@@ -100,7 +103,13 @@ def main():
 
     tA = timed(lambda: op(x, cc, y, G, dm))
     print(f"A  op alone                                   {tA:8.1f} us", flush=True)
-    for name, comm in (("native", scat.NativeComm()),):
+    def make_comm(wid=[700]):
+        wid[0] += 1
+        if a.transport == "peer":  # the PEER protocol, the rank's own arena as its neighbour's
+            return scat.NativeComm(transport="peer")
+        return scat.NativeComm(local=(wid[0], 1, 0)) if a.transport == "local" else scat.NativeComm()
+
+    for name, comm in ((a.transport, make_comm()),):
         for dname, mk in (("forward", scat.scatter_forward), ("reverse", scat.scatter_reverse)):
             sc = mk(comm, od, gd, N, np.float64)
             sc(w)
@@ -145,7 +154,7 @@ def main():
         # the whole HaloApply sequence around one apply (forward exchange of x-like vector w, reverse exchange of
         # y-like vector w2), with a self-neighbour plan, for several launch schedules.  Cells: boundary = the first
         # 8 590 cells (859 batches, as a 54^3 block of a 2x2x2 partition has), interior = the rest.
-        comm = scat.NativeComm()
+        comm = make_comm()
         fwd, rev = scat.scatter_forward(comm, od, gd, N, np.float64), scat.scatter_reverse(comm, od, gd, N, np.float64)
         w2 = torch.zeros_like(w)
         nb, nc = 8590, mesh.ncells
@@ -197,10 +206,76 @@ def main():
                 rev.begin(w2)
                 run(A2)
 
+            if lead == 0:
+                # the "concurrent" schedule of HaloApply: ONE interior launch on this stream; forward wait, boundary cells
+                # and the reverse exchange on a high-priority side stream next to it
+                I_ = [rng_(nb, nc)]
+                side = comm.stream() if a.transport != "native" else torch.cuda.Stream(priority=-1)
+                ev_a, ev_b = torch.cuda.Event(), torch.cuda.Event()
+
+                def concurrent(halo=True):
+                    main = torch.cuda.current_stream()
+                    ev_a.record(main)
+                    side.wait_event(ev_a)
+                    with torch.cuda.stream(side):
+                        k1 = fwd.begin(w) if halo else None
+                    run(I_)
+                    with torch.cuda.stream(side):
+                        if halo:
+                            fwd.end(w, k1)
+                        run(B_)
+                        if halo:
+                            k2 = rev.begin(w2)
+                            rev.end(w2, k2)
+                        ev_b.record(side)
+                    main.wait_event(ev_b)
+
+                tc0, tc1 = timed(lambda: concurrent(False)), timed(concurrent)
+                print(f"schedule {'concurrent: interior | side stream: boundary':45s}: launches alone {tc0:7.1f} us | with both exchanges {tc1:7.1f} us | "
+                      f"exposed {tc1 - tc0:+6.1f} | vs single launch {tc1 - tA:+6.1f}", flush=True)
             t0_, t1_ = timed(plain), timed(with_halo)
             t2_, t3_ = timed(begins_only), timed(fwd_wait_only)
             print(f"schedule {name:45s}: launches alone {t0_:7.1f} us | with both exchanges {t1_:7.1f} us | exposed {t1_ - t0_:+6.1f} "
                   f"| vs single launch {t1_ - tA:+6.1f} | [diagnostic: posted, never waited for {t2_ - t0_:+6.1f}; forward wait only {t3_ - t0_:+6.1f}]", flush=True)
+    if a.two_stream:
+        # Can boundary cells on a second (high-priority) stream run NEXT TO one launch over all interior cells, taking the
+        # workgroup slots that launch frees, so that the apply is not cut into three launches on one stream?
+        nb, nc = 8590, mesh.ncells
+        mid = nb + (nc - nb) // 2
+        vb, vi = (cc[:nb], G[:nb], dm[:nb]), (cc[nb:], G[nb:], dm[nb:])
+        v1, v2 = (cc[nb:mid], G[nb:mid], dm[nb:mid]), (cc[mid:], G[mid:], dm[mid:])
+        for v in (vb, vi, v1, v2):
+            op.prepare(v[2])
+        main = torch.cuda.current_stream()
+        side = torch.cuda.Stream(priority=-1)
+        side_lo = torch.cuda.Stream(priority=0)
+
+        def one_stream():
+            op(x, *v1[:1], y, *v1[1:]), op(x, *vb[:1], y, *vb[1:]), op(x, *v2[:1], y, *v2[1:])
+
+        def two_launches():
+            op(x, *vi[:1], y, *vi[1:]), op(x, *vb[:1], y, *vb[1:])
+
+        def concurrent(st, delay_first=False):
+            def f():
+                ev = torch.cuda.Event()
+                ev.record(main)
+                st.wait_event(ev)
+                if delay_first:
+                    op(x, *vi[:1], y, *vi[1:])
+                with torch.cuda.stream(st):
+                    op(x, *vb[:1], y, *vb[1:])
+                    ev2 = torch.cuda.Event()
+                    ev2.record(st)
+                if not delay_first:
+                    op(x, *vi[:1], y, *vi[1:])
+                main.wait_event(ev2)
+            return f
+
+        print(f"two-stream: interior1|boundary|interior2 on one stream {timed(one_stream):7.1f} us | interior;boundary on one stream "
+              f"{timed(two_launches):7.1f} us | boundary on a high-priority stream posted BEFORE the interior launch {timed(concurrent(side)):7.1f} us | "
+              f"posted AFTER it {timed(concurrent(side, True)):7.1f} us | normal-priority side stream, after {timed(concurrent(side_lo, True)):7.1f} us "
+              f"| single launch {tA:7.1f} us", flush=True)
     dist.destroy_process_group()
 
 
