@@ -49,6 +49,9 @@ def _signatures():
         "fus_comm_size": [_vp],
         "fus_comm_stream": [_vp],
         "fus_comm_last_error": [_vp],
+        "fus_comm_fork": [_vp, _vp],
+        "fus_comm_join": [_vp, _vp],
+        "fus_comm_sync_timeouts": [_vp, _vp],
         "fus_comm_destroy": [_vp],
         "fus_halo_create": [_vp, _int, _i64, _i64, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp, C.POINTER(_vp)],
         "fus_halo_is_direct": [_vp],
@@ -127,6 +130,8 @@ def load():
                       "fus_halo_ipc_blob_bytes": _i64, "fus_comm_last_error": C.c_char_p}.get(name, _int)
     lib.fus_error_string.argtypes = [_int]
     lib.fus_error_string.restype = C.c_char_p
+    lib.fus_source_hash.argtypes = []
+    lib.fus_source_hash.restype = C.c_char_p
     if lib.fus_abi_version() != ABI_VERSION:
         raise FusGpuError(f"{LIB_PATH}: ABI version {lib.fus_abi_version()}, this package needs {ABI_VERSION} "
                           "(include/fus_gpu.h FUS_ABI_VERSION): rebuild the library")
@@ -135,6 +140,26 @@ def load():
 
 
 ERR_COMM = -5
+
+
+def tree_source_hash():
+    """The hash csrc/Makefile embeds (fus_source_hash()), recomputed from the sources in this tree."""
+    import hashlib
+    import re
+
+    csrc = os.path.join(_HERE, "csrc")
+    mk = open(os.path.join(csrc, "Makefile")).read()
+    names = re.search(r"^SRC = (.*)$", mk, re.M).group(1).split() + re.search(r"^HDR = (.*)$", mk, re.M).group(1).split()
+    h = hashlib.sha256()
+    for n in sorted(names):
+        with open(os.path.join(csrc, n), "rb") as f:
+            h.update(f.read())
+    return h.hexdigest()[:16]
+
+
+def built_from_tree():
+    """True if the loaded library was built from exactly the sources in this tree."""
+    return load().fus_source_hash().decode() == tree_source_hash()
 
 
 def check(rc: int, what: str = "", comm=None):

@@ -343,6 +343,11 @@ extern "C" {
 
 int fus_abi_version(void) { return FUS_ABI_VERSION; }
 
+#ifndef FUS_SOURCE_HASH
+#define FUS_SOURCE_HASH "unknown"
+#endif
+const char* fus_source_hash(void) { return FUS_SOURCE_HASH; }
+
 const char* fus_error_string(int code) {
   switch (code) {
     case FUS_OK: return "ok";
@@ -740,6 +745,25 @@ int fus_comm_rank(fus_comm_t comm) { return comm ? comm->c.rank : FUS_ERR_INVALI
 int fus_comm_size(fus_comm_t comm) { return comm ? comm->c.nranks : FUS_ERR_INVALID_ARGUMENT; }
 void* fus_comm_stream(fus_comm_t comm) { return comm ? comm->c.stream : nullptr; }
 
+int fus_comm_fork(fus_comm_t comm, void* stream) {
+  if (!comm) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::comm_fork_join(&comm->c, static_cast<hipStream_t>(stream), 0));
+}
+int fus_comm_join(fus_comm_t comm, void* stream) {
+  if (!comm) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::comm_fork_join(&comm->c, static_cast<hipStream_t>(stream), 1));
+}
+int fus_comm_sync_timeouts(fus_comm_t comm, int64_t* out) {
+  if (!comm || !out) return FUS_ERR_INVALID_ARGUMENT;
+  *out = 0;
+  if (!comm->c.sync_words) return FUS_OK;
+  uint64_t w = 0;
+  hipError_t e = hipStreamSynchronize(comm->c.stream);
+  if (e == hipSuccess) e = hipMemcpy(&w, comm->c.sync_words + 2 + fus::ST_TIMEOUTS, sizeof w, hipMemcpyDeviceToHost);
+  *out = (int64_t)w;
+  return hip_rc(e);
+}
+
 const char* fus_comm_last_error(fus_comm_t comm) {
   return comm ? comm->c.last_error.c_str() : g_comm_error.c_str();
 }
@@ -755,6 +779,7 @@ int fus_comm_destroy(fus_comm_t comm) {
   if (comm->c.nccl) (void)fus::rccl().CommDestroy(comm->c.nccl);
   if (comm->c.stream2 && comm->c.stream2 != comm->c.stream) (void)hipStreamDestroy(comm->c.stream2);
   if (comm->c.stream) (void)hipStreamDestroy(comm->c.stream);
+  if (comm->c.sync_words) (void)hipFree(comm->c.sync_words);
   delete comm;
   return FUS_OK;
 }

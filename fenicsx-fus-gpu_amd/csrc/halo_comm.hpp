@@ -125,6 +125,10 @@ struct Comm {
   hipStream_t stream = nullptr;   // high priority: small exchange kernels between big operator kernels
   hipStream_t stream2 = nullptr;  // PEER: the receive kernels' stream (sends never queue behind a waiting receive)
   int nhalos = 0;                 // live halo objects: the communicator outlives them
+  // event-free fork / join between a caller's stream and ``stream`` (comm_fork / comm_join below)
+  uint64_t* sync_words = nullptr;  // device: [0] fork flag, [1] join flag, [2..] status (ST_TIMEOUTS, ST_DEAD)
+  uint64_t sync_seq[2] = {0, 0};
+  uint64_t sync_budget = 0;
   std::string last_error;
 };
 
@@ -144,6 +148,10 @@ inline hipError_t comm_make_stream(Comm* c) {
   if (e != hipSuccess) return e;
   e = hipDeviceGetStreamPriorityRange(&lo, &hi);  // hi = numerically lowest = highest priority
   if (e != hipSuccess) return e;
+  if (const char* pr = std::getenv("FUS_COMM_PRIORITY")) {  // experiments: "normal" / "low" instead of the highest
+    if (!std::strcmp(pr, "normal")) hi = 0;
+    if (!std::strcmp(pr, "low")) hi = lo;
+  }
   e = hipStreamCreateWithPriority(&c->stream, hipStreamNonBlocking, hi);
   if (e == hipSuccess && c->kind == Comm::PEER) {
     // One stream by default: send, receive and -- when the host puts them there (fus_comm_stream) -- the boundary-cell
@@ -156,6 +164,62 @@ inline hipError_t comm_make_stream(Comm* c) {
       c->stream2 = c->stream;
   }
   return e;
+}
+
+// ------------------------------------------------------------------------------------ fork / join without events
+// Ordering a side stream after the caller's stream with an event costs the caller's stream 7 us per fork next to
+// chip-filling launches (the record is a marker with a cache write-back between the caller's kernels), the join
+// another 3-4 us (profiles/r03g_forkjoin.log).  A one-thread kernel in the caller's stream costs 2.4 us.  So:
+//   fork   caller's stream: signal kernel (flag = seq: runs when everything before it in that stream has completed);
+//          communicator's stream: a one-wave kernel that waits (bounded) for flag >= seq -- what follows it in that
+//          stream starts after it, by stream order;
+//   join   the same with the roles exchanged.
+// Data written before the signal kernel is visible after the wait kernel for the reason two consecutive kernels of one
+// stream see each other's data: every kernel ends with a release and starts with an acquire at device scope.
+__global__ void stream_signal_kernel(uint64_t* flag, uint64_t seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
+__global__ void stream_wait_kernel(const uint64_t* flag, uint64_t seq, uint64_t* status, uint64_t budget) {
+  if (threadIdx.x != 0) return;
+  if (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= seq) return;
+  if (__hip_atomic_load(&status[ST_DEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  const uint64_t t0 = wall_clock64();
+  while (__hip_atomic_load(flag, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < seq) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > budget) {
+      atomicAdd((unsigned long long*)&status[ST_TIMEOUTS], 1ull);
+      __hip_atomic_store(&status[ST_DEAD], (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+}
+
+inline hipError_t comm_sync_init(Comm* c) {
+  if (c->sync_words) return hipSuccess;
+  hipError_t e = hipMalloc(&c->sync_words, (2 + ST_WORDS) * sizeof(uint64_t));
+  if (e == hipSuccess) e = hipMemset(c->sync_words, 0, (2 + ST_WORDS) * sizeof(uint64_t));
+  int khz = 100000;
+  (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, c->device);
+  double seconds = 20.0;
+  if (const char* v = std::getenv("FUS_IPC_SPIN_SECONDS")) seconds = std::atof(v) > 0 ? std::atof(v) : seconds;
+  c->sync_budget = (uint64_t)(seconds * 1e3 * khz);
+  if (e == hipSuccess) e = hipDeviceSynchronize();
+  return e;
+}
+
+// which: 0 fork (``stream`` -> communicator's stream), 1 join (communicator's stream -> ``stream``)
+inline hipError_t comm_fork_join(Comm* c, hipStream_t stream, int which) {
+  if (stream == c->stream) return hipSuccess;
+  hipError_t e = comm_sync_init(c);
+  if (e != hipSuccess) return e;
+  const uint64_t seq = ++c->sync_seq[which];
+  hipStream_t from = which == 0 ? stream : c->stream, to = which == 0 ? c->stream : stream;
+  hipLaunchKernelGGL(stream_signal_kernel, dim3(1), dim3(1), 0, from, c->sync_words + which, seq);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(stream_wait_kernel, dim3(1), dim3(64), 0, to, c->sync_words + which, seq, c->sync_words + 2, c->sync_budget);
+  return hipGetLastError();
 }
 
 // ------------------------------------------------------------------------------------ halo plan
@@ -485,13 +549,13 @@ inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq)
   const IpcRole& rr = dir == 0 ? st.recv_fwd : st.recv_rev;
   if (rr.nchunks > 0) {
     if (dir == 1)
-      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_ADD, true>), dim3(rr.nchunks), dim3(256), 0, c->stream2, vec, h->ghosts.idx_d,
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_ADD, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->ghosts.idx_d,
                          (int64_t)0, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
     else if (h->direct)
-      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, false>), dim3(rr.nchunks), dim3(256), 0, c->stream2, vec, h->owners.idx_d,
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, false>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->owners.idx_d,
                          h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
     else
-      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, true>), dim3(rr.nchunks), dim3(256), 0, c->stream2, vec, h->owners.idx_d,
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->owners.idx_d,
                          h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
@@ -508,13 +572,13 @@ inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir) {
   const IpcRole& sr = dir == 0 ? st.send_fwd : st.send_rev;
   if (sr.nchunks > 0) {
     if (dir == 0)  // owned entries listed in ghosts.idx -> the ghosting ranks
-      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(256), 0, c->stream, vec, h->ghosts.idx_d, (int64_t)0,
+      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->ghosts.idx_d, (int64_t)0,
                          sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
     else if (h->direct)  // ghost block, already grouped by owner -> the owners
-      hipLaunchKernelGGL((ipc_send_kernel<T, false>), dim3(sr.nchunks), dim3(256), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
+      hipLaunchKernelGGL((ipc_send_kernel<T, false>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
                          sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
     else
-      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(256), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
+      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
                          sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;

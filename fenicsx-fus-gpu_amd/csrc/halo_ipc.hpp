@@ -10,7 +10,7 @@
 // neighbours' receive arenas once (hipIpcGetMemHandle / hipIpcOpenMemHandle: xGMI stores between GPUs, plain stores
 // inside one GPU), and an exchange is two small kernels per rank:
 //
-//   send  (workgroup = 1024 message elements of ONE neighbour): wait until that neighbour has consumed the previous
+//   send  (workgroup = up to 8192 message elements of ONE neighbour): wait until that neighbour has consumed the previous
 //         message (credit flag in MY arena), gather the elements from the vector and store them straight into the
 //         neighbour's receive buffer (write-through stores), wait for their acknowledgement; the last workgroup of a
 //         neighbour's segment publishes the exchange's sequence number in the neighbour's "arrived" flag;
@@ -42,7 +42,27 @@
 
 namespace fus {
 
-constexpr int kIpcChunk = 1024;    // message elements per workgroup (256 threads x 4)
+// Workgroup shape of the exchange kernels (FUS_IPC_THREADS x FUS_IPC_CHUNK message elements per workgroup), measured
+// next to the config-3 operator launch with config-4 messages (profiles/r03f_sweep.log, exposed cost of both exchanges
+// of an apply): 64..512 threads with 512..4096 elements all cost the same 11-13 us; 256-element workgroups cost 22 (too
+// many), 1024-thread workgroups 50 (a workgroup that needs 16 wave slots of one CU at once waits long for them next to
+// an operator that fills every CU).  Default 256 x 1024: the footprint of the operator workgroup it displaces.
+constexpr int kIpcMaxThreads = 1024;
+constexpr int kIpcEpt = 8;  // elements per thread at most: all loads issued before the first store
+inline int ipc_env_int(const char* name, int dflt, int lo, int hi) {
+  const char* v = std::getenv(name);
+  const int x = v ? std::atoi(v) : dflt;
+  return x < lo ? lo : (x > hi ? hi : x);
+}
+// workgroup size and message elements per workgroup of the exchange kernels (chunk <= threads * kIpcEpt)
+inline int ipc_threads() {
+  static const int t = ipc_env_int("FUS_IPC_THREADS", 256, 64, kIpcMaxThreads) / 64 * 64;
+  return t;
+}
+inline int ipc_chunk() {
+  static const int c = ipc_env_int("FUS_IPC_CHUNK", 1024, 64, ipc_threads() * kIpcEpt);
+  return c;
+}
 constexpr int kIpcFlagStride = 64;  // bytes between two flags: one flag per 64-byte line
 constexpr uint32_t kIpcMagic = 0x46555349u;  // "FUSI"
 
@@ -128,7 +148,7 @@ __device__ inline float ipc_load_elem<float>(const float* p) {
 
 // GATHER: element i of the message is vec[index[i] + offset]; otherwise vec[offset + i] (ghosts numbered owner by owner)
 template <typename T, bool GATHER>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kIpcMaxThreads)
     ipc_send_kernel(const T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
                     const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
                     uint64_t* status, uint64_t seq, uint64_t budget) {
@@ -139,9 +159,19 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   if (ok) {
     T* dst = reinterpret_cast<T*>(p.data) + (c.start - p.seg_off);
-    for (int e = threadIdx.x; e < c.count; e += 256) {
-      const int64_t i = c.start + e;
-      ipc_store_elem<T>(dst + e, vec[(GATHER ? index[i] : i) + offset]);
+    T v[kIpcEpt];
+#pragma unroll
+    for (int k = 0; k < kIpcEpt; ++k) {
+      const int e = (int)threadIdx.x + k * (int)blockDim.x;
+      if (e < c.count) {
+        const int64_t i = c.start + e;
+        v[k] = vec[(GATHER ? index[i] : i) + offset];
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kIpcEpt; ++k) {
+      const int e = (int)threadIdx.x + k * (int)blockDim.x;
+      if (e < c.count) ipc_store_elem<T>(dst + e, v[k]);
     }
   }
   ipc_stores_done();  // my stores have reached the neighbour's memory before the flag can
@@ -151,7 +181,7 @@ __global__ void __launch_bounds__(256)
 
 // MODE: UNPACK_SET (forward: ghosts overwritten) or UNPACK_ADD (reverse: partial sums added into the owners' entries)
 template <typename T, int MODE, bool GATHER>
-__global__ void __launch_bounds__(256)
+__global__ void __launch_bounds__(kIpcMaxThreads)
     ipc_recv_kernel(T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
                     const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
                     uint64_t* status, uint64_t seq, uint64_t budget) {
@@ -162,14 +192,26 @@ __global__ void __launch_bounds__(256)
   __syncthreads();
   if (ok) {
     const T* src = reinterpret_cast<const T*>(p.data);
-    for (int e = threadIdx.x; e < c.count; e += 256) {
-      const int64_t i = c.start + e;
-      const T v = ipc_load_elem<T>(src + i);
-      const int64_t j = (GATHER ? index[i] : i) + offset;
-      if constexpr (MODE == UNPACK_SET)
-        vec[j] = v;
-      else
-        unsafeAtomicAdd(vec + j, v);
+    T v[kIpcEpt];
+    int64_t j[kIpcEpt];
+#pragma unroll
+    for (int k = 0; k < kIpcEpt; ++k) {
+      const int e = (int)threadIdx.x + k * (int)blockDim.x;
+      if (e < c.count) {
+        const int64_t i = c.start + e;
+        v[k] = ipc_load_elem<T>(src + i);
+        j[k] = (GATHER ? index[i] : i) + offset;
+      }
+    }
+#pragma unroll
+    for (int k = 0; k < kIpcEpt; ++k) {
+      const int e = (int)threadIdx.x + k * (int)blockDim.x;
+      if (e < c.count) {
+        if constexpr (MODE == UNPACK_SET)
+          vec[j[k]] = v[k];
+        else
+          unsafeAtomicAdd(vec + j[k], v[k]);
+      }
     }
   }
   __syncthreads();  // every load of this chunk has been consumed
@@ -245,8 +287,9 @@ inline hipError_t ipc_role_init(IpcRole& r, const std::vector<int64_t>& counts, 
   r.host_peers.assign(r.nnbr, IpcPeer());
   for (int k = 0; k < r.nnbr; ++k) {
     int n = 0;
-    for (int64_t s = 0; s < counts[k]; s += kIpcChunk, ++n)
-      ch.push_back(IpcChunk{k, (int32_t)std::min<int64_t>(kIpcChunk, counts[k] - s), offsets[k] + s});
+    const int chunk = ipc_chunk();
+    for (int64_t s = 0; s < counts[k]; s += chunk, ++n)
+      ch.push_back(IpcChunk{k, (int32_t)std::min<int64_t>(chunk, counts[k] - s), offsets[k] + s});
     r.host_peers[k].nchunks = n;
     r.host_peers[k].seg_off = offsets[k];
   }

@@ -111,6 +111,17 @@ class WesterveltSpectral3D(StepGraphMixin):
         # so the cell pass is ONE plain stiffness apply on w = u_n + kappa v_n, which the vector kernel writes
         ratio = self.cc4 / self.cc3
         kmin, kmax = float(ratio.min().item()), float(ratio.max().item())
+        # the decision (and kappa itself) must be the SAME on every rank -- a rank in single-gather mode forward-scatters
+        # w where a neighbour in two-gather mode expects u_n, with matching counts, so nothing would hang and the result
+        # would be silently wrong: min / max over all ranks.  cc3 / cc4 must not be edited after construction.
+        if comm is not None and getattr(comm, "size", 1) > 1 and getattr(comm, "_world_id", None) is None:
+            import torch.distributed as dist
+
+            if dist.is_available() and dist.is_initialized():
+                on_gpu = dist.get_backend() == "nccl"
+                t = torch.tensor([-kmin, kmax], dtype=torch.float64, device=self.dev if on_gpu else "cpu")
+                dist.all_reduce(t, op=dist.ReduceOp.MAX)
+                kmin, kmax = -float(t[0].item()), float(t[1].item())
         self.kappa = kmin if abs(kmax - kmin) <= 1e-14 * max(abs(kmin), abs(kmax), 1e-300) else None
         if uniform_ratio is False:  # force the general (two-gather) cell pass
             self.kappa = None

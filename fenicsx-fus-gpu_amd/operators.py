@@ -67,6 +67,16 @@ class _PlanCache:
         self._plans = {}
         self.capacity = capacity
         self.last_order = None  # cell order of the plan built last (None: natural order)
+        self._recording = None  # while a hipGraph is captured: every (workspace, dofmap) handed out
+
+    def start_recording(self):
+        self._recording = []
+
+    def stop_recording(self):
+        """-> the (workspace, dofmap) tensors handed out since ``start_recording``: whoever baked their addresses
+        into a captured graph holds this list, so eviction from the cache cannot free them."""
+        held, self._recording = self._recording or [], None
+        return held
 
     def get(self, dofmap: torch.Tensor):
         """-> (workspace tensor, entities_per_batch)"""
@@ -112,6 +122,8 @@ class _PlanCache:
             # freed and handed to another array with the same address / shape / version
             hit = (ws, epb, dofmap)
             self._plans[key] = hit
+        if self._recording is not None:
+            self._recording.append((hit[0], hit[2]))
         return hit[0], hit[1]
 
     def clear(self):

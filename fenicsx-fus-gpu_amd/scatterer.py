@@ -73,6 +73,14 @@ class TorchComm:
     def barrier(self):
         dist.barrier(group=self.group)
 
+    def all_ok(self, ok: bool) -> bool:
+        """True iff ``ok`` on EVERY rank (one all-reduce): lets a set-up step fail on all ranks together instead of
+        leaving the healthy ones inside the next collective."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        t = torch.tensor([1.0 if ok else 0.0], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
+        return bool(t.item() == 1.0)
+
     def allgather_bytes(self, payload: bytes):
         """Every rank's ``payload`` (host bytes of any length), as a list indexed by rank."""
         dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
@@ -141,18 +149,31 @@ class NativeComm:
             _lib.check(lib.fus_comm_create_peer(self.size, self.rank, C.byref(self.handle)), "fus_comm_create_peer")
             return
         self.backend = "rccl"
-        uid = torch.zeros(128, dtype=torch.uint8)
-        if self.rank == 0:
-            buf = C.create_string_buffer(128)
-            _lib.check(lib.fus_comm_unique_id(buf), "fus_comm_unique_id")
-            uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        # Bootstrap that fails on ALL ranks or on none: (1) every rank probes librccl (dlopen + ncclGetUniqueId; only
+        # rank 0's id is used) and the ranks agree on the outcome BEFORE anything is broadcast; (2) rank 0's id is
+        # broadcast; (3) ncclCommInitRank, then the ranks agree again before any of them proceeds.
+        buf = C.create_string_buffer(128)
+        rc = lib.fus_comm_unique_id(buf)
+        err = None if rc == 0 else f"fus_comm_unique_id: {lib.fus_error_string(rc).decode()}: {(lib.fus_comm_last_error(None) or b'?').decode()}"
+        if self.size > 1 and not self._torch.all_ok(err is None):
+            raise _lib.FusGpuError(f"RCCL is not usable on every rank (this rank: {err or 'ok'}): no native communicator")
+        if err is not None:
+            raise _lib.FusGpuError(err)
+        uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
         if self.size > 1:
             dev = torch.device("cuda", torch.cuda.current_device()) if self._torch.backend == "nccl" else torch.device("cpu")
             t = uid.to(dev)
             dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
             uid = t.cpu()
         raw = bytes(uid.numpy().tobytes())
-        _lib.check(lib.fus_comm_create(raw, self.size, self.rank, C.byref(self.handle)), "fus_comm_create")
+        rc = lib.fus_comm_create(raw, self.size, self.rank, C.byref(self.handle))
+        err = None if rc == 0 else f"fus_comm_create: {lib.fus_error_string(rc).decode()}: {(lib.fus_comm_last_error(None) or b'?').decode()}"
+        if self.size > 1 and not self._torch.all_ok(err is None):
+            if err is None:
+                self.close()
+            raise _lib.FusGpuError(f"ncclCommInitRank did not succeed on every rank (this rank: {err or 'ok'})")
+        if err is not None:
+            raise _lib.FusGpuError(err)
 
     def alltoallv_int64(self, send_np, send_counts, recv_counts):
         """Set-up path (index exchange of compute_scatterer_data): through torch.distributed."""
@@ -187,6 +208,21 @@ class NativeComm:
             self._stream = torch.cuda.ExternalStream(int(ptr)) if ptr else None
         return self._stream
 
+    def fork(self):
+        """Order the communicator's stream after the caller's current stream, without an event (``fus_comm_fork``)."""
+        _lib.check(self._lib.fus_comm_fork(self.handle, _lib.stream_ptr()), "fus_comm_fork", self.handle)
+
+    def join(self):
+        """Order the caller's current stream after the communicator's stream, without an event (``fus_comm_join``)."""
+        _lib.check(self._lib.fus_comm_join(self.handle, _lib.stream_ptr()), "fus_comm_join", self.handle)
+
+    def sync_timeouts(self):
+        import ctypes as C
+
+        n = C.c_int64(0)
+        _lib.check(self._lib.fus_comm_sync_timeouts(self.handle, C.byref(n)), "fus_comm_sync_timeouts", self.handle)
+        return int(n.value)
+
     # ---- PEER transport: hand a halo object's arena handle to its neighbours
     def _peer_connect(self, halo_handle, index, lazy_ok=True):
         """Connect halo object number ``index`` of this rank with the other ranks' object number ``index``.
@@ -216,7 +252,12 @@ class NativeComm:
             blobs = [mine]
         keep = [C.create_string_buffer(b, len(b)) for b in blobs]
         arr = (C.c_void_p * len(keep))(*[C.cast(k, C.c_void_p) for k in keep])
-        _lib.check(lib.fus_halo_ipc_connect(halo_handle, len(keep), arr), "fus_halo_ipc_connect", self.handle)
+        rc = lib.fus_halo_ipc_connect(halo_handle, len(keep), arr)
+        if self._world_id is None and self._torch is not None and not self._torch.all_ok(rc == 0):
+            # a rank that cannot map a neighbour's arena must not leave the others waiting for its messages
+            detail = (lib.fus_comm_last_error(self.handle) or b"").decode() if rc != 0 else "ok here"
+            raise _lib.FusGpuError(f"PEER halo {index}: mapping the neighbours' arenas did not succeed on every rank ({detail})")
+        _lib.check(rc, "fus_halo_ipc_connect", self.handle)
         return True
 
 
@@ -522,6 +563,7 @@ class HaloApply:
         # apply (event traffic) for ~20 us of pack/unpack launches it could take off the main
         # stream on a real partition (profiles/r01f_host_overhead.log); to be re-measured on 8 GPUs.
         self.side_stream = os.environ.get("FUS_HALO_SIDE_STREAM", "0") == "1"
+        self._lib_sync = os.environ.get("FUS_HALO_EVENT_SYNC", "0") != "1"  # 1: fork / join the side stream with events
         self._hs = None
 
     def neighbour_ranks(self):
@@ -594,16 +636,22 @@ class HaloApply:
             for sc, vec, wk in rv:
                 sc.end(vec, wk)
             return
-        if self.schedule_kind == "concurrent" and len(forward) > 0 and forward[0][1].is_cuda:
+        if self.schedule_kind == "concurrent" and len(percell) > 0 and percell[0].is_cuda:
             # main stream: ONE launch over all interior cells.  Side stream (the communicator's own high-priority stream
             # where the library has one: send, receive and the boundary kernels then follow each other in stream order,
             # no event edge between them): forward exchange -> boundary cells -> reverse exchange.
             main, side = torch.cuda.current_stream(), self._halo_stream()
+            # fork / join: the library's event-free pair where the side stream is the communicator's (2.4 us on the
+            # caller's stream instead of 7 + 3.5 for event record / wait next to chip-filling launches); events otherwise
+            lib_sync = side is getattr(self.comm, "_stream", None) and self._lib_sync
             if self._events is None:
                 self._events = (torch.cuda.Event(), torch.cuda.Event())
             ev_start, ev_side = self._events
-            ev_start.record(main)
-            side.wait_event(ev_start)
+            if lib_sync:
+                self.comm.fork()
+            else:
+                ev_start.record(main)
+                side.wait_event(ev_start)
             with torch.cuda.stream(side):
                 fw = begin_all(forward)
             yield "forward"
@@ -619,8 +667,12 @@ class HaloApply:
             with torch.cuda.stream(side):
                 for sc, vec, wk in rv:
                     sc.end(vec, wk)
-                ev_side.record(side)
-            main.wait_event(ev_side)
+                if not lib_sync:
+                    ev_side.record(side)
+            if lib_sync:
+                self.comm.join()
+            else:
+                main.wait_event(ev_side)
             return
         on_gpu = self.side_stream and len(forward) > 0 and forward[0][1].is_cuda and not isinstance(self.comm, NativeComm)
         if not on_gpu:
@@ -713,6 +765,13 @@ class HaloApply:
                 c_, G_, d_ = self._views(name, (cell_constants, G, dofmap))
                 fn(x, c_, y, G_, d_)
 
+    def apply_no_exchange(self, x, cell_constants, y, G, dofmap):
+        """The launches of ``apply`` in its own schedule (streams, events, sub-ranges) with NO exchange: what cutting
+        the apply into sub-launches costs by itself (bench.py: ``halo_split_cost_ms``).  Not an apply."""
+        fn = self._apply_fn if self._apply_fn is not None else self.op
+        for _ in self.schedule(lambda c_, G_, d_: fn(x, c_, y, G_, d_), (cell_constants, G, dofmap), [], []):
+            pass
+
     def _launch_names(self):
         """The cell sub-ranges this schedule launches, in issue order."""
         if self.schedule_kind == "concurrent":
@@ -725,4 +784,6 @@ class HaloApply:
         for sc in (self.fwd, self.rev):
             if hasattr(sc, "status"):
                 n += int(sc.status().get("timeouts", 0))
+        if isinstance(self.comm, NativeComm) and self.comm.handle:
+            n += self.comm.sync_timeouts()
         return n

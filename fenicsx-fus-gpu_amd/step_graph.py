@@ -43,10 +43,22 @@ class StepGraphMixin:
             torch.cuda.synchronize()
             for t, s_ in zip(state, saved):
                 t.copy_(s_)
+            # the captured nodes hold the RAW device pointers of the batch-plan workspaces the operators looked up:
+            # keep those workspaces (and the dofmaps they belong to) alive for as long as the graph lives -- the plan
+            # cache is bounded and evicts oldest-first, and an evicted workspace that nothing else references would be
+            # freed under the graph's feet (replay does not go through the plan registry)
+            from . import operators as ops
+
             g = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(g):
-                self._graph_step_body(dt)
+            ops._PLANS.start_recording()
+            try:
+                with torch.cuda.graph(g):
+                    self._graph_step_body(dt)
+            finally:
+                held = ops._PLANS.stop_recording()
             self._graphs[dt] = g
+            self._graph_plans = getattr(self, "_graph_plans", {})
+            self._graph_plans[dt] = held
         return g
 
     def rk4_graph(self, start_time, final_time, dt, max_steps=None):

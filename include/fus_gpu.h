@@ -54,6 +54,9 @@ extern "C" {
 #define FUS_ABI_VERSION 2
 /* Library / device queries. */
 int fus_abi_version(void);
+/* First 16 hex digits of the SHA-256 of the sources (csrc/*.hip, *.hpp, this header, concatenated in sorted path order)
+ * the library was built from; "unknown" for a build outside csrc/Makefile. */
+const char* fus_source_hash(void);
 const char* fus_error_string(int code);
 /* name: >= 256 bytes or NULL; returns FUS_OK or FUS_ERR_NO_DEVICE. */
 int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_bytes, int* lds_bytes_per_cu);
@@ -364,6 +367,19 @@ int fus_comm_create_peer(int nranks, int rank, fus_comm_t* comm);
 int fus_comm_rank(fus_comm_t comm);
 int fus_comm_size(fus_comm_t comm);
 void* fus_comm_stream(fus_comm_t comm); /* the hipStream_t the exchanges run on */
+/*
+ * Event-free ordering between a caller's stream and the communicator's stream (any transport), for hosts that put
+ * work of their own on fus_comm_stream() -- e.g. the boundary-cell kernels between a forward and a reverse exchange,
+ * next to ONE launch over the interior cells on the caller's stream (scatterer.HaloApply, schedule "concurrent").
+ *   fus_comm_fork: what is enqueued on the communicator's stream from now on starts after everything enqueued on
+ *                  ``stream`` so far (a one-thread signal kernel on ``stream``, a one-wave bounded wait kernel on the
+ *                  communicator's stream: 2.4 us on ``stream`` where an event record costs 7 next to chip-filling launches);
+ *   fus_comm_join: the reverse direction.
+ * fus_comm_sync_timeouts: waits of these kernels that gave up (FUS_IPC_SPIN_SECONDS); synchronises the communicator's stream.
+ */
+int fus_comm_fork(fus_comm_t comm, void* stream);
+int fus_comm_join(fus_comm_t comm, void* stream);
+int fus_comm_sync_timeouts(fus_comm_t comm, int64_t* out);
 const char* fus_comm_last_error(fus_comm_t comm /* NULL: errors raised before a communicator existed */);
 int fus_comm_destroy(fus_comm_t comm);
 

@@ -18,16 +18,17 @@ def pytest_configure(config):
     config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
     # the native pieces are normally built by __graft_entry__.build(); build them here if a fresh
     # checkout runs the tests first (hipcc cross-compiles gfx950 without a GPU)
-    lib = os.path.join(ROOT, "fenicsx-fus-gpu_amd", "csrc", "libfusgpu.so")
-    orc = os.path.join(ROOT, "oracle", "_build", "libfus_oracle.so")
-    if not (os.path.exists(lib) and os.path.exists(orc)):
-        import subprocess
+    import subprocess
 
-        subprocess.run(["make", "-C", os.path.dirname(lib), "libfusgpu.so"], check=False, capture_output=True)
+    import __graft_entry__ as entry
+
+    # a prebuilt libfusgpu.so travels with the tree (git-ignored, not gpurun-ignored): rebuild it unless it was built
+    # from exactly these sources (fus_source_hash() vs the tree's hash), here and on the GPU box alike
+    entry.ensure_library(log=lambda m: print(f"[conftest] {m}", file=sys.stderr))
+    orc = os.path.join(ROOT, "oracle", "_build", "libfus_oracle.so")
+    if not os.path.exists(orc):
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "_build/libfus_oracle.so"], check=False, capture_output=True)
     if os.path.isdir("/root/reference") and not os.path.exists(os.path.join(ROOT, "oracle", "_ref", "libref_sumfact.so")):
-        import subprocess
-
         subprocess.run(["make", "-C", os.path.join(ROOT, "oracle"), "ref"], check=False, capture_output=True)
 
 

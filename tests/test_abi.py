@@ -26,7 +26,7 @@ def test_library_exports_every_declared_symbol():
     for name in names:
         assert hasattr(raw, name), f"{name} declared in include/fus_gpu.h but not exported"
     # and the ctypes binding covers the same set
-    bound = set(lib_mod.SIGNATURES) | {"fus_error_string"}
+    bound = set(lib_mod.SIGNATURES) | {"fus_error_string", "fus_source_hash"}
     assert bound == set(names), sorted(bound ^ set(names))
 
 

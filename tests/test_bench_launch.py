@@ -80,7 +80,7 @@ def test_gpus_mismatch_is_an_error():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("halo", ["native", "torch"])
+@pytest.mark.parametrize("halo", ["peer", "native", "torch"])
 def test_distributed_code_path_on_one_gpu(halo):
     """The N > 1 code path (HaloApply, three cell sub-ranges, halo begin/end, communicator bring-up) in a
     1-rank world on the GPU box, through bench.py itself."""
@@ -91,7 +91,11 @@ def test_distributed_code_path_on_one_gpu(halo):
     cfg = out["config"]
     assert out["n_gpus"] == 1 and cfg["ranks"] == 1 and cfg["halo"] == "overlapped"
     assert cfg["halo_exposed_ms"] is not None and out["value"] > 0
-    assert ("libfusgpu" in cfg["halo_transport"]) == (halo == "native")
+    assert cfg["halo_split_cost_ms"] is not None and cfg["halo_exchange_exposed_ms"] is not None
+    assert ("libfusgpu" in cfg["halo_transport"]) == (halo in ("peer", "native")) and ("PEER" in cfg["halo_transport"]) == (halo == "peer")
+    assert cfg["halo_schedule"] == ("concurrent" if halo == "peer" else "split")
+    assert cfg["halo_transports_tried"] == [{"transport": halo, "result": "ok"}]
+    assert cfg["lib_built_from_tree"] is True
     assert cfg["halo_check"]["ok"] is True and cfg["halo_check"]["forward_max_abs_err"] == 0.0
     assert out["roofline"]["kernel_ms"] > 0 and cfg["lib_sha"]
 
@@ -114,8 +118,9 @@ def test_mass_mode_line(dist_path):
 @pytest.mark.parametrize("n,mode", [(2, "stiffness"), (2, "mass"), (2, "rk4"), (4, "stiffness"), (4, "westervelt")])
 def test_multi_rank_rehearsal_on_one_gpu(n, mode):
     """bench.py's own N = 2 / N = 4 path end to end with real processes and real HIP kernels on the one-GPU box:
-    self-spawned ranks share the GPU, torch.distributed over gloo, exchange staged through the host
-    (FUS_BENCH_REHEARSAL=1; the line is marked invalid).  Covers what the N = 1 forced-dist run cannot: real
+    self-spawned ranks share the GPU, torch.distributed over gloo carries the bootstrap only, the exchange is the
+    PEER transport itself -- arenas mapped across the processes with HIP IPC handles, send / receive kernels
+    (FUS_BENCH_REHEARSAL=1; the line is marked invalid: the ranks share one GPU).  Covers what the N = 1 forced-dist run cannot: real
     neighbours inside the timed loop, the max-over-ranks reduction, rank 0 printing for the whole job."""
     cmd = [sys.executable, BENCH, "--gpus", str(n), "--mode", mode, "--steps", "3", "--warmup", "1", "--cells", "10", "--no-cpu-baseline"]
     if mode == "westervelt":
@@ -131,3 +136,4 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
         assert cfg["global_dofs"] == (4 * 20 + 1) * (4 * 10 * gy + 1) * 41 and cfg["cells_per_gpu"] == 1000
         # the run checks its own exchanges before timing anything (forward: exact copy; reverse: owned sums)
         assert cfg["halo_check"]["ok"] is True and cfg["halo_check"]["owned_sum_defect_over_sum_abs"] < 1e-9
+        assert "PEER" in cfg["halo_transport"] and cfg["halo_check"]["device_wait_timeouts"] == 0

@@ -357,6 +357,41 @@ def test_linear_solver_graph_replay_matches_rk4(geom):
     assert rel_l2(b.u_sol(), a.u_sol()) < 1e-13 and rel_l2(b.v_sol(), a.v_sol()) < 1e-13
 
 
+def test_graph_replay_survives_plan_cache_eviction():
+    """A captured step holds raw pointers into batch-plan workspaces; the plan cache is bounded (16) and evicts
+    oldest-first.  The graph keeps its workspaces alive itself: after the cache has been flushed and more than 16
+    other plans have been built (whose allocations would otherwise land on the freed memory), replay still equals rk4."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, ops = pkg("boxmesh"), pkg("linear_solver"), pkg("operators")
+    P, N, L = 3, 5, 0.012
+    mesh = boxmesh.BoxMesh(P, N, length=L, perturb=0.12, seed=4)
+    h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    a, b = ls.LinearSpectral3D(mesh, np.float64), ls.LinearSpectral3D(mesh, np.float64)
+    a.init(), b.init()
+    ta, sa = a.rk4(0.0, tf, dt)
+    t1, s1 = b.rk4_graph(0.0, tf, dt, max_steps=5)  # captures
+    assert len(b._graph_plans[dt]) >= 1
+    held = [ws.data_ptr() for ws, _ in b._graph_plans[dt]]
+    ops._PLANS.clear()  # every cached plan released; only the graph's references keep its workspaces alive
+    dev = torch.device("cuda", 0)
+    junk = []
+    for k in range(ops._PLANS.capacity + 4):  # fresh plans of the same size class: they would reuse freed blocks
+        dm = torch.from_numpy(np.roll(mesh.dofmap, k + 1, axis=0).copy()).to(dev)
+        junk.append(dm)
+        ws, _ = ops._PLANS.get(dm)
+        assert ws.data_ptr() not in held
+        ws.fill_(0xFF) if k % 2 else None  # scribble over some of them
+        if k % 2:
+            ops._PLANS.clear()
+    torch.cuda.synchronize()
+    t2, s2 = b.rk4_graph(t1, tf, dt)
+    assert s1 + s2 == sa and t2 == ta
+    assert rel_l2(b.u_sol(), a.u_sol()) < 1e-13 and rel_l2(b.v_sol(), a.v_sol()) < 1e-13
+
+
 @pytest.mark.parametrize("mode", ["single-gather", "two-gather", "in-kernel-geometry"])
 def test_westervelt_solver_graph_replay_matches_rk4(mode):
     """rk4_graph of the Westervelt solver (g and dg/dt of every stage read from device memory)."""

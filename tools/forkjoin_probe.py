@@ -90,7 +90,56 @@ def main():
         hip.hipEventRecord(raw[1], ss)
         hip.hipStreamWaitEvent(ms, raw[1], 0)
 
-    for rnd in range(2):
+    def side_kernels(k, n):
+        def f():
+            ea.record(main_s)
+            side.wait_event(ea)
+            apply()
+            with torch.cuda.stream(side):
+                for _ in range(k):
+                    lib.fus_fill_f64(ctypes.c_double(1.0), zz.data_ptr(), n, _lib.stream_ptr())
+            eb.record(side)
+            main_s.wait_event(eb)
+        return f
+
+    zz = torch.zeros(1 << 20, dtype=torch.float64, device=dev)
+    # how much does each small kernel on the high-priority side stream cost the chip-filling launch next to it?
+    for n in (4096, 1 << 17):
+        base = []
+        rows = {k: [] for k in (0, 1, 2, 4, 8)}
+        for _ in range(5):
+            base.append(timed(apply))
+            for k in rows:
+                rows[k].append(timed(side_kernels(k, n)))
+        b = float(np.median(base))
+        print(f"side kernels of {n} elements ({n * 8 // 1024} KiB filled each): plain {b:7.1f} us | " +
+              " | ".join(f"{k} kernels {float(np.median(v)):7.1f} ({float(np.median(np.array(v) - np.array(base))):+5.1f})" for k, v in rows.items()), flush=True)
+
+    # what would a fork WITHOUT an event cost the main stream?  f: a one-element kernel in front of every apply;
+    # g: hipStreamWriteValue64 in front of every apply (both followed by nothing on the side stream)
+    flag = torch.zeros(8, dtype=torch.int64, device=dev)
+
+    def tiny_then_apply():
+        lib.fus_fill_f64(ctypes.c_double(1.0), z.data_ptr(), 1, _lib.stream_ptr())
+        apply()
+
+    seqc = [0]
+
+    def writevalue_then_apply():
+        seqc[0] += 1
+        hip.hipStreamWriteValue64(ms, ctypes.c_void_p(flag.data_ptr()), ctypes.c_uint64(seqc[0]), 0)
+        apply()
+
+    rows = {"plain": [], "f tiny kernel before each apply": [], "g hipStreamWriteValue64 before each apply": [], "b fork+join events": []}
+    for _ in range(5):
+        rows["plain"].append(timed(apply))
+        rows["f tiny kernel before each apply"].append(timed(tiny_then_apply))
+        rows["g hipStreamWriteValue64 before each apply"].append(timed(writevalue_then_apply))
+        rows["b fork+join events"].append(timed(forkjoin))
+    base = np.array(rows["plain"])
+    print("event-free fork candidates: " + " | ".join(f"{k} {float(np.median(v)):7.1f} ({float(np.median(np.array(v) - base)):+5.1f})" for k, v in rows.items()), flush=True)
+
+    for rnd in range(1):
         ta = timed(apply)
         tb = timed(forkjoin)
         tc = timed(lambda: forkjoin(True))

@@ -35,6 +35,11 @@ def main():
     ap.add_argument("--transport", default="native", choices=["native", "local", "peer"],
                     help="native: RCCL to self; local: the library's in-process transport (pack + device copy + unpack, no RCCL kernel)")
     ap.add_argument("--two-stream", action="store_true", help="also time boundary cells on a high-priority side stream next to ONE interior launch")
+    ap.add_argument("--random-indices", action="store_true",
+                    help="owned dofs of the messages drawn at random over the vector (worst case) instead of the faces / edges / corner of a block")
+    ap.add_argument("--paired", type=int, default=0, metavar="ROUNDS",
+                    help="the judged comparison, noise-robust: ROUNDS alternating rounds of (single launch | the transport's own "
+                         "HaloApply schedule without exchange | with both exchanges); medians and medians of the per-round differences")
     ap.add_argument("--slice", default="", help="also time begin; op(slice 1); op(slice 2); ...; op(rest); end -- comma-separated cell fractions")
     a = ap.parse_args()
     if a.max_channels:
@@ -66,7 +71,20 @@ def main():
     N = mesh.ndofs - ng
     o_idx = rng.permutation(ng).astype(np.int64) if a.permuted else np.arange(ng, dtype=np.int64)
     od = [o_idx, np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
-    gd = [rng.choice(N, size=ng, replace=False).astype(np.int64), np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+    if a.random_indices:
+        g_idx = rng.choice(N, size=ng, replace=False).astype(np.int64)
+    else:
+        # the owned dofs a rank of a 2x2x2 partition sends: the three low faces of its 217^3 lexicographic block (one
+        # contiguous plane, one plane of runs of 217, one plane of stride 217), three edges, one corner
+        n1 = 4 * 54 + 1
+        ii, jj = np.meshgrid(np.arange(n1), np.arange(n1), indexing="ij")
+        lex = lambda i, j, k: ((i * n1 + j) * n1 + k).reshape(-1)  # noqa: E731
+        z0 = np.zeros_like(ii)
+        ar, zr = np.arange(n1), np.zeros(n1, dtype=np.int64)
+        g_idx = np.concatenate([lex(z0, ii, jj), lex(ii, z0, jj), lex(ii, jj, z0), lex(zr, zr, ar), lex(zr, ar, zr), lex(ar, zr, zr),
+                                np.array([0])]).astype(np.int64) % N  # (the last three lattice planes wrap: the ghost block ends the vector)
+        assert g_idx.size == ng
+    gd = [g_idx, np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
 
     if a.reserve_cus:
         import ctypes
@@ -101,14 +119,43 @@ def main():
         torch.cuda.synchronize()
         return e0.elapsed_time(e1) / a.reps * 1e3
 
-    tA = timed(lambda: op(x, cc, y, G, dm))
-    print(f"A  op alone                                   {tA:8.1f} us", flush=True)
     def make_comm(wid=[700]):
         wid[0] += 1
         if a.transport == "peer":  # the PEER protocol, the rank's own arena as its neighbour's
             return scat.NativeComm(transport="peer")
         return scat.NativeComm(local=(wid[0], 1, 0)) if a.transport == "local" else scat.NativeComm()
 
+    if a.paired:
+        # HaloApply itself, as bench.py uses it, on a config-4-shaped rank: boundary cells first (8 590 of them), a
+        # self-neighbour plan of config-4 message sizes
+        class _M:  # the few attributes HaloApply reads from a mesh
+            pass
+
+        m = _M()
+        m.num_boundary_cells, m.ncells, m.nlocal, m.dofmap, m.index_map = 8590, mesh.ncells, N, mesh.dofmap, None
+        comm = make_comm()
+        halo = scat.HaloApply(m, op, comm, np.float64, plan=(od, gd))
+        xg = torch.randn(mesh.ndofs, dtype=torch.float64, device=dev)
+        halo.prepare(xg, cc, G, dm)
+        fns = {"single launch": lambda: op(x, cc, y, G, dm),
+               "schedule, no exchange": lambda: halo.apply_no_exchange(xg, cc, y, G, dm),
+               "schedule + both exchanges": lambda: halo.apply(xg, cc, y, G, dm)}
+        res = {k: [] for k in fns}
+        for _ in range(a.paired):
+            for k, fn in fns.items():
+                res[k].append(timed(fn))
+        med = {k: float(np.median(v)) for k, v in res.items()}
+        d_split = float(np.median(np.array(res["schedule, no exchange"]) - np.array(res["single launch"])))
+        d_halo = float(np.median(np.array(res["schedule + both exchanges"]) - np.array(res["single launch"])))
+        d_exch = float(np.median(np.array(res["schedule + both exchanges"]) - np.array(res["schedule, no exchange"])))
+        print(f"paired [{a.transport}{', permuted ghosts' if a.permuted else ''}{', random indices' if a.random_indices else ''}; schedule {halo.schedule_kind}, lead {halo.lead_cells}; {a.paired} rounds x {a.reps} applies]: "
+              f"single launch {med['single launch']:7.1f} us | schedule without exchange {med['schedule, no exchange']:7.1f} ({d_split:+5.1f}) | "
+              f"with both exchanges {med['schedule + both exchanges']:7.1f} us: vs single launch {d_halo:+5.1f} us = {100 * d_halo / med['single launch']:4.1f} % "
+              f"(exchanges {d_exch:+5.1f}, split {d_split:+5.1f}); time-outs {halo.health()}", flush=True)
+        dist.destroy_process_group()
+        return
+    tA = timed(lambda: op(x, cc, y, G, dm))
+    print(f"A  op alone                                   {tA:8.1f} us", flush=True)
     for name, comm in ((a.transport, make_comm()),):
         for dname, mk in (("forward", scat.scatter_forward), ("reverse", scat.scatter_reverse)):
             sc = mk(comm, od, gd, N, np.float64)
