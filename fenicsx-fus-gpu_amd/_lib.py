@@ -80,6 +80,7 @@ def _signatures():
         sig[f"fus_fill_{suf}"] = [ct, _vp, _i64, _vp]
         sig[f"fus_pointwise_divide_{suf}"] = [_vp, _vp, _vp, _i64, _vp]
         sig[f"fus_square_{suf}"] = [_vp, _vp, _i64, _vp]
+        sig[f"fus_muladd_{suf}"] = [_vp, _vp, _vp, _i64, _vp]
         sig[f"fus_geometry_factors_{suf}"] = [_vp, _vp, _vp, _vp, _int, _i64, _vp, _vp, _vp]
         sig[f"fus_facet_jacobian_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp, _vp]
         sig[f"fus_westervelt_cell_apply_planned_{suf}"] = [_vp] * 12 + [_int, _i64, _vp]

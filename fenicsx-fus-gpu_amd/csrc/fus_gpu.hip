@@ -533,6 +533,12 @@ FUS_FACET(float, f32)
   int fus_square_##SUF(const T* a, T* b, int64_t n, void* s) {                                                \
     return ew<T, fus::OpSquare<T>, true, false>(a, nullptr, b, n, fus::OpSquare<T>{}, s);                     \
   }                                                                                                           \
+  int fus_muladd_##SUF(const T* w, const T* x, T* y, int64_t n, void* s) {                                    \
+    if (n < 0) return FUS_ERR_INVALID_ARGUMENT;                                                               \
+    if (n == 0) return FUS_OK;                                                                                \
+    if (!w || !x || !y) return FUS_ERR_INVALID_ARGUMENT;                                                      \
+    return hip_rc(fus::launch_muladd<T>(w, x, y, n, static_cast<hipStream_t>(s)));                            \
+  }                                                                                                           \
   int fus_pack_fwd_##SUF(const T* in, T* out, const int64_t* idx, int64_t cnt, void* s) {                     \
     return halo<T, fus::PACK>(in, out, idx, cnt, 0, s);                                                       \
   }                                                                                                           \

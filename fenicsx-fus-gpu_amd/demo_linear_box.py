@@ -44,7 +44,7 @@ def main():
     comm = None
     if world > 1:
         dist.init_process_group("nccl", device_id=torch.device("cuda", torch.cuda.current_device()))
-        comm = scat.NativeComm()  # exchange issued by libfusgpu.so (RCCL); torch.distributed only bootstraps it
+        comm = scat.default_comm()  # exchange issued by libfusgpu.so (PEER transport; FUS_HALO=native: RCCL); torch.distributed only bootstraps it
 
     # cuda/demo_linear_box.py:53-80
     float_type = np.float64

@@ -199,6 +199,46 @@ class _MassOperator(_Launchable):
 mass_operator = _MassOperator()
 
 
+class DiagonalMassOperator:
+    """The cell mass apply in CACHED-DIAGONAL form (opt-in; own bytes contract: 3 vector touches per dof).
+
+    With GLL collocation the operator of numba-cpu/operators.py:19-68 is diagonal:  M(c) x = (M(c) 1) (.) x.
+    ``DiagonalMassOperator(entity_constants, entity_detJ, entity_dofmap, ndofs)`` assembles ``w = M(c) 1`` once with the
+    reference-compatible ``mass_operator`` (so ``w`` carries exactly its rounding) and ``op(x, y)`` then does
+    ``y += w * x`` (``fus_muladd_*``).  The reference's drivers re-apply the gather / scatter form on every use
+    (cuda/demo_nonlinear_bowl.py:603-632); the Westervelt solver of this package uses the same identity for its two
+    mass terms.  ``w`` is valid for the (constants, detJ, dofmap) it was built from: ``refresh()`` after changing them.
+    On a partitioned mesh ``w`` holds this rank's cells' contributions, like ``y`` after the cell operator (reverse-scatter
+    either ``w`` once or ``y`` every time)."""
+
+    def __init__(self, entity_constants, entity_detJ, entity_dofmap, ndofs, float_type=None):
+        dt = entity_detJ.dtype if float_type is None else _lib.torch_dtype(float_type)
+        _req(entity_constants, dt, "entity_constants")
+        _req(entity_detJ, dt, "entity_detJ")
+        _req(entity_dofmap, torch.int32, "entity_dofmap")
+        self.dtype, self.ndofs = dt, int(ndofs)
+        self._args = (entity_constants, entity_detJ, entity_dofmap)
+        self.w = torch.zeros(self.ndofs, dtype=dt, device=entity_detJ.device)
+        self._fn = getattr(_lib.load(), f"fus_muladd_{_lib.suffix(dt)}")
+        self.refresh()
+
+    def refresh(self):
+        cc, detJ, dm = self._args
+        self.w.zero_()
+        _mass_apply(torch.ones(self.ndofs, dtype=self.dtype, device=self.w.device), cc, self.w, detJ, dm)
+
+    def __call__(self, x, y):
+        _req(x, self.dtype, "x")
+        _req(y, self.dtype, "y")
+        if x.numel() != self.ndofs or y.numel() != self.ndofs:
+            raise ValueError(f"x and y must have {self.ndofs} entries")
+        _lib.check(self._fn(self.w.data_ptr(), x.data_ptr(), y.data_ptr(), self.ndofs, _lib.stream_ptr()), "fus_muladd")
+
+
+def diagonal_mass_operator(entity_constants, entity_detJ, entity_dofmap, ndofs, float_type=None):
+    return DiagonalMassOperator(entity_constants, entity_detJ, entity_dofmap, ndofs, float_type)
+
+
 def facet_terms(y, source, field, scalars=None):
     """The boundary-facet terms of one RK4 stage in one launch (csrc/mass.hpp, ``fus_facet_terms_*``):
 

@@ -261,6 +261,18 @@ class NativeComm:
         return True
 
 
+def default_comm(group=None):
+    """The communicator a driver should use at N > 1 (one process per GPU, ``torch.distributed`` initialised): the PEER
+    transport of libfusgpu.so unless ``FUS_HALO=native`` (grouped RCCL send / recv) or ``FUS_HALO=torch``
+    (``all_to_all_single``).  Creation fails on all ranks or on none."""
+    import os
+
+    kind = os.environ.get("FUS_HALO", "peer")
+    if kind == "torch":
+        return TorchComm(group)
+    return NativeComm(group, transport="peer" if kind == "peer" else "rccl")
+
+
 class _NativeScatter:
     """scatter_forward / scatter_reverse closure over ``fus_halo_*`` (the exchange is issued from C++)."""
 

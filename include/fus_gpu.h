@@ -222,6 +222,14 @@ int fus_scale_f64(double alpha, const double* a, double* b, int64_t n, void* str
 int fus_scale_f32(float alpha, const float* a, float* b, int64_t n, void* stream);
 int fus_square_f64(const double* a, double* b, int64_t n, void* stream);                       /* b = a^2 */
 int fus_square_f32(const float* a, float* b, int64_t n, void* stream);
+/*
+ * y += w (.) x  -- the cell mass apply in cached-diagonal form (opt-in; no counterpart in the reference, whose drivers
+ * call mass_operator on every use, cuda/demo_nonlinear_bowl.py:603-632).  With GLL collocation M(c) x = (M(c) 1) (.) x:
+ * assemble w = M(c) 1 once with fus_mass_apply_* (x = 1), then 3 vector touches per dof per apply instead of the
+ * gather-scale-scatter's 47.6 B/dof (P = 4, fp64).  w must be re-assembled when constants, detJ or the dofmap change.
+ */
+int fus_muladd_f64(const double* w, const double* x, double* y, int64_t n, void* stream);
+int fus_muladd_f32(const float* w, const float* x, float* y, int64_t n, void* stream);
 
 /*
  * Geometry precompute on the device, same inputs / conventions / outputs as the reference's host

@@ -16,10 +16,19 @@ import sys
 ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 tag = sys.argv[1]
 kernel_key = sys.argv[2] if len(sys.argv) > 2 else "stiffness"
+out_tag = tag
+for a_ in sys.argv[3:]:
+    if a_.startswith("--as="):
+        out_tag = a_[5:]  # several kernels of one profiled run: one summary file each
+# traffic_latest.json (what bench.py replays as roofline.traffic of the HEADLINE line) is rewritten only by the pass
+# over the headline kernel in the default mode
+update_latest = "--headline" in sys.argv[3:]
 src = os.path.join(ROOT, "gpurun_out", f"prof_{tag}")
 out = os.path.join(ROOT, "profiles")
 shutil.copy(os.path.join(src, "trace", "trace_kernel_stats.csv"), os.path.join(out, f"{tag}_kernel_stats.csv"))
+_tag_for_files = out_tag
 counters = {}
+meta = {}
 for sub, name in (("pmc_fetch", "fetch"), ("pmc_write", "write"), ("pmc_tcc", "tcc"), ("pmc_sq", "sq")):
     p = os.path.join(src, sub, f"{name}_counter_collection.csv")
     if not os.path.exists(p):
@@ -37,7 +46,8 @@ for r in csv.DictReader(open(os.path.join(src, "trace", "trace_kernel_stats.csv"
     if kernel_key in r["Name"]:
         stats = {"kernel": r["Name"], "calls": int(r["Calls"]), "avg_ns": float(r["AverageNs"]), "min_ns": int(r["MinNs"]), "max_ns": int(r["MaxNs"])}
 bench = json.load(open(os.path.join(src, "bench_trace.json")))
-res = {"tag": tag, "kernel_stats": stats, "dispatch": meta, "counters": counters, "lib_sha": bench.get("config", {}).get("lib_sha")}
+res = {"tag": tag, "kernel_key": kernel_key, "kernel_stats": stats, "dispatch": meta, "counters": counters,
+       "lib_sha": bench.get("config", {}).get("lib_sha"), "bench_metric": bench.get("metric"), "bench_ms_per_step": bench.get("ms_per_step")}
 # back-to-back launches overlap at their tails: besides the per-dispatch durations of --stats, take the
 # longest run of consecutive dispatches of the kernel from the trace and divide its span by its length
 tr = os.path.join(src, "trace", "trace_kernel_trace.csv")
@@ -61,12 +71,24 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     res["hbm_bytes_per_launch"] = (2 * f + w) * 1024
     res["fetch_bytes_corrected"] = 2 * f * 1024
     res["write_bytes"] = w * 1024
-    ncell = bench["config"]["cells_per_gpu"]
-    res["algorithmic_bytes_per_launch"] = ncell * bench["roofline"]["algorithmic_bytes_per_cell"]
-    res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
-    json.dump({"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
-               "source": f"profiles/{tag}_counters.json", "lib_sha": res["lib_sha"], "dtype": bench.get("dtype", "f64")},
-              open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
+    bytes_model = {"stiffness_plan_kernel": lambda nc, P: nc * (6 * (P + 1) ** 3 * 8 + 4 * (P + 1) ** 3 + 3 * 8 * P ** 3 + 8),
+                   "mass_plan_kernel": lambda nc, P: nc * ((P + 1) ** 3 * 8 + 4 * (P + 1) ** 3 + 3 * 8 * P ** 3 + 8)}
+    ncell = bench["config"].get("cells_per_gpu") or bench.get("roofline", {}).get("cells_per_launch")
+    P = bench["config"].get("degree")
+    if "algorithmic_bytes_per_cell" in (bench.get("roofline") or {}) and ncell:
+        res["algorithmic_bytes_per_launch"] = ncell * bench["roofline"]["algorithmic_bytes_per_cell"]
+    for key, fn in bytes_model.items():  # a kernel inside a larger step (RK4): its own model
+        if key in kernel_key and ncell and P and "algorithmic_bytes_per_launch" not in res:
+            res["algorithmic_bytes_per_launch"] = fn(ncell, P)
+    if "algorithmic_bytes_per_launch" in res:
+        res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
+    if stats:
+        res["hbm_gbs_from_counters"] = res["hbm_bytes_per_launch"] / stats["avg_ns"]
+    if update_latest:
+        json.dump({"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
+                   "source": f"profiles/{_tag_for_files}_counters.json", "lib_sha": res["lib_sha"],
+                   "kernel_src_sha": bench.get("config", {}).get("kernel_src_sha"), "dtype": bench.get("dtype", "f64")},
+                  open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
 if "TCC_EA0_ATOMIC_sum" in counters and stats:
     res["atomic_requests_per_s"] = counters["TCC_EA0_ATOMIC_sum"]["mean_per_launch"] / (stats["avg_ns"] * 1e-9)
 if "SQ_LDS_BANK_CONFLICT" in counters and "SQ_LDS_IDX_ACTIVE" in counters:
@@ -74,6 +96,6 @@ if "SQ_LDS_BANK_CONFLICT" in counters and "SQ_LDS_IDX_ACTIVE" in counters:
 if "SQ_WAVE_CYCLES" in counters and "SQ_WAIT_ANY" in counters:
     wc = counters["SQ_WAVE_CYCLES"]["mean_per_launch"]
     res["wave_cycle_shares"] = {k: counters[k]["mean_per_launch"] / wc for k in ("SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY") if k in counters}
-json.dump(res, open(os.path.join(out, f"{tag}_counters.json"), "w"), indent=1)
+json.dump(res, open(os.path.join(out, f"{_tag_for_files}_counters.json"), "w"), indent=1)
 json.dump(bench, open(os.path.join(out, f"{tag}_bench.json"), "w"), indent=1)
 print(json.dumps(res, indent=1))

@@ -116,7 +116,7 @@ def main():
         # numba-cpu/test_operators.py:274-279
         return 100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])
 
-    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter | plan
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter | plan | rk4
 
     # ---- operator + precompute fixtures --------------------------------------
     cases = []
@@ -282,6 +282,127 @@ def main():
             tag = f"halo_plan_P{P}_{shape[0]}x{shape[1]}x{shape[2]}_grid{grid[0]}x{grid[1]}x{grid[2]}_{ghost_order}"
             np.savez_compressed(os.path.join(HERE, tag + ".npz"), **out)
             print("wrote", tag)
+
+
+    # ---- time-loop fixtures: the reference's OWN operators and scatter closures driven through the stage sequence
+    # of its RK4 loop (cuda/demo_linear_box.py:487-566 == numba-cpu/demo_linear_box.py's f0 / f1 / rk4; the demos
+    # themselves need dolfinx for the mesh and cannot run here).  Every array operation below is a call into the imported
+    # reference (copy / axpy / fill / pointwise_divide / mass_operator / stiffness_operator / scatter_forward /
+    # scatter_reverse); what this script contributes is the ORDER of the calls, written next to the reference's lines,
+    # and the inputs.  It pins the operator-composition half of the time loop (which vector goes where, t vs tn, signs of
+    # the facet terms as the demo passes them); the material constants and the source formula are restated from
+    # cuda/demo_linear_box.py:336-345,512-533.
+    if only in ("all", "rk4"):
+        ls = fusgpu_loader.submodule("linear_solver")
+        c0, rho0, f0, p0 = 1500.0, 1000.0, 0.5e6, 60000.0
+        w0 = 2 * np.pi * f0
+        rk_cases = [("P2_2x2x2_pert_1rank", 2, (2, 2, 2), (1, 1, 1), 0.12, 12), ("P2_4x2x2_pert_2ranks", 2, (4, 2, 2), (2, 1, 1), 0.12, 8)]
+        for tag, P, shape, grid, perturb, nsteps in rk_cases:
+            n = P + 1
+            R = int(np.prod(grid))
+            L = 0.003 * shape[0]
+            lengths = tuple(L * s_ / shape[0] for s_ in shape)
+            meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, length=lengths, perturb=perturb, seed=11) for r in range(R)]
+            od_all, gd_all = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+            pts, wts, D = gll.tabulate_1d(P)
+            wts3, wts2 = gll.tensor_weights_3d(wts), gll.tensor_weights_2d(wts)
+            dphi_g, dphi_f = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts)), pre.tabulate_facet_gradients(pts)
+            h = min(ls.time_step_parameters(m, P, c0, f0, L) for m in meshes)
+            dt, _, _ = ls.snap_time_step(h, P, c0, f0, L)
+            rk = []  # per rank: the arrays the demo builds at set-up (cuda/demo_linear_box.py:245-345)
+            for m in meshes:
+                nc = m.ncells
+                G, detJ = np.zeros((nc, n**3, 6)), np.zeros((nc, n**3))
+                ref_pre.compute_scaled_geometrical_factor(G, (m.x_dofs, m.x_g), nc, dphi_g, wts3)
+                ref_pre.compute_scaled_jacobian_determinant(detJ, (m.x_dofs, m.x_g), nc, dphi_g, wts3)
+                bd1, bd2 = m.boundary_facets([2]), m.boundary_facets([3])  # x = 0 source, x = L absorbing
+                dF1, dF2 = np.zeros((bd1.shape[0], n * n)), np.zeros((bd2.shape[0], n * n))
+                if bd1.shape[0]:
+                    ref_pre.compute_boundary_facets_scaled_jacobian_determinant(dF1, (m.x_dofs, m.x_g), bd1, dphi_f, wts2)
+                if bd2.shape[0]:
+                    ref_pre.compute_boundary_facets_scaled_jacobian_determinant(dF2, (m.x_dofs, m.x_g), bd2, dphi_f, wts2)
+                rk.append(dict(m=m, G=G, detJ=detJ, dF1=dF1, dF2=dF2, fd1=m.facet_dofmap(bd1), fd2=m.facet_dofmap(bd2),
+                               cc1=np.full(nc, 1.0 / rho0 / c0 / c0), cc2=np.full(nc, -1.0 / rho0),      # :336-337
+                               fc1=np.full(bd1.shape[0], 1.0 / rho0), fc2=np.full(bd2.shape[0], -1.0 / rho0 / c0)))  # :339-345
+            world = FakeWorld()
+            fwd = [ref_sc.scatter_forward(FakeComm(world, r), od_all[r], gd_all[r], meshes[r].nlocal, np.float64) for r in range(R)]
+            rev = [ref_sc.scatter_reverse(FakeComm(world, r), od_all[r], gd_all[r], meshes[r].nlocal, np.float64) for r in range(R)]
+
+            def scatter_all(closures, arrays):
+                """every rank's reference closure on its vector; the closure packs, sends, receives and unpacks in one
+                call, so a first pass over scratch copies puts every rank's sends into the mailbox"""
+                if R == 1:
+                    return
+                world.box.clear()
+                scratch = [a.copy() for a in arrays]
+                for r in range(R):
+                    try:
+                        closures[r](scratch[r])
+                    except KeyError:
+                        pass
+                for r in range(R):
+                    closures[r](arrays[r])
+
+            stiff = ref_ops.stiffness_operator(P, D.flatten(), np.float64)
+            mass_c, mass_f = ref_ops.mass_operator(n**3, np.float64), ref_ops.mass_operator(n * n, np.float64)
+            out = {"P": P, "shape": np.array(shape), "grid": np.array(grid), "perturb": perturb, "seed": 11, "lengths": np.array(lengths),
+                   "dt": dt, "nsteps": nsteps, "c0": c0, "rho0": rho0, "f0": f0, "p0": p0}
+            for source_time in ("tn", "t"):
+                st = []
+                for d in rk:
+                    nd_ = d["m"].ndofs
+                    z = lambda: np.zeros(nd_)  # noqa: E731
+                    st.append(dict(u=z(), v=z(), un=z(), vn=z(), u0=z(), v0=z(), ku=z(), kv=z(), g=z(), b=z(), m=z(), u_n=z(), v_n=z(),
+                                   axpy=ref_ops.axpy(nd_)))
+                # lumped mass (:421-428): u_t = 1; m = M(cc1) u_t; scatter_rev(m)
+                for d, s_ in zip(rk, st):
+                    ones = np.zeros(d["m"].ndofs)
+                    ref_ops.fill(1.0, ones)
+                    ref_ops.fill(0.0, s_["m"])
+                    mass_c(ones, d["cc1"], s_["m"], d["detJ"], d["m"].dofmap)
+                scatter_all(rev, [s_["m"] for s_ in st])
+                a_runge, b_runge, c_runge = (0.0, 0.5, 0.5, 1.0), (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0), (0.0, 0.5, 0.5, 1.0)
+                t = 0.0
+                for _ in range(nsteps):
+                    for s_ in st:
+                        ref_ops.copy(s_["u"], s_["u0"])  # :491-492
+                        ref_ops.copy(s_["v"], s_["v0"])
+                    for i in range(4):
+                        tn = t + c_runge[i] * dt
+                        ts_ = tn if source_time == "tn" else t  # the CUDA demo evaluates window and g at t (:515-532), numba-cpu / C++ at tn
+                        T_, alpha = 1.0 / f0, 4.0
+                        window = 0.5 * (1.0 - np.cos(f0 * np.pi * ts_ / alpha)) if ts_ < T_ * alpha else 1.0
+                        g_vals = window * p0 * w0 / c0 * np.cos(w0 * ts_)
+                        for d, s_ in zip(rk, st):
+                            ref_ops.copy(s_["u0"], s_["un"])  # :496-500
+                            ref_ops.copy(s_["v0"], s_["vn"])
+                            s_["axpy"](a_runge[i] * dt, s_["ku"], s_["un"])
+                            s_["axpy"](a_runge[i] * dt, s_["kv"], s_["vn"])
+                            ref_ops.copy(s_["vn"], s_["ku"])  # f0, :508
+                            ref_ops.fill(g_vals, s_["g"])  # :533
+                            ref_ops.copy(s_["un"], s_["u_n"])  # :536-537
+                            ref_ops.copy(s_["vn"], s_["v_n"])
+                        scatter_all(fwd, [s_["u_n"] for s_ in st])  # :539-540
+                        scatter_all(fwd, [s_["v_n"] for s_ in st])
+                        for d, s_ in zip(rk, st):
+                            ref_ops.fill(0.0, s_["b"])  # :543
+                            stiff(s_["u_n"], d["cc2"], s_["b"], d["G"], d["m"].dofmap)  # :545-547
+                            mass_f(s_["g"], d["fc1"], s_["b"], d["dF1"], d["fd1"])  # :548-550
+                            mass_f(s_["v_n"], d["fc2"], s_["b"], d["dF2"], d["fd2"])  # :551-553
+                        scatter_all(rev, [s_["b"] for s_ in st])  # :555
+                        for s_ in st:
+                            ref_ops.pointwise_divide(s_["b"], s_["m"], s_["kv"])  # :558
+                            s_["axpy"](b_runge[i] * dt, s_["ku"], s_["u"])  # :564-565
+                            s_["axpy"](b_runge[i] * dt, s_["kv"], s_["v"])
+                    t += dt
+                scatter_all(fwd, [s_["u"] for s_ in st])
+                scatter_all(fwd, [s_["v"] for s_ in st])
+                for r, s_ in enumerate(st):
+                    out[f"ref_u_{source_time}_{r}"] = s_["u"]
+                    out[f"ref_v_{source_time}_{r}"] = s_["v"]
+                    out[f"ref_m_{r}"] = s_["m"]
+            np.savez_compressed(os.path.join(HERE, f"rk4_{tag}.npz"), **out)
+            print("wrote", f"rk4_{tag}", "dt", dt, "max|u|", max(float(np.abs(out[f"ref_u_tn_{r}"]).max()) for r in range(R)))
 
 
 if __name__ == "__main__":

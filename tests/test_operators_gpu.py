@@ -7,7 +7,7 @@ oracle / golden data."""
 import numpy as np
 import pytest
 
-from conftest import TOL, build_problem, golden_files, pkg, rel_l2, rel_max
+from conftest import TOL, build_problem, golden_files, pkg, ref_field, rel_l2, rel_max
 
 pytestmark = pytest.mark.gpu
 
@@ -330,6 +330,88 @@ def test_device_precompute_vs_reference(gpu, path):
     pre.compute_boundary_facets_scaled_jacobian_determinant_device(
         dF, mesh, dev.to_device(d["boundary_data"].astype(np.int32)), dev.to_device(d["dphi_facet"]), dev.to_device(d["wts2"]))
     assert rel_l2(dF.copy_to_host(), d["ref_detJ_f"]) < tol
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P", [2, 4, 6])
+def test_cached_diagonal_mass_equals_mass_operator(gpu, oracle_c, P, dtype):
+    """diagonal_mass_operator: y += (M(c) 1) (.) x equals the oracle's gather-scale-scatter mass apply (GLL collocation makes
+    the operator diagonal), accumulate-into semantics included; refresh() follows a change of the constants."""
+    import torch
+
+    dev, ops = gpu
+    pb = build_problem(P, 5, dtype=dtype, perturb=0.16)
+    mesh = pb["mesh"]
+    rng = np.random.default_rng(3)
+    y0 = rng.standard_normal(mesh.ndofs).astype(dtype)
+    y_ref = y0.astype(np.float64)
+    oracle_c.mass_apply(pb["x"].astype(np.float64), pb["cc"].astype(np.float64), y_ref, pb["detJ"].astype(np.float64), mesh.dofmap)
+    cc_d, dj_d, dm_d = dev.to_device(pb["cc"]), dev.to_device(pb["detJ"]), dev.to_device(mesh.dofmap)
+    op = ops.diagonal_mass_operator(cc_d, dj_d, dm_d, mesh.ndofs, dtype)
+    y = dev.to_device(y0.copy())
+    op(dev.to_device(pb["x"]), y)
+    torch.cuda.synchronize()
+    _check(y.cpu().numpy(), y_ref, dtype, "cached-diagonal mass")
+    cc_d.mul_(2.0)
+    op.refresh()
+    y2 = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    op(dev.to_device(pb["x"]), y2)
+    torch.cuda.synchronize()
+    _check(y2.cpu().numpy(), 2.0 * (y_ref - y0), dtype, "cached-diagonal mass after refresh")
+
+
+def test_config2_full_size(gpu, oracle_c):
+    """BASELINE config 2 at its stated size (P = 4, 25^3 perturbed cells, 1 030 301 dofs: the small-mesh regime,
+    1.5 rounds of the chip): stiffness (planned and plan-free), cell mass (planned) and the boundary-facet mass of all
+    six faces, each against the oracle, fp64 to 1e-12."""
+    import torch
+
+    dev, ops = gpu
+    boxmesh, gll, pre = pkg("boxmesh"), pkg("gll"), pkg("precompute")
+    P, N = 4, 25
+    mesh = boxmesh.BoxMesh(P, N, perturb=0.16, seed=0)
+    assert mesh.ndofs == 1030301 and mesh.ncells == 15625
+    pts, wts, D = gll.tabulate_1d(P)
+    n = P + 1
+    gm = (dev.to_device(mesh.x_dofs), dev.to_device(mesh.x_g))
+    dg = dev.to_device(pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts)))
+    w3 = dev.to_device(gll.tensor_weights_3d(wts))
+    G = dev.device_array((mesh.ncells, n**3, 6), np.float64)
+    detJ = dev.device_array((mesh.ncells, n**3), np.float64)
+    pre.compute_scaled_geometrical_factor_device(G, gm, mesh.ncells, dg, w3, detJ=detJ)
+    bd = mesh.boundary_facets()
+    assert bd.shape[0] == 6 * N * N
+    dF = dev.device_array((bd.shape[0], n * n), np.float64)
+    pre.compute_boundary_facets_scaled_jacobian_determinant_device(
+        dF, gm, dev.to_device(bd.astype(np.int32)), dev.to_device(pre.tabulate_facet_gradients(pts)), dev.to_device(gll.tensor_weights_2d(wts)))
+    fdm = mesh.facet_dofmap(bd)
+    rng = np.random.default_rng(2)
+    x = ref_field(mesh.dof_coordinates())
+    cc = 1.0 + 0.25 * rng.standard_normal(mesh.ncells)
+    fc = 1.0 + 0.25 * rng.standard_normal(bd.shape[0])
+    x_d, cc_d, fc_d, dm, fdm_d = (dev.to_device(a) for a in (x, cc, fc, mesh.dofmap, fdm))
+    threads = max(1, min(32, oracle_c.max_threads()))
+    G_h, detJ_h, dF_h = G.copy_to_host(), detJ.copy_to_host(), dF.copy_to_host()
+    # stiffness
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, D, x, cc, y_ref, G_h, mesh.dofmap, threads=threads)
+    op = ops.stiffness_operator(P, D.flatten(), np.float64)
+    for plan in (True, False):
+        ops.use_plan(plan)
+        try:
+            y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+            op(x_d, cc_d, y, G, dm)
+            _check(y.cpu().numpy(), y_ref, np.float64, f"stiffness, config 2, plan={plan}")
+        finally:
+            ops.use_plan(True)
+    # cell mass (>= 32 k entries: the planned kernel) and facet mass (3 750 facets x 25 dofs: planned too)
+    for name, consts, dj_d, dj_h, dmap_d, dmap_h, nper in (("cell mass", (cc, cc_d), detJ, detJ_h, dm, mesh.dofmap, n**3),
+                                                              ("facet mass", (fc, fc_d), dF, dF_h, fdm_d, fdm, n * n)):
+        y_ref = np.zeros(mesh.ndofs)
+        oracle_c.mass_apply(x, consts[0], y_ref, dj_h, dmap_h)
+        y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+        ops.mass_operator(nper, np.float64)(x_d, consts[1], y, dj_d, dmap_d)
+        _check(y.cpu().numpy(), y_ref, np.float64, f"{name}, config 2")
 
 
 def test_full_size_config3(gpu, oracle_c):

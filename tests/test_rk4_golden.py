@@ -1,0 +1,101 @@
+"""The time loop against REFERENCE-HELD data: tests/golden/rk4_*.npz were produced by driving the
+imported reference's own operators and scatter closures (numba-cpu/operators.py, scatterer.py) through the stage sequence
+of its RK4 loop (cuda/demo_linear_box.py:487-566) -- tests/golden/generate_golden.py --only rk4.
+
+  * CPU: the oracle-side loop (tests/rk4_oracle.py, what every solver test compares with) reproduces them, for the
+    source evaluated at the stage time (numba-cpu / C++ drivers) and at the step time (the CUDA demos' quirk);
+  * GPU: the solver itself -- reference launch sequence and fused stages, one rank and two in-process ranks over both
+    in-process transports -- reproduces them.
+This pins the operator-composition half of the loop (which vector feeds which operator, accumulate-into, t vs tn,
+the order of the updates); the source formula and the material constants are restated in the generator."""
+import os
+
+import numpy as np
+import pytest
+
+from conftest import GOLDEN, pkg, rel_l2
+import rk4_oracle
+
+
+def _case(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    boxmesh = pkg("boxmesh")
+    P, shape, grid = int(d["P"]), tuple(int(v) for v in d["shape"]), tuple(int(v) for v in d["grid"])
+    kw = dict(length=tuple(float(v) for v in d["lengths"]), perturb=float(d["perturb"]), seed=int(d["seed"]))
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, **kw) for r in range(R)]
+    serial = boxmesh.BoxMesh(P, shape, **kw)
+    return d, meshes, serial
+
+
+@pytest.mark.parametrize("source_time", ["tn", "t"])
+def test_oracle_loop_reproduces_reference_driven_loop(source_time):
+    d, meshes, serial = _case("rk4_P2_2x2x2_pert_1rank")
+    u, v = rk4_oracle.solve(serial, int(d["nsteps"]), float(d["dt"]), c0=float(d["c0"]), rho0=float(d["rho0"]), f0=float(d["f0"]),
+                            p0=float(d["p0"]), source_time=source_time)
+    assert np.max(np.abs(d[f"ref_u_{source_time}_0"])) > 1e3
+    assert rel_l2(u, d[f"ref_u_{source_time}_0"]) < 1e-12 and rel_l2(v, d[f"ref_v_{source_time}_0"]) < 1e-12
+    # the two source conventions really differ (the test would not notice a t / tn slip otherwise)
+    assert rel_l2(d["ref_u_t_0"], d["ref_u_tn_0"]) > 1e-3
+
+
+def test_oracle_loop_reproduces_reference_driven_two_rank_loop():
+    """The reference's scatter closures inside the loop (forward of u_n, v_n; reverse of b and of the lumped mass):
+    the serial oracle loop on the whole box equals every rank's owned AND ghost entries."""
+    d, meshes, serial = _case("rk4_P2_4x2x2_pert_2ranks")
+    u, v = rk4_oracle.solve(serial, int(d["nsteps"]), float(d["dt"]), c0=float(d["c0"]), rho0=float(d["rho0"]), f0=float(d["f0"]),
+                            p0=float(d["p0"]), source_time="tn")
+    for r, m in enumerate(meshes):
+        lex = m.global_lexicographic_ids()
+        assert rel_l2(u[lex], d[f"ref_u_tn_{r}"]) < 1e-12 and rel_l2(v[lex], d[f"ref_v_tn_{r}"]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fused", [False, True], ids=["reference-sequence", "fused"])
+@pytest.mark.parametrize("source_time", ["tn", "t"])
+def test_gpu_solver_reproduces_reference_driven_loop(fused, source_time):
+    import torch
+
+    torch.cuda.set_device(0)
+    ls = pkg("linear_solver")
+    d, meshes, serial = _case("rk4_P2_2x2x2_pert_1rank")
+    s = ls.LinearSpectral3D(serial, np.float64, speed_of_sound=float(d["c0"]), density=float(d["rho0"]), source_frequency=float(d["f0"]),
+                            source_amplitude=float(d["p0"]), fused=fused, source_time=source_time)
+    assert not s.affine
+    s.init()
+    nsteps, dt = int(d["nsteps"]), float(d["dt"])
+    _, steps = s.rk4(0.0, 1.0, dt, max_steps=nsteps)
+    assert steps == nsteps
+    assert rel_l2(s.u_sol(), d[f"ref_u_{source_time}_0"]) < 1e-11 and rel_l2(s.v_sol(), d[f"ref_v_{source_time}_0"]) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["local", "peer"])
+@pytest.mark.parametrize("fused", [False, True], ids=["reference-sequence", "fused"])
+def test_gpu_partitioned_solver_reproduces_reference_driven_loop(fused, transport):
+    """Two in-process ranks, the library's exchange inside every stage, against what the reference's own scatter
+    closures produced inside the same loop."""
+    import torch
+
+    from test_solver_gpu import _lockstep
+
+    torch.cuda.set_device(0)
+    ls, scat, utils = pkg("linear_solver"), pkg("scatterer"), pkg("utils")
+    d, meshes, serial = _case("rk4_P2_4x2x2_pert_2ranks")
+    R = len(meshes)
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = 7300 + 2 * int(fused) + (transport == "peer")
+    comms = [scat.NativeComm(local=(wid, R, r), transport="peer" if transport == "peer" else "rccl") for r in range(R)]
+    solvers = [ls.LinearSpectral3D(meshes[r], np.float64, speed_of_sound=float(d["c0"]), density=float(d["rho0"]),
+                                   source_frequency=float(d["f0"]), source_amplitude=float(d["p0"]), comm=comms[r], fused=fused,
+                                   halo_plan=(od[r], gd[r]), defer_setup_exchange=True) for r in range(R)]
+    _lockstep([s._setup for s in solvers])
+    for s in solvers:
+        s.init()
+    nsteps, dt = int(d["nsteps"]), float(d["dt"])
+    res = _lockstep([s.rk4_schedule(0.0, 1.0, dt, max_steps=nsteps) for s in solvers])
+    torch.cuda.synchronize()
+    assert all(r[1] == nsteps for r in res)
+    for r, (m, s) in enumerate(zip(meshes, solvers)):
+        assert rel_l2(s.u_sol(), d[f"ref_u_tn_{r}"][: m.nlocal]) < 1e-11
+        assert rel_l2(s.v_sol(), d[f"ref_v_tn_{r}"][: m.nlocal]) < 1e-11

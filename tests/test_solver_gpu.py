@@ -238,6 +238,57 @@ def test_driver_scripts_run(tmp_path):
     assert r.returncode == 0 and r.stdout.count("Elapsed time") == 3, r.stdout + r.stderr
 
 
+def test_nonlinear_bowl_driver_dumps_last_period(tmp_path, oracle_c):
+    """demo_nonlinear_bowl.py (counterpart of cuda/demo_nonlinear_bowl.py): complete run on a small bowl-warped box;
+    once t > L/c + 6/f it writes one pressure-field file per time step for exactly one period (:662-680), in the
+    reference's ``x,y,value`` text format; the last dumped field equals the oracle-side Westervelt loop run to the same
+    step."""
+    import os
+    import subprocess
+    import sys
+
+    from conftest import ROOT
+
+    out_dir = os.path.join(tmp_path, "fields")
+    P, N, L = 3, 4, 0.004
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "fenicsx-fus-gpu_amd", "demo_nonlinear_bowl.py"), "--degree", str(P), "--cells", str(N),
+                        "--length", str(L), "--out-dir", out_dir], capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0 and "Solve time per step" in r.stdout, r.stdout + r.stderr
+    lines = {ln.split(":")[0]: ln.split(":")[1].strip() for ln in r.stdout.splitlines() if ln.startswith("Number of")}
+    spp, nstep = int(lines["Number of steps per period"]), int(lines["Number of steps"])
+    files = sorted(os.listdir(out_dir), key=lambda f: int(f.split("_")[-1][:-4]))
+    assert files == [f"pressure_field_{k}.txt" for k in range(spp)]  # one period, no more
+    last = np.loadtxt(os.path.join(out_dir, files[-1]), delimiter=",")
+    assert last.shape == ((P * N + 1) ** 2, 3)
+    # the oracle-side loop on the same mesh up to the step of the last dump
+    boxmesh, ls = pkg("boxmesh"), pkg("linear_solver")
+
+    def bowl(xg):
+        out = xg.copy()
+        yy, zz = xg[:, 1] / L - 0.5, xg[:, 2] / L - 0.5
+        out[:, 0] = xg[:, 0] + 0.15 * (L / N) * 4 * (yy * yy + zz * zz) * (1.0 - xg[:, 0] / L)
+        return out
+
+    mesh = boxmesh.BoxMesh(P, N, length=L, warp=bowl)
+    c0, f0 = 1480.0, 1.1e6
+    h = ls.time_step_parameters(mesh, P, c0, f0, L)
+    dt = 0.40 * h / (c0 * P**2)
+    assert int((1 / f0) / dt) + 1 == spp
+    dt = (1 / f0) / spp
+    first = int(np.floor((L / c0 + 6.0 / f0) / dt)) + 1  # first step whose end time exceeds the collection threshold
+    while not first * dt > L / c0 + 6.0 / f0:
+        first += 1
+    k_last = first + spp - 1
+    assert k_last <= nstep
+    u_ref, _ = rk4_oracle.solve_westervelt(mesh, k_last, dt, c0=c0, f0=f0, oracle_c=oracle_c)
+    lex = mesh.global_lexicographic_ids()
+    gd = mesh.global_dof_dims
+    sel = np.nonzero((lex % gd[2]) == gd[2] // 2)[0]
+    assert np.max(np.abs(u_ref[sel])) > 1.0
+    # the file holds 8 decimals (the reference's "%.8f")
+    assert np.max(np.abs(last[:, 2] - u_ref[sel])) < 1e-7 + 1e-9 * np.max(np.abs(u_ref[sel]))
+
+
 def _lockstep(gens):
     """Advance the generators of several in-process ranks together: each ``next`` runs a rank up to the point
     where it has posted a set of halo exchanges; results are the generators' return values."""
