@@ -31,6 +31,9 @@ def main():
     ap.add_argument("--reference-sequence", action="store_true", help="the reference's unfused launch sequence")
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--out", default=None)
+    ap.add_argument("--eval-out", default=None, metavar="DIR",
+                    help="evaluate the final pressure field at the reference's 100 x 100 points of the z = 0 plane and append the rows "
+                         "'x,y,value' to DIR/pressure_field_nproc<N>.txt, rank after rank (cuda/demo_linear_box.py:128-141,587-605)")
     a = ap.parse_args()
 
     import torch
@@ -84,6 +87,26 @@ def main():
         on_plane = (lex % gd[2]) == 0  # z = 0 plane of the dof grid
         np.savez(a.out if world == 1 else f"{a.out}.rank{rank}", lex=lex[on_plane], u=solver.u_sol()[on_plane],
                  dims=np.array(gd), t=t, steps=steps)
+    if a.eval_out:
+        pe = fusgpu_loader.submodule("point_evaluation")
+        xp = np.linspace(0, domain_length, 100, dtype=float_type)  # :130-139
+        X_p, Y_p = np.meshgrid(xp, xp)
+        points = np.zeros((3, 100 * 100), dtype=float_type)
+        points[0], points[1] = X_p.flatten(), Y_p.flatten()
+        x_eval, cell_eval = pe.compute_eval_params(mesh, points, float_type)
+        u_full = solver.u_sol(with_ghosts=True)
+        data = np.zeros_like(x_eval)
+        if len(cell_eval):
+            data[:, 0], data[:, 1] = x_eval[:, 0], x_eval[:, 1]
+            data[:, 2] = pe.eval_function(mesh, u_full, x_eval, cell_eval)
+        if rank == 0:
+            os.makedirs(a.eval_out, exist_ok=True)
+        for i in range(world):  # :597-605: one rank after the other appends to the same file
+            if world > 1:
+                dist.barrier()
+            if rank == i:
+                with open(os.path.join(a.eval_out, f"pressure_field_nproc{world}.txt"), "a") as f:
+                    np.savetxt(f, data, fmt="%.8f", delimiter=",")
     if world > 1:
         dist.destroy_process_group()
 

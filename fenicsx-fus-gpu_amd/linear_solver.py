@@ -322,9 +322,15 @@ class LinearSpectral3D(StepGraphMixin):
                 pass
             self._rk4_stage_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if first else 0))
 
-    def u_sol(self):
-        """Owned part of the pressure field on the host."""
-        return self.u[: self.nlocal].detach().cpu().numpy()
+    def u_sol(self, with_ghosts=False):
+        """Owned part of the pressure field on the host; ``with_ghosts``: the whole local vector after a forward scatter
+        (``scatter_fwd(u_n_d); u_n_d.copy_to_host(u_n)``, cuda/demo_linear_box.py:568-570 -- what point evaluation needs)."""
+        if not with_ghosts:
+            return self.u[: self.nlocal].detach().cpu().numpy()
+        if self.halo is not None:
+            self.halo.fwd(self.u)
+            torch.cuda.synchronize()
+        return self.u.detach().cpu().numpy()
 
     def v_sol(self):
         return self.v[: self.nlocal].detach().cpu().numpy()

@@ -129,3 +129,93 @@ def test_partitioned_apply_through_adaptor_gpu(oracle_c, P, cells, grid):
         m = rk["mesh"]
         lex = m.global_lexicographic_ids()
         assert rel_l2(s["y"].cpu().numpy()[: m.nlocal], y_ser[lex[: m.nlocal]]) < 1e-12
+
+
+class _AdjacencyList:
+    """The members of dolfinx.graph.AdjacencyList a driver touches."""
+
+    def __init__(self, array, offsets):
+        self.array, self.offsets = np.asarray(array, dtype=np.int32), np.asarray(offsets, dtype=np.int32)
+
+    def links(self, i):
+        return self.array[self.offsets[i]: self.offsets[i + 1]]
+
+    @property
+    def num_nodes(self):
+        return self.offsets.size - 1
+
+
+class DolfinxIndexMapLike:
+    """Nothing but what ``dolfinx.common.IndexMap`` exposes and the reference's compute_scatterer_data reads
+    (cuda/utils.py:20-47): size_local, num_ghosts, ghosts (GLOBAL indices), owners, local_range,
+    index_to_dest_ranks() -> AdjacencyList.  Built from plain arrays only."""
+
+    def __init__(self, size_local, local_range, ghosts, owners, dest_array, dest_offsets):
+        self.size_local, self.num_ghosts = int(size_local), int(len(ghosts))
+        self.local_range = (int(local_range[0]), int(local_range[1]))
+        self.ghosts, self.owners = np.asarray(ghosts, dtype=np.int64), np.asarray(owners, dtype=np.int32)
+        self._dest = _AdjacencyList(dest_array, dest_offsets)
+
+    def index_to_dest_ranks(self):
+        return self._dest
+
+
+def _as_dolfinx_like(im):
+    dest = im.index_to_dest_ranks()
+    return DolfinxIndexMapLike(im.size_local, im.local_range, np.array(im.ghosts), np.array(im.owners), np.array(dest.array),
+                               np.array(dest.offsets))
+
+
+@pytest.mark.parametrize("fixture", ["halo_plan_P2_4x4x2_grid2x2x1_7", "halo_plan_P2_4x4x4_grid2x2x2_lex", "halo_plan_P3_3x3x3_grid3x1x1_5"])
+def test_duck_typed_index_map_end_to_end_on_reference_plans(oracle_c, fixture):
+    """A dolfinx-like IndexMap made of plain arrays -> adaptor -> halo plan == what the REFERENCE's compute_scatterer_data
+    returned for the same partition (tests/golden/halo_plan_*.npz) -> partitioned apply == serial apply."""
+    import os
+
+    from conftest import GOLDEN
+    from oracle import oracle_np
+
+    ad, utils, boxmesh, gll, pre = (pkg(m) for m in ("dolfinx_adaptor", "utils", "boxmesh", "gll", "precompute"))
+    d = np.load(os.path.join(GOLDEN, fixture + ".npz"))
+    P, shape, grid = int(d["P"]), tuple(int(v) for v in d["shape"]), tuple(int(v) for v in d["grid"])
+    go = str(d["ghost_order"])
+    go = go if go in ("owner", "lex") else int(go)
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, ghost_order=go, perturb=0.1, seed=2) for r in range(R)]
+    ims = [_as_dolfinx_like(m.index_map) for m in meshes]
+    # the reference-sort plan, element for element, from the duck-typed maps
+    od, gd = utils.compute_scatterer_data_all(ims, stable=False)
+    for r in range(R):
+        assert np.array_equal(od[r][0], d[f"owners_idx_{r}"]) and np.array_equal(od[r][3], d[f"unique_owners_{r}"])
+        assert np.array_equal(gd[r][0], d[f"ghosts_idx_{r}"]) and np.array_equal(gd[r][3], d[f"unique_ghosts_{r}"])
+    # end to end: scrambled cells -> partition_for_overlap(duck-typed map) -> exchange + operator == serial
+    n = P + 1
+    pts, wts, D = gll.tabulate_1d(P)
+    od, gd = utils.compute_scatterer_data_all(ims)
+    xs, rms = [], []
+    for r, m in enumerate(meshes):
+        G = np.zeros((m.ncells, n**3, 6))
+        pre.compute_scaled_geometrical_factor(G, (m.x_dofs, m.x_g), m.ncells, pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts)),
+                                              gll.tensor_weights_3d(wts))
+        cperm = np.random.default_rng(r).permutation(m.ncells)
+        rm, (Gp, ccp) = ad.partition_for_overlap(m.dofmap[cperm], ims[r], (G[cperm], global_cell_constants(m)[cperm]))
+        assert rm.index_map is ims[r] and rm.nlocal == m.nlocal and rm.nghost == m.nghost
+        x = ref_field(m.dof_coordinates())
+        x[m.nlocal:] = -777.0
+        xs.append(x)
+        rms.append((rm, Gp, ccp))
+    nl = [m.nlocal for m in meshes]
+    oracle_np.scatter_forward_all(xs, od, gd, nl)
+    ys = []
+    for (rm, Gp, ccp), x in zip(rms, xs):
+        y = np.zeros(rm.ndofs)
+        oracle_c.stiffness_apply(P, D, x, ccp, y, Gp, rm.dofmap)
+        ys.append(y)
+    oracle_np.scatter_reverse_all(ys, od, gd, nl)
+    pb = build_problem(P, shape, perturb=0.1, seed=2)
+    ms = pb["mesh"]
+    y_ser = np.zeros(ms.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], global_cell_constants(ms), y_ser, pb["G"], ms.dofmap)
+    for m, y in zip(meshes, ys):
+        lex = m.global_lexicographic_ids()
+        assert rel_l2(y[: m.nlocal], y_ser[lex[: m.nlocal]]) < 1e-13

@@ -228,11 +228,18 @@ def test_driver_scripts_run(tmp_path):
 
     pkgdir = os.path.join(ROOT, "fenicsx-fus-gpu_amd")
     out = os.path.join(tmp_path, "plane.npz")
+    ev = os.path.join(tmp_path, "eval")
     r = subprocess.run([sys.executable, os.path.join(pkgdir, "demo_linear_box.py"), "--cells", "6", "--degree", "3",
-                        "--max-steps", "5", "--out", out], capture_output=True, text=True, timeout=300)
+                        "--max-steps", "5", "--out", out, "--eval-out", ev], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "Solve time per step" in r.stdout, r.stdout + r.stderr
     d = np.load(out)
     assert d["u"].size == (3 * 6 + 1) ** 2 and int(d["steps"]) == 5
+    # the reference's output: 100 x 100 points of the z = 0 plane, rows x,y,value (cuda/demo_linear_box.py:128-141,587-605);
+    # points that coincide with dofs of the plane carry those dofs' values
+    rows = np.loadtxt(os.path.join(ev, "pressure_field_nproc1.txt"), delimiter=",")
+    assert rows.shape == (10000, 3) and abs(rows[:, 0].max() - 0.12) < 1e-8 and np.max(np.abs(rows[:, 2])) > 0
+    corner = rows[(rows[:, 0] == 0) & (rows[:, 1] == 0)][0, 2]
+    assert abs(corner - d["u"][np.argmin(d["lex"])]) < 1e-7
     r = subprocess.run([sys.executable, os.path.join(pkgdir, "time_operators.py"), "--degree", "2", "--cells", "6",
                         "--nreps", "3"], capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and r.stdout.count("Elapsed time") == 3, r.stdout + r.stderr
