@@ -473,6 +473,15 @@ inline int halo_ipc_connect(Halo* h, int nblobs, const void* const* blobs) {
         v.arena = reinterpret_cast<char*>((uintptr_t)v.hd->base);  // same address space (in-process ranks, self-neighbour)
         if (rank != c->rank) st.defer_recv = true;
       } else {
+        // another process (normally another GPU): refuse up front what would otherwise fault inside a kernel
+        int ndev = 0, can = 1;
+        if (hipGetDeviceCount(&ndev) == hipSuccess && v.hd->device >= 0 && v.hd->device < ndev && v.hd->device != c->device &&
+            hipDeviceCanAccessPeer(&can, c->device, v.hd->device) == hipSuccess && !can) {
+          c->last_error = "device " + std::to_string(c->device) + " has no peer access to device " + std::to_string(v.hd->device) +
+                          " (rank " + std::to_string(rank) + ")";
+          return false;
+        }
+        (void)hipGetLastError();
         void* p = nullptr;
         const hipError_t e = hipIpcOpenMemHandle(&p, v.hd->handle, hipIpcMemLazyEnablePeerAccess);
         if (e != hipSuccess) {
