@@ -8,6 +8,11 @@ modes
   golden <fixture.npz> <dtype>     forward (twice) and reverse scatter of the reference closures' inputs == their outputs
   apply <P> <nx> <ny> <nz> <gx> <gy> <gz> <ghost_order> <schedule>
                                    HaloApply (two applies) on a partitioned perturbed box == the serial C oracle
+  solver <rk4 fixture.npz> <fused 0|1>
+                                   the linear RK4 solver, one PROCESS per rank, == what the reference's own operators and
+                                   scatter closures produced in the same loop (tests/golden/rk4_*_2ranks.npz)
+  deadpeer                         the owner rank never posts its exchange: the ghosting rank's receive must give up after
+                                   FUS_IPC_SPIN_SECONDS and report a time-out instead of hanging
 Prints PEER_WORKER_OK <rank> on success; any failure is a non-zero exit."""
 import os
 import sys
@@ -23,7 +28,7 @@ def main():
     mode, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     args = sys.argv[5:]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-    os.environ.setdefault("FUS_IPC_SPIN_SECONDS", "10")
+    os.environ.setdefault("FUS_IPC_SPIN_SECONDS", "1" if mode == "deadpeer" else "10")
     import torch
     import torch.distributed as dist
 
@@ -105,6 +110,50 @@ def main():
         assert np.allclose(x_d.cpu().numpy(), pb["x"][lex], rtol=0, atol=1e-12), "ghosts not refreshed"
         dist.barrier()
         halo.fwd.close(), halo.rev.close()
+    elif mode == "solver":
+        d = np.load(args[0])
+        fused = bool(int(args[1]))
+        ls = pkg("linear_solver")
+        P, shape, grid = int(d["P"]), tuple(int(v) for v in d["shape"]), tuple(int(v) for v in d["grid"])
+        assert int(np.prod(grid)) == world
+        mesh = boxmesh.BoxMesh(P, shape, grid=grid, rank=rank, length=tuple(float(v) for v in d["lengths"]), perturb=float(d["perturb"]),
+                               seed=int(d["seed"]))
+        s = ls.LinearSpectral3D(mesh, np.float64, speed_of_sound=float(d["c0"]), density=float(d["rho0"]), source_frequency=float(d["f0"]),
+                                source_amplitude=float(d["p0"]), comm=comm, fused=fused)
+        s.init()
+        nsteps, dt = int(d["nsteps"]), float(d["dt"])
+        _, steps = s.rk4(0.0, 1.0, dt, max_steps=nsteps)
+        torch.cuda.synchronize()
+        assert steps == nsteps and s.halo.schedule_kind == "concurrent" and s.halo.health() == 0
+        eu = rel_l2(s.u_sol(), d[f"ref_u_tn_{rank}"][: mesh.nlocal])
+        ev = rel_l2(s.v_sol(), d[f"ref_v_tn_{rank}"][: mesh.nlocal])
+        assert eu < 1e-11 and ev < 1e-11, f"rank {rank}: u {eu} v {ev} vs the reference-driven loop"
+        full = s.u_sol(with_ghosts=True)  # forward scatter at the end, as the demo does before copying to the host
+        assert rel_l2(full, d[f"ref_u_tn_{rank}"]) < 1e-11
+        dist.barrier()
+        del s
+    elif mode == "deadpeer":
+        import time
+
+        m = boxmesh.BoxMesh(2, (4, 2, 2), grid=(2, 1, 1), rank=rank)
+        meshes = [boxmesh.BoxMesh(2, (4, 2, 2), grid=(2, 1, 1), rank=r) for r in range(2)]
+        od, gd = utils.compute_scatterer_data_all([mm.index_map for mm in meshes])
+        fwd = scat.scatter_forward(comm, od[rank], gd[rank], m.nlocal, np.float64)  # connects (collective)
+        buf = torch.zeros(m.ndofs, dtype=torch.float64, device=dev)
+        if rank == 1:  # the ghosting rank posts; its owner (rank 0) stays silent
+            t0 = time.perf_counter()
+            fwd(buf)
+            torch.cuda.synchronize()
+            el = time.perf_counter() - t0
+            st = fwd.status()
+            assert st["timeouts"] >= 1, st
+            assert 0.5 < el < 8.0, el  # FUS_IPC_SPIN_SECONDS = 1 for this mode: gave up, did not hang
+            t0 = time.perf_counter()
+            fwd(buf)  # after a time-out the halo no longer waits at all
+            torch.cuda.synchronize()
+            assert time.perf_counter() - t0 < 0.5
+        dist.barrier()
+        fwd.close()
     else:
         raise SystemExit(f"unknown mode {mode}")
     comm.close()

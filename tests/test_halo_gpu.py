@@ -326,6 +326,23 @@ def test_peer_transport_real_processes_partitioned_apply(gpu, P, cells, grid, gh
     _run_peer_world(int(np.prod(grid)), "apply", [P, *cells, *grid, ghost_order, schedule])
 
 
+@pytest.mark.parametrize("fused", [0, 1], ids=["reference-sequence", "fused"])
+def test_peer_transport_real_processes_rk4_solver_vs_reference_driven_loop(gpu, fused):
+    """Two real processes, PEER transport, the whole linear RK4 solver (set-up reverse scatter of the lumped mass, per
+    stage the grouped forward scatter of (u_n, v_n) and the reverse scatter of b, concurrent schedule) against the
+    fixture produced by the reference's own operators and scatter closures in the same loop."""
+    import os
+
+    _run_peer_world(2, "solver", [os.path.join(os.path.dirname(__file__), "golden", "rk4_P2_4x2x2_pert_2ranks.npz"), fused])
+
+
+def test_peer_transport_dead_peer_times_out_instead_of_hanging(gpu):
+    """Every device-side wait of the PEER transport is bounded: a rank whose neighbour never sends gets its time-out
+    counted (``status()["timeouts"]``) after FUS_IPC_SPIN_SECONDS and its kernels drain; later exchanges of that halo do
+    not wait at all."""
+    _run_peer_world(2, "deadpeer", [])
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("direct", [True, False], ids=["direct", "permuted"])
 @pytest.mark.parametrize("transport", ["rccl", "peer"])
