@@ -214,12 +214,20 @@ int main(int argc, char** argv) {
     for (void* p : {(void*)d_dphi, (void*)d_w3, (void*)d_G2, (void*)d_dJ2}) (void)hipFree(p);
   }
 
-  // ---- halo exchange, RCCL transport, 1-rank world: rank 0 ghosts 100 of its own dofs
-  {
-    unsigned char id[FUS_UNIQUE_ID_BYTES];
-    CHECK_FUS(fus_comm_unique_id(id));
+  // ---- halo exchange in a 1-rank world whose rank ghosts 100 of its own dofs: the RCCL transport (unique id ->
+  // fus_comm_create) and the PEER transport (fus_comm_create_peer; the arena handles go through the blob round trip a
+  // multi-rank host does with MPI_Allgatherv: export -> connect), with the exchanges of the PEER pass issued on the
+  // communicator's own stream between fus_comm_fork and fus_comm_join, as HaloApply's concurrent schedule does
+  for (int transport = 0; transport < 2; ++transport) {
+    const char* tname = transport == 0 ? "RCCL send/recv to self" : "PEER transport, own arena";
     fus_comm_t comm = nullptr;
-    CHECK_FUS(fus_comm_create(id, 1, 0, &comm));
+    if (transport == 0) {
+      unsigned char id[FUS_UNIQUE_ID_BYTES];
+      CHECK_FUS(fus_comm_unique_id(id));
+      CHECK_FUS(fus_comm_create(id, 1, 0, &comm));
+    } else {
+      CHECK_FUS(fus_comm_create_peer(1, 0, &comm));
+    }
     const int64_t N = 1000, ng = 100;
     std::vector<int64_t> o_idx(ng), g_idx(ng);
     for (int64_t i = 0; i < ng; ++i) {
@@ -230,6 +238,12 @@ int main(int argc, char** argv) {
     const int64_t size = ng;
     fus_halo_t halo = nullptr;
     CHECK_FUS(fus_halo_create(comm, 8, N, ng, 1, &rank0, &size, o_idx.data(), 1, &rank0, &size, g_idx.data(), &halo));
+    if (transport == 1) {
+      std::vector<char> blob((size_t)fus_halo_ipc_blob_bytes(halo));
+      CHECK_FUS(fus_halo_ipc_export(halo, blob.data()));
+      const void* blobs[1] = {blob.data()};  // every rank's blob, here: one rank, its own neighbour
+      CHECK_FUS(fus_halo_ipc_connect(halo, 1, blobs));
+    }
     std::vector<double> v(N + ng), ref;
     for (int64_t i = 0; i < N + ng; ++i) v[i] = std::sin(0.1 * i) + 2.0;
     double* d_v = nullptr;
@@ -238,14 +252,22 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipStreamCreate(&s));
     // forward: ghosts take their owner's value
     CHECK_HIP(hipMemcpyAsync(d_v, v.data(), v.size() * 8, hipMemcpyHostToDevice, s));
-    CHECK_FUS(fus_halo_forward_begin(halo, d_v, s));
-    CHECK_FUS(fus_halo_forward_end(halo, d_v, s));
+    if (transport == 0) {
+      CHECK_FUS(fus_halo_forward_begin(halo, d_v, s));
+      CHECK_FUS(fus_halo_forward_end(halo, d_v, s));
+    } else {
+      void* cs = fus_comm_stream(comm);
+      CHECK_FUS(fus_comm_fork(comm, s));  // the communicator's stream after everything on s so far (the upload)
+      CHECK_FUS(fus_halo_forward_begin(halo, d_v, cs));
+      CHECK_FUS(fus_halo_forward_end(halo, d_v, cs));
+      CHECK_FUS(fus_comm_join(comm, s));  // s after the exchange
+    }
     std::vector<double> got(v.size());
     CHECK_HIP(hipMemcpyAsync(got.data(), d_v, v.size() * 8, hipMemcpyDeviceToHost, s));
     CHECK_HIP(hipStreamSynchronize(s));
     ref = v;
     for (int64_t i = 0; i < ng; ++i) ref[N + o_idx[i]] = v[g_idx[i]];
-    report("halo forward (RCCL send/recv to self)", rel_l2(got, ref.data()), 1e-15);
+    report((std::string("halo forward (") + tname + ")").c_str(), rel_l2(got, ref.data()), 1e-15);
     // reverse: owners accumulate their ghosts' partial sums
     CHECK_HIP(hipMemcpyAsync(d_v, v.data(), v.size() * 8, hipMemcpyHostToDevice, s));
     CHECK_FUS(fus_halo_reverse(halo, d_v, s));
@@ -253,7 +275,13 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipStreamSynchronize(s));
     ref = v;
     for (int64_t i = 0; i < ng; ++i) ref[g_idx[i]] += v[N + o_idx[i]];
-    report("halo reverse (RCCL send/recv to self)", rel_l2(got, ref.data()), 1e-15);
+    report((std::string("halo reverse (") + tname + ")").c_str(), rel_l2(got, ref.data()), 1e-15);
+    if (transport == 1) {
+      int64_t st[4] = {-1, -1, -1, -1}, sync_to = -1;
+      CHECK_FUS(fus_halo_ipc_status(halo, st));
+      CHECK_FUS(fus_comm_sync_timeouts(comm, &sync_to));
+      report("PEER transport: device-side waits that timed out", (double)(st[0] + sync_to), 0.5);
+    }
     CHECK_FUS(fus_halo_destroy(halo));
     CHECK_FUS(fus_comm_destroy(comm));
     (void)hipFree(d_v);

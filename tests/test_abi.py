@@ -119,15 +119,16 @@ def test_raw_golden_twin_matches_npz():
 def test_c_abi_golden_plain_cpp_host():
     """examples/c_abi_golden.cpp: a C++ host with no Python/torch compares stiffness (three entry points),
     cell / facet mass and the device precompute with the REFERENCE'S outputs (golden twin), and runs a
-    fus_halo_* exchange over the RCCL transport in a 1-rank world."""
+    fus_halo_* exchange in a 1-rank world over the RCCL transport and over the PEER transport (arena blob export ->
+    connect, exchanges on the communicator's stream between fus_comm_fork and fus_comm_join)."""
     import subprocess
 
     exe = os.path.join(ROOT, "examples", "c_abi_golden")
-    if not os.path.exists(exe):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)  # rebuilds if the source is newer
     r = subprocess.run([exe, os.path.join(ROOT, "tests", "golden", "ops_P4_2x2x2_pert_float64.bin")],
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C_ABI_GOLDEN_OK" in r.stdout, r.stdout + r.stderr
+    assert "halo reverse (PEER transport, own arena)" in r.stdout and "halo forward (RCCL send/recv to self)" in r.stdout
 
 
 @pytest.mark.gpu
