@@ -935,6 +935,12 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     region_ms = r0.elapsed_time(r1) / args.steps
+    if halo is not None:
+        # a device-side wait that gave up inside the timed region means an exchange did not deliver: no line then
+        late = torch.tensor([float(halo.health())], dtype=torch.float64, device=coll_device(device))
+        dist.all_reduce(late)
+        if float(late.item()) != 0.0:
+            raise SystemExit(f"rank {rank}: {int(late.item())} device-side halo wait(s) timed out during the timed region: the run is invalid")
 
     # isolated launches (outside the timed region): one event pair per step, as the reference's
     # protocol times one apply at a time (cuda/time_operators.py:272-282); agrees with the per-dispatch

@@ -35,6 +35,8 @@ def main():
     ap.add_argument("--transport", default="native", choices=["native", "local", "peer"],
                     help="native: RCCL to self; local: the library's in-process transport (pack + device copy + unpack, no RCCL kernel)")
     ap.add_argument("--two-stream", action="store_true", help="also time boundary cells on a high-priority side stream next to ONE interior launch")
+    ap.add_argument("--message-scale", type=float, default=1.0,
+                    help="shrink the messages to this fraction of the config-4 size (what of the exposed cost is per exchange, what per byte)")
     ap.add_argument("--random-indices", action="store_true",
                     help="owned dofs of the messages drawn at random over the vector (worst case) instead of the faces / edges / corner of a block")
     ap.add_argument("--paired", type=int, default=0, metavar="ROUNDS",
@@ -84,6 +86,13 @@ def main():
         g_idx = np.concatenate([lex(z0, ii, jj), lex(ii, z0, jj), lex(ii, jj, z0), lex(zr, zr, ar), lex(zr, ar, zr), lex(ar, zr, zr),
                                 np.array([0])]).astype(np.int64) % N  # (the last three lattice planes wrap: the ghost block ends the vector)
         assert g_idx.size == ng
+    if a.message_scale != 1.0:
+        ng = max(1, int(ng * a.message_scale))
+        g_idx = np.ascontiguousarray(g_idx[:ng])
+        o_idx = (rng.permutation(ng) if a.permuted else np.arange(ng)).astype(np.int64)
+        N = mesh.ndofs - ng
+        g_idx = g_idx % N
+        od = [o_idx, np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
     gd = [g_idx, np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
 
     if a.reserve_cus:
@@ -148,7 +157,7 @@ def main():
         d_split = float(np.median(np.array(res["schedule, no exchange"]) - np.array(res["single launch"])))
         d_halo = float(np.median(np.array(res["schedule + both exchanges"]) - np.array(res["single launch"])))
         d_exch = float(np.median(np.array(res["schedule + both exchanges"]) - np.array(res["schedule, no exchange"])))
-        print(f"paired [{a.transport}{', permuted ghosts' if a.permuted else ''}{', random indices' if a.random_indices else ''}; schedule {halo.schedule_kind}, lead {halo.lead_cells}; {a.paired} rounds x {a.reps} applies]: "
+        print(f"paired [{a.transport}{', permuted ghosts' if a.permuted else ''}{', random indices' if a.random_indices else ''}{', messages x ' + str(a.message_scale) if a.message_scale != 1.0 else ''}; schedule {halo.schedule_kind}, lead {halo.lead_cells}; {a.paired} rounds x {a.reps} applies]: "
               f"single launch {med['single launch']:7.1f} us | schedule without exchange {med['schedule, no exchange']:7.1f} ({d_split:+5.1f}) | "
               f"with both exchanges {med['schedule + both exchanges']:7.1f} us: vs single launch {d_halo:+5.1f} us = {100 * d_halo / med['single launch']:4.1f} % "
               f"(exchanges {d_exch:+5.1f}, split {d_split:+5.1f}); time-outs {halo.health()}", flush=True)
