@@ -893,6 +893,8 @@ def main():
             dist.all_reduce(flag, op=dist.ReduceOp.MIN)
             if float(flag.item()) == 1.0:
                 verdict = check_halo()
+                if kind in os.environ.get("FUS_BENCH_TEST_REJECT", "").split(","):  # test hook: exercise the fall-back path
+                    verdict = dict(verdict, ok=False, rejected_by="FUS_BENCH_TEST_REJECT")
             if verdict is not None and verdict["ok"]:
                 transport, halo_check = kind, verdict
                 tried.append({"transport": kind, "result": "ok"})

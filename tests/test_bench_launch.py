@@ -101,6 +101,25 @@ def test_distributed_code_path_on_one_gpu(halo):
 
 
 @pytest.mark.gpu
+def test_transport_fallback_after_a_failed_halo_check():
+    """A transport whose exchanges fail the run's own check is torn down (halo objects, communicator) and the next one
+    is brought up and checked: peer rejected -> native (RCCL) used; peer and native rejected -> torch; the line says
+    what was tried.  (The rejection is injected: FUS_BENCH_TEST_REJECT.)"""
+    for reject, used in (("peer", "ncclSend"), ("peer,native", "all_to_all_single")):
+        r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--cells", "12", "--no-cpu-baseline"],
+                           env=_env(FUS_BENCH_FORCE_DIST="1", FUS_BENCH_TEST_REJECT=reject), capture_output=True, text=True, timeout=900)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+        cfg = _one_json_line(r.stdout)["config"]
+        assert used in cfg["halo_transport"] and cfg["halo_check"]["ok"] is True
+        tried = cfg["halo_transports_tried"]
+        assert [t["transport"] for t in tried] == ["peer", "native", "torch"][: len(reject.split(",")) + 1]
+        assert all("rejected" in t["result"] for t in tried[:-1]) and tried[-1]["result"] == "ok"
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--cells", "12", "--no-cpu-baseline"],
+                       env=_env(FUS_BENCH_FORCE_DIST="1", FUS_BENCH_TEST_REJECT="peer,native,torch"), capture_output=True, text=True, timeout=900)
+    assert r.returncode != 0 and "no halo transport passed" in (r.stdout + r.stderr)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("dist_path", [False, True])
 def test_mass_mode_line(dist_path):
     """SURVEY 8d's second operator line (cell mass apply), alone and through the N > 1 code path."""
