@@ -25,6 +25,7 @@
 #include <vector>
 
 #include "fus_gpu.h"
+#include "fus_gpu.hpp"
 
 struct Entry {
   int dtype = 0;
@@ -211,6 +212,26 @@ int main(int argc, char** argv) {
     CHECK_HIP(hipMemcpy(dJ2.data(), d_dJ2, dJ2.size() * 8, hipMemcpyDeviceToHost));
     report("device precompute: G", rel_l2(G2, g["ref_G"].f64()), 1e-13);
     report("device precompute: detJ", rel_l2(dJ2, g["ref_detJ"].f64()), 1e-13);
+    // ---- the C++ functor twins of cpp/common/spectral_op.hpp (include/fus_gpu.hpp): constructed from the dofmap and the
+    // P1 geometry (they compute G / detJ on the device and own their batch plan), applied like the reference's operator()
+    if (P == 4) {
+      try {
+        const fus_gpu::Geometry<double> geo{d_xg, d_xd, d_dphi, d_w3};
+        fus_gpu::StiffnessSpectral3D<double, 4> stiffness(d_dm, ncell, geo, d_D);
+        fus_gpu::MassSpectral3D<double, 4> mass(d_dm, ncell, geo);
+        CHECK_HIP(reset_y());
+        stiffness(d_x, d_cc, d_y);
+        CHECK_HIP(fetch_y());
+        report("StiffnessSpectral3D<double,4>::operator()", rel_l2(y, g["ref_y_stiffness"].f64()), tol);
+        CHECK_HIP(reset_y());
+        mass(d_x, d_cc, d_y);
+        CHECK_HIP(fetch_y());
+        report("MassSpectral3D<double,4>::operator()", rel_l2(y, g["ref_y_mass"].f64()), tol);
+      } catch (const std::exception& e) {
+        std::fprintf(stderr, "functor twins: %s\n", e.what());
+        ok = false;
+      }
+    }
     for (void* p : {(void*)d_dphi, (void*)d_w3, (void*)d_G2, (void*)d_dJ2}) (void)hipFree(p);
   }
 

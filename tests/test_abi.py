@@ -129,6 +129,8 @@ def test_c_abi_golden_plain_cpp_host():
                        capture_output=True, text=True, timeout=300)
     assert r.returncode == 0 and "C_ABI_GOLDEN_OK" in r.stdout, r.stdout + r.stderr
     assert "halo reverse (PEER transport, own arena)" in r.stdout and "halo forward (RCCL send/recv to self)" in r.stdout
+    # the C++ functor twins of cpp/common/spectral_op.hpp (include/fus_gpu.hpp) against the reference's outputs
+    assert "StiffnessSpectral3D<double,4>::operator()" in r.stdout and "MassSpectral3D<double,4>::operator()" in r.stdout
 
 
 @pytest.mark.gpu
