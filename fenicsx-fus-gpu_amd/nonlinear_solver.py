@@ -103,6 +103,14 @@ class WesterveltSpectral3D(StepGraphMixin):
         self.mass_cell(self.g, self.cc5, self.w5, self.detJ, self.dofmap)
         # the reverse scatters of the three assembled diagonals (m0, w2, w5), as one grouped exchange: now, or
         # by a driver that runs several ranks from one process (setup_schedule, see LinearSpectral3D)
+        # the third reverse closure of the set-up exchange is built HERE, with the others: building a closure is a collective
+        # step of the PEER transport (arena handles), and ranks driven from one process must all have built theirs before
+        # any of them exchanges
+        self._rev_w5 = None
+        if self.halo is not None:
+            from .scatterer import scatter_reverse
+
+            self._rev_w5 = scatter_reverse(self.halo.comm, self.halo.owners_data, self.halo.ghosts_data, self.nlocal, self.tdt_np)
         self._setup = self.setup_schedule()
         if not defer_setup_exchange:
             for _ in self._setup:
@@ -140,11 +148,9 @@ class WesterveltSpectral3D(StepGraphMixin):
 
     def setup_schedule(self):
         if self.halo is not None:
-            from .scatterer import begin_all, scatter_reverse
+            from .scatterer import begin_all
 
-            mk = lambda: scatter_reverse(self.halo.comm, self.halo.owners_data, self.halo.ghosts_data, self.nlocal,  # noqa: E731
-                                         self.tdt_np)
-            self._rev_setup = [self.halo.rev, self.rev_m, mk()]
+            self._rev_setup = [self.halo.rev, self.rev_m, self._rev_w5]
             pending = begin_all(zip(self._rev_setup, (self.m0, self.w2, self.w5)))
             yield "reverse"
             for sc, vec, wk in pending:

@@ -116,7 +116,7 @@ def main():
         # numba-cpu/test_operators.py:274-279
         return 100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])
 
-    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter | plan | rk4
+    only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter | plan | rk4 | rk4nl
 
     # ---- operator + precompute fixtures --------------------------------------
     cases = []
@@ -403,6 +403,149 @@ def main():
                     out[f"ref_m_{r}"] = s_["m"]
             np.savez_compressed(os.path.join(HERE, f"rk4_{tag}.npz"), **out)
             print("wrote", f"rk4_{tag}", "dt", dt, "max|u|", max(float(np.abs(out[f"ref_u_tn_{r}"]).max()) for r in range(R)))
+
+
+    # ---- the Westervelt loop the same way: cuda/demo_nonlinear_bowl.py:357-374 (coefficients), :458-475 (steady part of
+    # the lumped mass, incl. the absorbing-facet term), :533-650 (stage: g and dg/dt, w_n = v_n^2, three forward scatters,
+    # m = M(cc2) u_n + m0 with its own reverse scatter, two stiffness applies, cell mass of w_n, three facet masses,
+    # reverse scatter of b, pointwise divide).  Every array operation is the imported reference's (numba-cpu flavour);
+    # its CUDA-only ``square`` kernel (cuda/operators.py) is the one pointwise op done in numpy (w_n = v_n * v_n).
+    if only in ("all", "rk4nl"):
+        ls = fusgpu_loader.submodule("linear_solver")
+        c0, rho0, f0, beta0, att_dB = 1480.0, 1000.0, 1.1e6, 3.5, 0.2
+        p0 = rho0 * c0 * 0.38557513826589934  # :56-62
+        w0 = 2 * np.pi * f0
+        delta0 = 2 * (att_dB / 20 * np.log(10)) * c0**3 / w0 / w0  # compute_diffusivity_of_sound, cuda/utils.py:157-162
+        for tag, P, shape, grid, nsteps in (("P2_2x2x2_bowl_1rank", 2, (2, 2, 2), (1, 1, 1), 10), ("P2_4x2x2_bowl_2ranks", 2, (4, 2, 2), (2, 1, 1), 8)):
+            n = P + 1
+            R = int(np.prod(grid))
+            L = 0.0015 * shape[0]
+            lengths = tuple(L * s_ / shape[0] for s_ in shape)
+            amp = 0.15 * (L / shape[0])
+
+            def bowl(xg, L=L, lengths=lengths, amp=amp):
+                out = xg.copy()
+                yy, zz = xg[:, 1] / lengths[1] - 0.5, xg[:, 2] / lengths[2] - 0.5
+                out[:, 0] = xg[:, 0] + amp * 4 * (yy * yy + zz * zz) * (1.0 - xg[:, 0] / L)
+                return out
+
+            meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, length=lengths, warp=bowl) for r in range(R)]
+            od_all, gd_all = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+            pts, wts, D = gll.tabulate_1d(P)
+            wts3, wts2 = gll.tensor_weights_3d(wts), gll.tensor_weights_2d(wts)
+            dphi_g, dphi_f = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts)), pre.tabulate_facet_gradients(pts)
+            h = min(ls.time_step_parameters(m, P, c0, f0, L) for m in meshes)
+            dt = 0.40 * h / (c0 * P**2)  # :119-125
+            dt = (1.0 / f0) / (int((1.0 / f0) / dt) + 1)
+            rk = []
+            for m in meshes:
+                nc = m.ncells
+                G, detJ = np.zeros((nc, n**3, 6)), np.zeros((nc, n**3))
+                ref_pre.compute_scaled_geometrical_factor(G, (m.x_dofs, m.x_g), nc, dphi_g, wts3)
+                ref_pre.compute_scaled_jacobian_determinant(detJ, (m.x_dofs, m.x_g), nc, dphi_g, wts3)
+                bd1, bd2 = m.boundary_facets([2]), m.boundary_facets([3])
+                dF1, dF2 = np.zeros((bd1.shape[0], n * n)), np.zeros((bd2.shape[0], n * n))
+                if bd1.shape[0]:
+                    ref_pre.compute_boundary_facets_scaled_jacobian_determinant(dF1, (m.x_dofs, m.x_g), bd1, dphi_f, wts2)
+                if bd2.shape[0]:
+                    ref_pre.compute_boundary_facets_scaled_jacobian_determinant(dF2, (m.x_dofs, m.x_g), bd2, dphi_f, wts2)
+                full = lambda k, v: np.full(k, v)  # noqa: E731
+                rk.append(dict(m=m, G=G, detJ=detJ, dF1=dF1, dF2=dF2, fd1=m.facet_dofmap(bd1), fd2=m.facet_dofmap(bd2),
+                               cc1=full(nc, 1.0 / rho0 / c0 / c0), cc2=full(nc, -2.0 * beta0 / rho0 / rho0 / c0**4),          # :358-359
+                               cc3=full(nc, -1.0 / rho0), cc4=full(nc, -delta0 / rho0 / c0 / c0),                              # :360-361
+                               cc5=full(nc, 2.0 * beta0 / rho0 / rho0 / c0**4),                                                # :362
+                               fc1_1=full(bd1.shape[0], 1.0 / rho0), fc2_1=full(bd1.shape[0], delta0 / rho0 / c0 / c0),        # :366-368
+                               fc1_2=full(bd2.shape[0], delta0 / rho0 / c0**3), fc2_2=full(bd2.shape[0], -1.0 / rho0 / c0)))   # :372-374
+            world = FakeWorld()
+            fwd = [ref_sc.scatter_forward(FakeComm(world, r), od_all[r], gd_all[r], meshes[r].nlocal, np.float64) for r in range(R)]
+            rev = [ref_sc.scatter_reverse(FakeComm(world, r), od_all[r], gd_all[r], meshes[r].nlocal, np.float64) for r in range(R)]
+
+            def scatter_all(closures, arrays):
+                if R == 1:
+                    return
+                world.box.clear()
+                scratch = [a.copy() for a in arrays]
+                for r in range(R):
+                    try:
+                        closures[r](scratch[r])
+                    except KeyError:
+                        pass
+                for r in range(R):
+                    closures[r](arrays[r])
+
+            stiff = ref_ops.stiffness_operator(P, D.flatten(), np.float64)
+            mass_c, mass_f = ref_ops.mass_operator(n**3, np.float64), ref_ops.mass_operator(n * n, np.float64)
+            st = []
+            for d in rk:
+                nd_ = d["m"].ndofs
+                z = lambda nd_=nd_: np.zeros(nd_)  # noqa: E731
+                st.append(dict(u=z(), v=z(), un=z(), vn=z(), u0=z(), v0=z(), ku=z(), kv=z(), g=z(), dg=z(), b=z(), m=z(), m0=z(), u_n=z(),
+                               v_n=z(), w_n=z(), axpy=ref_ops.axpy(nd_)))
+            for d, s_ in zip(rk, st):  # :458-468  m0 = M(cc1) 1 + M_f2(fc1_2) 1, scatter_rev
+                ones = np.zeros(d["m"].ndofs)
+                ref_ops.fill(1.0, ones)
+                mass_c(ones, d["cc1"], s_["m0"], d["detJ"], d["m"].dofmap)
+                if d["fd2"].size:
+                    mass_f(ones, d["fc1_2"], s_["m0"], d["dF2"], d["fd2"])
+            scatter_all(rev, [s_["m0"] for s_ in st])
+            a_runge, b_runge, c_runge = (0.0, 0.5, 0.5, 1.0), (1.0 / 6.0, 1.0 / 3.0, 1.0 / 3.0, 1.0 / 6.0), (0.0, 0.5, 0.5, 1.0)
+            t = 0.0
+            for _ in range(nsteps):
+                for s_ in st:
+                    ref_ops.copy(s_["u"], s_["u0"])
+                    ref_ops.copy(s_["v"], s_["v0"])
+                for i in range(4):
+                    tn = t + c_runge[i] * dt  # this package's default (numba-cpu / C++ convention); the CUDA demo uses t
+                    T_, alpha = 1.0 / f0, 4.0
+                    if tn < T_ * alpha:
+                        window = 0.5 * (1.0 - np.cos(f0 * np.pi * tn / alpha))
+                        dwindow = 0.5 * np.pi * f0 / alpha * np.sin(f0 * np.pi * tn / alpha)
+                    else:
+                        window, dwindow = 1.0, 0.0
+                    g_vals = window * 2.0 * p0 * w0 / c0 * np.cos(w0 * tn)  # :569-576
+                    dg_vals = dwindow * 2.0 * p0 * w0 / c0 * np.cos(w0 * tn) - window * 2.0 * p0 * w0**2 / c0 * np.sin(w0 * tn)  # :577-591
+                    for d, s_ in zip(rk, st):
+                        ref_ops.copy(s_["u0"], s_["un"])
+                        ref_ops.copy(s_["v0"], s_["vn"])
+                        s_["axpy"](a_runge[i] * dt, s_["ku"], s_["un"])
+                        s_["axpy"](a_runge[i] * dt, s_["kv"], s_["vn"])
+                        ref_ops.copy(s_["vn"], s_["ku"])
+                        ref_ops.fill(g_vals, s_["g"])
+                        ref_ops.fill(dg_vals, s_["dg"])
+                        ref_ops.copy(s_["un"], s_["u_n"])  # :597-599
+                        ref_ops.copy(s_["vn"], s_["v_n"])
+                        s_["w_n"][:] = s_["vn"] * s_["vn"]  # square[...](vn_d, w_n_d): CUDA-only kernel, done in numpy
+                    for key in ("u_n", "v_n", "w_n"):
+                        scatter_all(fwd, [s_[key] for s_ in st])  # :600-602
+                    for d, s_ in zip(rk, st):
+                        ref_ops.fill(0.0, s_["m"])  # :605-608
+                        mass_c(s_["u_n"], d["cc2"], s_["m"], d["detJ"], d["m"].dofmap)
+                    scatter_all(rev, [s_["m"] for s_ in st])  # :609
+                    for d, s_ in zip(rk, st):
+                        s_["axpy"](1.0, s_["m0"], s_["m"])  # :611
+                        ref_ops.fill(0.0, s_["b"])  # :614
+                        stiff(s_["u_n"], d["cc3"], s_["b"], d["G"], d["m"].dofmap)  # :616-621
+                        stiff(s_["v_n"], d["cc4"], s_["b"], d["G"], d["m"].dofmap)
+                        mass_c(s_["w_n"], d["cc5"], s_["b"], d["detJ"], d["m"].dofmap)  # :622-624
+                        if d["fd1"].size:
+                            mass_f(s_["g"], d["fc1_1"], s_["b"], d["dF1"], d["fd1"])  # :625-631
+                            mass_f(s_["dg"], d["fc2_1"], s_["b"], d["dF1"], d["fd1"])
+                        if d["fd2"].size:
+                            mass_f(s_["v_n"], d["fc2_2"], s_["b"], d["dF2"], d["fd2"])  # :632-635
+                    scatter_all(rev, [s_["b"] for s_ in st])  # :636
+                    for s_ in st:
+                        ref_ops.pointwise_divide(s_["b"], s_["m"], s_["kv"])  # :639
+                        s_["axpy"](b_runge[i] * dt, s_["ku"], s_["u"])  # :645-646
+                        s_["axpy"](b_runge[i] * dt, s_["kv"], s_["v"])
+                t += dt
+            scatter_all(fwd, [s_["u"] for s_ in st])
+            scatter_all(fwd, [s_["v"] for s_ in st])
+            out = {"P": P, "shape": np.array(shape), "grid": np.array(grid), "lengths": np.array(lengths), "bowl_amplitude": amp, "dt": dt,
+                   "nsteps": nsteps, "c0": c0, "rho0": rho0, "f0": f0, "p0": p0, "beta": beta0, "att_dB": att_dB}
+            for r, s_ in enumerate(st):
+                out[f"ref_u_tn_{r}"], out[f"ref_v_tn_{r}"], out[f"ref_m0_{r}"] = s_["u"], s_["v"], s_["m0"]
+            np.savez_compressed(os.path.join(HERE, f"rk4nl_{tag}.npz"), **out)
+            print("wrote", f"rk4nl_{tag}", "dt", dt, "max|u|", max(float(np.abs(out[f"ref_u_tn_{r}"]).max()) for r in range(R)))
 
 
 if __name__ == "__main__":

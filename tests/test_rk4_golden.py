@@ -99,3 +99,83 @@ def test_gpu_partitioned_solver_reproduces_reference_driven_loop(fused, transpor
     for r, (m, s) in enumerate(zip(meshes, solvers)):
         assert rel_l2(s.u_sol(), d[f"ref_u_tn_{r}"][: m.nlocal]) < 1e-11
         assert rel_l2(s.v_sol(), d[f"ref_v_tn_{r}"][: m.nlocal]) < 1e-11
+
+
+# ------------------------------------------------------------------------------------------- Westervelt loop
+def _case_nl(name):
+    d = np.load(os.path.join(GOLDEN, name + ".npz"))
+    boxmesh = pkg("boxmesh")
+    P, shape, grid = int(d["P"]), tuple(int(v) for v in d["shape"]), tuple(int(v) for v in d["grid"])
+    lengths, amp = tuple(float(v) for v in d["lengths"]), float(d["bowl_amplitude"])
+    L = lengths[0]
+
+    def bowl(xg):
+        out = xg.copy()
+        yy, zz = xg[:, 1] / lengths[1] - 0.5, xg[:, 2] / lengths[2] - 0.5
+        out[:, 0] = xg[:, 0] + amp * 4 * (yy * yy + zz * zz) * (1.0 - xg[:, 0] / L)
+        return out
+
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, length=lengths, warp=bowl) for r in range(R)]
+    serial = boxmesh.BoxMesh(P, shape, length=lengths, warp=bowl)
+    kw = dict(c0=float(d["c0"]), rho0=float(d["rho0"]), f0=float(d["f0"]), p0=float(d["p0"]), beta=float(d["beta"]), att_dB=float(d["att_dB"]))
+    return d, meshes, serial, kw
+
+
+@pytest.mark.parametrize("name", ["rk4nl_P2_2x2x2_bowl_1rank", "rk4nl_P2_4x2x2_bowl_2ranks"])
+def test_oracle_westervelt_loop_reproduces_reference_driven_loop(name):
+    """tests/golden/rk4nl_*.npz: the reference's own operators and scatter closures driven through the stage sequence of
+    cuda/demo_nonlinear_bowl.py:458-475,533-650 (``generate_golden.py --only rk4nl``); ``rk4_oracle.solve_westervelt`` --
+    what the Westervelt solver tests compare with -- reproduces them on every rank's owned and ghost entries."""
+    d, meshes, serial, kw = _case_nl(name)
+    u, v = rk4_oracle.solve_westervelt(serial, int(d["nsteps"]), float(d["dt"]), **kw)
+    assert np.max(np.abs(u)) > 1e3
+    for r, m in enumerate(meshes):
+        lex = m.global_lexicographic_ids()
+        assert rel_l2(u[lex], d[f"ref_u_tn_{r}"]) < 1e-12 and rel_l2(v[lex], d[f"ref_v_tn_{r}"]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("variant", ["reference-sequence", "fused", "fused-two-gather", "fused-in-kernel-geometry"])
+def test_gpu_westervelt_solver_reproduces_reference_driven_loop(variant):
+    import torch
+
+    torch.cuda.set_device(0)
+    nls = pkg("nonlinear_solver")
+    d, meshes, serial, kw = _case_nl("rk4nl_P2_2x2x2_bowl_1rank")
+    s = nls.WesterveltSpectral3D(serial, np.float64, speed_of_sound=kw["c0"], density=kw["rho0"], source_frequency=kw["f0"],
+                                 source_amplitude=kw["p0"], nonlinear_coefficient=kw["beta"], attenuation_coefficient_dB=kw["att_dB"],
+                                 fused=variant != "reference-sequence", in_kernel_geometry=variant.endswith("geometry"),
+                                 uniform_ratio=False if variant == "fused-two-gather" else "auto")
+    s.init()
+    _, steps = s.rk4(0.0, 1.0, float(d["dt"]), max_steps=int(d["nsteps"]))
+    assert steps == int(d["nsteps"])
+    assert rel_l2(s.u_sol(), d["ref_u_tn_0"]) < 1e-11 and rel_l2(s.v_sol(), d["ref_v_tn_0"]) < 1e-11
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["local", "peer"])
+def test_gpu_partitioned_westervelt_solver_reproduces_reference_driven_loop(transport):
+    import torch
+
+    from test_solver_gpu import _lockstep
+
+    torch.cuda.set_device(0)
+    nls, scat, utils = pkg("nonlinear_solver"), pkg("scatterer"), pkg("utils")
+    d, meshes, serial, kw = _case_nl("rk4nl_P2_4x2x2_bowl_2ranks")
+    R = len(meshes)
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = 7400 + (transport == "peer")
+    comms = [scat.NativeComm(local=(wid, R, r), transport="peer" if transport == "peer" else "rccl") for r in range(R)]
+    solvers = [nls.WesterveltSpectral3D(meshes[r], np.float64, speed_of_sound=kw["c0"], density=kw["rho0"], source_frequency=kw["f0"],
+                                        source_amplitude=kw["p0"], nonlinear_coefficient=kw["beta"], attenuation_coefficient_dB=kw["att_dB"],
+                                        comm=comms[r], fused=True, halo_plan=(od[r], gd[r]), defer_setup_exchange=True) for r in range(R)]
+    _lockstep([s._setup for s in solvers])
+    for s in solvers:
+        s.init()
+    res = _lockstep([s.rk4_schedule(0.0, 1.0, float(d["dt"]), max_steps=int(d["nsteps"])) for s in solvers])
+    torch.cuda.synchronize()
+    assert all(r[1] == int(d["nsteps"]) for r in res)
+    for r, (m, s) in enumerate(zip(meshes, solvers)):
+        assert rel_l2(s.u_sol(), d[f"ref_u_tn_{r}"][: m.nlocal]) < 1e-11
+        assert rel_l2(s.v_sol(), d[f"ref_v_tn_{r}"][: m.nlocal]) < 1e-11
