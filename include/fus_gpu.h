@@ -54,7 +54,7 @@ extern "C" {
 #define FUS_ABI_VERSION 2
 /* Library / device queries. */
 int fus_abi_version(void);
-/* First 16 hex digits of the SHA-256 of the sources (csrc/*.hip, *.hpp, this header, concatenated in sorted path order)
+/* First 16 hex digits of the SHA-256 of the sources (the .hip and .hpp files of csrc/ and this header, concatenated in sorted path order)
  * the library was built from; "unknown" for a build outside csrc/Makefile. */
 const char* fus_source_hash(void);
 const char* fus_error_string(int code);
