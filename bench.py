@@ -632,6 +632,12 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
         tt = torch.tensor([el], dtype=torch.float64, device=coll_device(device))
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         el = float(tt.item())
+    if world > 1 and getattr(solver, "halo", None) is not None:
+        # the solver's exchanges are not re-derived here; a device-side wait that gave up invalidates the run
+        late = torch.tensor([float(solver.halo.health())], dtype=torch.float64, device=coll_device(device))
+        dist.all_reduce(late)
+        if float(late.item()) != 0.0:
+            raise SystemExit(f"rank {rank}: {int(late.item())} device-side halo wait(s) timed out: the run is invalid")
     dev_ms = e0.elapsed_time(e1) / steps  # device time of the region on the launch stream
     geo_kernel = bool(getattr(solver, "in_kernel_geometry", False))
     model = rk4_step_bytes(P, T, mesh.ncells, mesh.ndofs, int(solver.fdm1.shape[0]), int(solver.fdm2.shape[0]), mode,
