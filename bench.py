@@ -134,15 +134,15 @@ def lib_sha():
         return None
 
 
-def kernel_src_sha():
-    """Hash of what defines the HEADLINE kernel's code (its sources and the compile flags): a PMC pass stays valid for
-    a library that differs from the profiled one only elsewhere (halo transport, ABI glue)."""
+def kernel_src_sha(files=("plan.hpp", "stiffness.hpp", "stiffness_plan.hpp")):
+    """Hash of what defines a kernel's code (its sources and the compile flags; default: the HEADLINE kernel): a PMC pass
+    stays valid for a library that differs from the profiled one only elsewhere (halo transport, ABI glue)."""
     import hashlib
 
     csrc = os.path.join(ROOT, "fenicsx-fus-gpu_amd", "csrc")
     h = hashlib.sha256()
     try:
-        for n in ("Makefile", "plan.hpp", "stiffness.hpp", "stiffness_plan.hpp"):
+        for n in ("Makefile",) + tuple(files):
             with open(os.path.join(csrc, n), "rb") as f:
                 data = f.read()
             if n == "Makefile":  # only the compile flags: the header list changes with every new file
@@ -398,9 +398,21 @@ def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, o
     ms = e0.elapsed_time(e1) / K
     bpc = mass_bytes_per_cell(P, T)
     achieved = mesh.ncells * bpc / (ms * 1e-3) / 1e9
+    traffic, traffic_source = None, "no PMC pass of the mass kernel in profiles/traffic_latest.json"
+    try:  # replayed like the headline's: only if the mass kernel's sources and flags are the profiled ones
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            tm = json.load(f).get("aux", {}).get("mass")
+        if tm and int(tm["P"]) == P and int(tm["ncell"]) == mesh.ncells and tm.get("dtype", "f64") == args.dtype:
+            if tm.get("kernel_src_sha") == kernel_src_sha(("plan.hpp", "mass.hpp")) and lib_built_from_tree():
+                traffic = float(tm["hbm_bytes_per_launch"])
+                traffic_source = f"replayed from {tm['source']} (rocprofv3 --pmc; same kernel sources and compile flags)"
+            else:
+                traffic_source = "the mass kernel's sources differ from the profiled ones"
+    except Exception:
+        pass
     out = {"metric": "mass_apply_dof_per_s", "value": mesh.ndofs_global / (wall_ms * 1e-3), "unit": "DOF/s", "ms_per_step": wall_ms, "steps": K,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": None, "kernel": "fus::mass_plan_kernel", "kernel_ms": ms,
+                        "traffic": traffic, "traffic_source": traffic_source, "kernel": "fus::mass_plan_kernel", "kernel_ms": ms,
                         "kernel_ms_how": "one HIP-event pair around K back-to-back launches / K",
                         "algorithmic_bytes_per_cell": bpc, "cells_per_launch": mesh.ncells},
            "cpu_baseline": None}

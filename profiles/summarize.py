@@ -84,11 +84,27 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         res["traffic_over_algorithmic"] = res["hbm_bytes_per_launch"] / res["algorithmic_bytes_per_launch"]
     if stats:
         res["hbm_gbs_from_counters"] = res["hbm_bytes_per_launch"] / stats["avg_ns"]
+    latest_path = os.path.join(out, "traffic_latest.json")
+    try:
+        latest = json.load(open(latest_path))
+    except Exception:
+        latest = {}
     if update_latest:
-        json.dump({"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
-                   "source": f"profiles/{_tag_for_files}_counters.json", "lib_sha": res["lib_sha"],
-                   "kernel_src_sha": bench.get("config", {}).get("kernel_src_sha"), "dtype": bench.get("dtype", "f64")},
-                  open(os.path.join(out, "traffic_latest.json"), "w"), indent=1)
+        latest = {"P": bench["config"]["degree"], "ncell": ncell, "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
+                  "source": f"profiles/{_tag_for_files}_counters.json", "lib_sha": res["lib_sha"],
+                  "kernel_src_sha": bench.get("config", {}).get("kernel_src_sha"), "dtype": bench.get("dtype", "f64"),
+                  "aux": latest.get("aux", {})}
+        json.dump(latest, open(latest_path, "w"), indent=1)
+    if "--aux=mass" in sys.argv[3:]:  # what bench.py replays as aux.mass.roofline.traffic (gated on the mass kernel's sources)
+        sys.path.insert(0, ROOT)
+        import bench as bench_py
+
+        latest.setdefault("aux", {})["mass"] = {
+            "P": bench["config"]["degree"], "ncell": ncell, "dtype": bench.get("dtype", "f64"), "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
+            "source": f"profiles/{_tag_for_files}_counters.json", "lib_sha": res["lib_sha"],
+            "kernel_src_sha": bench_py.kernel_src_sha(("plan.hpp", "mass.hpp")),
+            "atomic_requests_per_launch": counters.get("TCC_EA0_ATOMIC_sum", {}).get("mean_per_launch")}
+        json.dump(latest, open(latest_path, "w"), indent=1)
 if "TCC_EA0_ATOMIC_sum" in counters and stats:
     res["atomic_requests_per_s"] = counters["TCC_EA0_ATOMIC_sum"]["mean_per_launch"] / (stats["avg_ns"] * 1e-9)
 if "SQ_LDS_BANK_CONFLICT" in counters and "SQ_LDS_IDX_ACTIVE" in counters:
