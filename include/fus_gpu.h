@@ -49,7 +49,7 @@ extern "C" {
  *      was not built and registered through this library at that address, fus_comm_destroy refuses while halo
  *      objects of the communicator are alive; new: the PEER halo transport (fus_comm_create_peer, fus_halo_ipc_*).
  * There are deliberately NO fus_cpu_* twins of the entry points (SURVEY.md 8b proposed them): a CPU path inside the
- * product would be a silent fallback; the CPU restatement lives in oracle/ and is test infrastructure only.
+ * product would be a silent fallback; the CPU restatement of the reference is test infrastructure and lives outside the product tree.
  */
 #define FUS_ABI_VERSION 2
 /* Library / device queries. */
