@@ -182,3 +182,18 @@ def test_c_abi_linear_box_plain_cpp_host(tmp_path, geometry, warp):
     assert u_cpp.shape == u_py.shape
     scale = np.max(np.abs(u_py))
     assert scale > 0 and np.max(np.abs(u_cpp - u_py)) < 1e-10 * scale, np.max(np.abs(u_cpp - u_py)) / scale
+
+
+def test_committed_pmc_passes_belong_to_the_kernels_in_this_tree():
+    """bench.py replays HBM traffic from profiles/traffic_latest.json only for a library built from the kernel sources and
+    compile flags that were profiled.  This test fails when a kernel source changed after the last PMC pass: re-profile
+    (profiles/run_profile.sh + summarize.py) instead of shipping a line whose ``roofline.traffic`` would be null."""
+    import json
+
+    sys.path.insert(0, ROOT)
+    import bench
+
+    t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
+    assert t["kernel_src_sha"] == bench.kernel_src_sha(), "stiffness kernel sources changed since profiles/" + t["source"]
+    assert t["aux"]["mass"]["kernel_src_sha"] == bench.kernel_src_sha(("plan.hpp", "mass.hpp")), "mass kernel sources changed"
+    assert os.path.exists(os.path.join(ROOT, t["source"])) and os.path.exists(os.path.join(ROOT, t["aux"]["mass"]["source"]))
