@@ -189,6 +189,7 @@ def test_committed_pmc_passes_belong_to_the_kernels_in_this_tree():
     compile flags that were profiled.  This test fails when a kernel source changed after the last PMC pass: re-profile
     (profiles/run_profile.sh + summarize.py) instead of shipping a line whose ``roofline.traffic`` would be null."""
     import json
+    import sys
 
     sys.path.insert(0, ROOT)
     import bench
