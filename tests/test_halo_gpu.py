@@ -326,6 +326,73 @@ def test_peer_transport_real_processes_partitioned_apply(gpu, P, cells, grid, gh
     _run_peer_world(int(np.prod(grid)), "apply", [P, *cells, *grid, ghost_order, schedule])
 
 
+@pytest.mark.parametrize("transport", TRANSPORTS)
+@pytest.mark.parametrize("seed,permute", [(0, False), (1, True), (2, True)])
+def test_random_plans_uneven_multi_chunk_segments(gpu, seed, permute, transport):
+    """Halo plans that no box partition produces: 4 ranks, every ordered pair with its own message size from
+    {0, 1, 700, 1024, 1025, 2500, 5000} (segments of several 1 024-element chunks next to empty and one-element ones, so the
+    per-segment completion counters, credits and chunk tables of the PEER kernels all see uneven shapes), an owned dof
+    ghosted by several ranks (reverse adds from two neighbours land on one entry), ghosts grouped by owner or permuted.
+    Forward and reverse, three exchanges each, against numpy."""
+    torch = gpu
+    scat = pkg("scatterer")
+    rng = np.random.default_rng(100 + seed)
+    R, nlocal = 4, 20000
+    sizes = [0, 1, 700, 1024, 1025, 2500, 5000]
+    count = {(q, r): (int(rng.choice(sizes)) if q != r else 0) for q in range(R) for r in range(R)}  # q ghosts count dofs of r
+    owned_pick = {(q, r): rng.choice(nlocal, size=count[(q, r)], replace=False).astype(np.int64) for q in range(R) for r in range(R)}
+    od, gd, nghost = [], [], []
+    ghost_pos = {}
+    for q in range(R):  # owners side of q: its ghost block = the owners' segments in ascending owner order
+        owners = [r for r in range(R) if count[(q, r)] > 0]
+        ng = sum(count[(q, r)] for r in owners)
+        pos = rng.permutation(ng).astype(np.int64) if permute else np.arange(ng, dtype=np.int64)
+        off = np.concatenate(([0], np.cumsum([count[(q, r)] for r in owners]))).astype(np.int64)
+        for i, r in enumerate(owners):
+            ghost_pos[(q, r)] = pos[off[i]: off[i + 1]]
+        od.append([pos, np.array([count[(q, r)] for r in owners], dtype=np.int64), off, np.array(owners, dtype=np.int32)])
+        nghost.append(ng)
+    for r in range(R):  # ghosts side of r: its owned dofs in the order each ghosting rank packs them
+        ghosters = [q for q in range(R) if count[(q, r)] > 0]
+        idx = np.concatenate([owned_pick[(q, r)] for q in ghosters]) if ghosters else np.zeros(0, np.int64)
+        off = np.concatenate(([0], np.cumsum([count[(q, r)] for q in ghosters]))).astype(np.int64)
+        gd.append([idx.astype(np.int64), np.array([count[(q, r)] for q in ghosters], dtype=np.int64), off, np.array(ghosters, dtype=np.int32)])
+    wid = next(_world_ids)
+    comms = [_local_comm(scat, wid, R, r, transport) for r in range(R)]
+    fwd = [scat.scatter_forward(comms[r], od[r], gd[r], nlocal, np.float64) for r in range(R)]
+    rev = [scat.scatter_reverse(comms[r], od[r], gd[r], nlocal, np.float64) for r in range(R)]
+    dev = torch.device("cuda", 0)
+    for rep in range(3):
+        host = [rng.standard_normal(nlocal + nghost[r]) for r in range(R)]
+        # forward
+        bufs = [torch.from_numpy(h).to(dev) for h in host]
+        for r in range(R):
+            fwd[r].begin(bufs[r])
+        for r in range(R):
+            fwd[r].end(bufs[r])
+        torch.cuda.synchronize()
+        for q in range(R):
+            ref = host[q].copy()
+            for r in range(R):
+                if count[(q, r)]:
+                    ref[nlocal + ghost_pos[(q, r)]] = host[r][owned_pick[(q, r)]]
+            assert np.array_equal(bufs[q].cpu().numpy(), ref), f"forward, rank {q}, rep {rep}"
+        # reverse
+        bufs = [torch.from_numpy(h).to(dev) for h in host]
+        for r in range(R):
+            rev[r].begin(bufs[r])
+        for r in range(R):
+            rev[r].end(bufs[r])
+        torch.cuda.synchronize()
+        for r in range(R):
+            ref = host[r].copy()
+            for q in range(R):
+                if count[(q, r)]:
+                    np.add.at(ref, owned_pick[(q, r)], host[q][nlocal + ghost_pos[(q, r)]])
+            assert np.allclose(bufs[r].cpu().numpy(), ref, rtol=0, atol=1e-13), f"reverse, rank {r}, rep {rep}"
+    assert all(sc.status()["timeouts"] == 0 for sc in fwd + rev)
+
+
 @pytest.mark.parametrize("fused", [0, 1], ids=["reference-sequence", "fused"])
 def test_peer_transport_real_processes_rk4_solver_vs_reference_driven_loop(gpu, fused):
     """Two real processes, PEER transport, the whole linear RK4 solver (set-up reverse scatter of the lumped mass, per
