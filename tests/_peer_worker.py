@@ -11,6 +11,8 @@ modes
   solver <rk4 fixture.npz> <fused 0|1>
                                    the linear RK4 solver, one PROCESS per rank, == what the reference's own operators and
                                    scatter closures produced in the same loop (tests/golden/rk4_*_2ranks.npz)
+  soak <iterations>                forward + reverse exchanges with data that changes every iteration and random host-side
+                                   skew between the ranks: every ghost value and every owned sum checked exactly each time
   deadpeer                         the owner rank never posts its exchange: the ghosting rank's receive must give up after
                                    FUS_IPC_SPIN_SECONDS and report a time-out instead of hanging
 Prints PEER_WORKER_OK <rank> on success; any failure is a non-zero exit."""
@@ -132,6 +134,41 @@ def main():
         assert rel_l2(full, d[f"ref_u_tn_{rank}"]) < 1e-11
         dist.barrier()
         del s
+    elif mode == "soak":
+        import time
+
+        iters = int(args[0])
+        P, shape, grid = 2, (4, 4, 2), (2, 2, 1)
+        assert world == 4
+        meshes = [boxmesh.BoxMesh(P, shape, grid=grid, rank=r, ghost_order=5) for r in range(world)]
+        od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+        m = meshes[rank]
+        fwd = scat.scatter_forward(comm, od[rank], gd[rank], m.nlocal, np.float64)
+        rev = scat.scatter_reverse(comm, od[rank], gd[rank], m.nlocal, np.float64)
+        lex = torch.from_numpy(m.global_lexicographic_ids().astype(np.float64)).to(dev)
+        # how many ranks ghost each of my owned dofs (reverse: every ghosting rank adds k to the owner's entry)
+        mult = np.zeros(m.ndofs)
+        np.add.at(mult, np.asarray(gd[rank][0], dtype=np.int64), 1.0)
+        mult_d = torch.from_numpy(mult).to(dev)
+        rng = np.random.default_rng(rank)
+        bad = torch.zeros((), dtype=torch.float64, device=dev)
+        for k in range(1, iters + 1):
+            if rng.random() < 0.05:
+                time.sleep(float(rng.random()) * 0.004)  # host-side skew: this rank posts late now and then
+            v = lex * 3.0 + float(k)  # integer-valued: every comparison below is exact
+            v[m.nlocal:] = -1.0
+            fwd(v)
+            bad += (v != lex * 3.0 + float(k)).sum()
+            w = torch.zeros_like(lex)
+            w[m.nlocal:] = float(k)
+            rev(w)
+            bad += (w[: m.nlocal] != mult_d[: m.nlocal] * float(k)).sum()
+        torch.cuda.synchronize()
+        assert float(bad.item()) == 0.0, f"rank {rank}: {int(bad.item())} wrong values in {iters} iterations"
+        assert fwd.status()["timeouts"] == 0 and rev.status()["timeouts"] == 0
+        assert fwd.status()["forward_posted"] == iters and rev.status()["reverse_posted"] == iters
+        dist.barrier()
+        fwd.close(), rev.close()
     elif mode == "deadpeer":
         import time
 

@@ -403,6 +403,13 @@ def test_peer_transport_real_processes_rk4_solver_vs_reference_driven_loop(gpu, 
     _run_peer_world(2, "solver", [os.path.join(os.path.dirname(__file__), "golden", "rk4_P2_4x2x2_pert_2ranks.npz"), fused])
 
 
+def test_peer_transport_real_processes_soak_with_host_skew(gpu):
+    """Four real processes, 1 500 forward + 1 500 reverse exchanges back to back with data that changes every iteration
+    and random host-side delays on every rank (a rank posts up to 4 ms late now and then): sequence flags and credits
+    must keep every message apart -- every ghost value and every owned sum is checked exactly on the device each time."""
+    _run_peer_world(4, "soak", [1500], timeout=600)
+
+
 def test_peer_transport_dead_peer_times_out_instead_of_hanging(gpu):
     """Every device-side wait of the PEER transport is bounded: a rank whose neighbour never sends gets its time-out
     counted (``status()["timeouts"]``) after FUS_IPC_SPIN_SECONDS and its kernels drain; later exchanges of that halo do
