@@ -765,6 +765,10 @@ class HaloApply:
             a, b = self.ranges[name]
             if b > a and self.op is not None and hasattr(self.op, "prepare"):
                 self.op.prepare(self._views(name, (cell_constants, G, dofmap))[2])
+        # the device-side waits of the PEER transport are bounded: line the ranks up on the host before the first
+        # exchange, so that a rank whose set-up took longer is not mistaken for a dead one
+        if hasattr(self.comm, "barrier") and getattr(self.comm, "_world_id", None) is None:
+            self.comm.barrier()
         self.fwd(x)
         self.rev(x.new_zeros(x.shape))
 
