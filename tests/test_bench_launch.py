@@ -101,6 +101,23 @@ def test_distributed_code_path_on_one_gpu(halo):
 
 
 @pytest.mark.gpu
+def test_torchrun_form_rehearsal_on_one_gpu():
+    """The driver's own launch form (python -m torch.distributed.run --nproc-per-node 2 ... bench.py --gpus 2) with real
+    processes and real HIP kernels sharing the one GPU: PEER transport across the processes, halo check passing."""
+    with socket.socket() as s_:
+        s_.bind(("127.0.0.1", 0))
+        port = s_.getsockname()[1]
+    r = subprocess.run([sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "2", "--master-addr", "127.0.0.1",
+                        "--master-port", str(port), BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--cells", "10", "--no-cpu-baseline"],
+                       env=_env(FUS_BENCH_REHEARSAL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    cfg = out["config"]
+    assert out["n_gpus"] == 2 and out["valid"] is False and "PEER" in cfg["halo_transport"] and cfg["halo_check"]["ok"] is True
+    assert cfg["halo_schedule"] == "concurrent" and cfg["halo_check"]["device_wait_timeouts"] == 0
+
+
+@pytest.mark.gpu
 def test_transport_fallback_after_a_failed_halo_check():
     """A transport whose exchanges fail the run's own check is torn down (halo objects, communicator) and the next one
     is brought up and checked: peer rejected -> native (RCCL) used; peer and native rejected -> torch; the line says
