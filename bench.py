@@ -626,6 +626,29 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
                                    perturb=0.16, seed=0)
         solver = ls.LinearSpectral3D(mesh, dt_np, comm=comm, fused=True, in_kernel_geometry=in_kernel_geometry)
     solver.init()
+    halo_check = None
+    if world > 1 and getattr(solver, "halo", None) is not None:
+        # the exchange this solver will use, checked before anything is timed: every ghost must come back from a forward
+        # scatter holding its owner's value (the global lexicographic id, exact in floating point), and the reverse
+        # scatter of "1 in every ghost" must leave on every owned dof the number of ranks that ghost it, whose global sum is
+        # the global number of ghosts
+        tdt = torch.float64 if dt_np == np.float64 else torch.float32
+        lex = torch.from_numpy(mesh.global_lexicographic_ids().astype(dt_np)).to(device) % 8191.0  # exact in fp32 too
+        v = lex.clone()
+        v[mesh.nlocal:] = -1.0
+        solver.halo.fwd(v)
+        bad = float((v != lex).sum().item())
+        w = torch.zeros(mesh.ndofs, dtype=tdt, device=device)
+        w[mesh.nlocal:] = 1.0
+        solver.halo.rev(w)
+        sums = torch.tensor([bad, float(w[: mesh.nlocal].sum().item()), float(mesh.ndofs - mesh.nlocal), float(solver.halo.health())],
+                            dtype=torch.float64, device=coll_device(device))
+        dist.all_reduce(sums)
+        halo_check = {"forward_wrong_ghosts": int(sums[0].item()), "reverse_sum": float(sums[1].item()), "global_ghosts": float(sums[2].item()),
+                      "device_wait_timeouts": int(sums[3].item())}
+        halo_check["ok"] = bool(sums[0].item() == 0 and sums[1].item() == sums[2].item() and sums[3].item() == 0)
+        if not halo_check["ok"]:
+            raise SystemExit(f"rank {rank}: halo check failed: {halo_check}")
     solver.rk4(0.0, tf, dts, max_steps=max(1, warmup))
     if world > 1:
         dist.barrier()
@@ -667,6 +690,7 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
                    "steps_to_final_time": nstep, "dt": dts,
                    "geometry": "affine box: constant-G fast path (opt-in, checked at set-up)" if solver.affine
                    else ("G and detJ formed in the cell kernel from the vertices (opt-in)" if geo_kernel else "general per-quadrature-point G"),
+                   "halo_check": halo_check, "halo_schedule": getattr(getattr(solver, "halo", None), "schedule_kind", None),
                    "lib_sha": lib_sha(), "lib_built_from_tree": lib_built_from_tree()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": None, "traffic_source": "no PMC pass replayed for the whole step",
