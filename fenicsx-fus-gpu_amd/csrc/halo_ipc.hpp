@@ -20,8 +20,8 @@
 //
 // Flags carry sequence numbers (exchange 1, 2, ...), so nothing depends on the order in which the processes' hosts
 // issue their calls, and the hosts never synchronise with each other after the one-off exchange of the arena handles.
-// The arenas are fine-grained device memory (what RCCL's own peer-to-peer buffers are), so a reader never sees a stale
-// cache line.  Sends and receives run on two streams of the communicator: a send never waits for remote data, so
+// The arenas are uncached device memory (what RCCL's own peer-to-peer flag buffers are on this architecture), so a reader
+// never sees a stale cache line.  Sends and receives run on two streams of the communicator: a send never waits for remote data, so
 // exchanges posted in different orders on different ranks cannot dead-lock.
 //
 // Every wait is bounded (FUS_IPC_SPIN_SECONDS, default 20 s of the device's wall clock): on a time-out the kernel records
@@ -309,10 +309,17 @@ inline hipError_t ipc_role_upload(IpcRole& r) {
 }
 
 inline hipError_t ipc_arena_alloc(IpcState& st, int64_t bytes) {
-  const char* force = std::getenv("FUS_IPC_MEMORY");  // "finegrained" (default) | "uncached" | "coarse": experiments only
-  const int first = force ? (!std::strcmp(force, "uncached") ? 1 : !std::strcmp(force, "coarse") ? 2 : 0) : 0;
+  // Arena memory: UNCACHED device memory first (what RCCL gives its own peer-to-peer flag / LL buffers on gfx942 / gfx950;
+  // every access of the exchange kernels bypasses the caches anyway, and nothing else may ever find a stale line of it),
+  // then fine-grained, then ordinary memory.  FUS_IPC_MEMORY = uncached | finegrained | coarse picks the first choice
+  // (all three export / open through HIP IPC and pass the two-process probe: profiles/r03a_ipc_probe.log).
+  const char* force = std::getenv("FUS_IPC_MEMORY");
+  const int first = force ? (!std::strcmp(force, "finegrained") ? 0 : !std::strcmp(force, "coarse") ? 2 : 1) : 1;
+  const int order[3] = {first, first == 1 ? 0 : 1, first == 2 ? 0 : 2};
   hipError_t e = hipErrorOutOfMemory;
-  for (int kind = first; kind < 3; ++kind) {
+  for (int i = 0; i < 3; ++i) {
+    const int kind = order[i];
+    if (i > 0 && kind == order[0]) continue;
     void* p = nullptr;
     e = kind == 0   ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocFinegrained)
         : kind == 1 ? hipExtMallocWithFlags(&p, bytes, hipDeviceMallocUncached)

@@ -107,7 +107,7 @@ class NativeComm:
     box), transport = stream-ordered device copies; every rank's ``begin`` of an exchange must be
     called before any rank's ``end``.
 
-    ``transport="peer"`` (csrc/halo_ipc.hpp): no RCCL.  Each scatter closure owns a receive arena in fine-grained
+    ``transport="peer"`` (csrc/halo_ipc.hpp): no RCCL.  Each scatter closure owns a receive arena in uncached
     device memory whose HIP IPC handle goes once to its neighbours (all-gathered through ``torch.distributed``, any
     backend); an exchange is a send kernel that stores straight into the neighbours' arenas and a receive kernel that
     waits for a sequence flag -- small kernels that run NEXT TO a chip-filling operator launch, which RCCL's

@@ -356,7 +356,7 @@ int fus_unpack_rev_f32(const float* in, float* out, const int64_t* index, int64_
  * fus_comm_create_local: all ranks live in one process (tests on a one-GPU box; one process driving
  * several GPUs); ranks that pass the same world_id form a world.  Host-side contract of this transport:
  * every rank's *_begin of an exchange is called before any rank's *_end of it.
- * fus_comm_create_peer: no RCCL.  Every halo object of such a communicator owns a receive arena in fine-grained
+ * fus_comm_create_peer: no RCCL.  Every halo object of such a communicator owns a receive arena in uncached (fallback: fine-grained)
  * device memory; the ranks exchange the arenas' HIP IPC handles once (fus_halo_ipc_export -> any all-gather the host
  * has -> fus_halo_ipc_connect) and an exchange is then two small kernels per rank: a send kernel that stores straight
  * into the neighbours' arenas (xGMI stores) and publishes a sequence flag, a receive kernel that waits for the flag
