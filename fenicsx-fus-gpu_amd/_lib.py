@@ -50,7 +50,11 @@ def _signatures():
         "fus_comm_stream": [_vp],
         "fus_comm_last_error": [_vp],
         "fus_comm_fork": [_vp, _vp],
+        "fus_comm_fork_lazy": [_vp, _vp],
         "fus_comm_join": [_vp, _vp],
+        "fus_comm_arm_join": [_vp],
+        "fus_comm_health": [_vp, _vp],
+        "fus_comm_health_detail": [_vp, _vp],
         "fus_comm_sync_timeouts": [_vp, _vp],
         "fus_comm_destroy": [_vp],
         "fus_halo_create": [_vp, _int, _i64, _i64, _int, _vp, _vp, _vp, _int, _vp, _vp, _vp, C.POINTER(_vp)],
@@ -103,7 +107,7 @@ TUNE_MASS_VARIANT = 3
 TUNE_PLAN_VARIANT = 4
 TUNE_PLAN_RUNS = 5
 
-ABI_VERSION = 2  # include/fus_gpu.h FUS_ABI_VERSION
+ABI_VERSION = 3  # include/fus_gpu.h FUS_ABI_VERSION
 
 _lib = None
 
@@ -169,6 +173,10 @@ def check(rc: int, what: str = "", comm=None):
         if rc == ERR_COMM:
             detail = load().fus_comm_last_error(comm)
             msg += ": " + (detail.decode() if detail else "?")
+        elif comm is not None and rc == -1:  # a misuse the communicator explains (fork / join stream contract)
+            detail = load().fus_comm_last_error(comm)
+            if detail:
+                msg += ": " + detail.decode()
         raise FusGpuError(f"{what or 'libfusgpu call'} failed: {msg} (code {rc})")
 
 

@@ -751,13 +751,27 @@ int fus_comm_rank(fus_comm_t comm) { return comm ? comm->c.rank : FUS_ERR_INVALI
 int fus_comm_size(fus_comm_t comm) { return comm ? comm->c.nranks : FUS_ERR_INVALID_ARGUMENT; }
 void* fus_comm_stream(fus_comm_t comm) { return comm ? comm->c.stream : nullptr; }
 
-int fus_comm_fork(fus_comm_t comm, void* stream) {
+static int comm_fork_join_rc(fus_comm_t comm, void* stream, int which, bool lazy) {
   if (!comm) return FUS_ERR_INVALID_ARGUMENT;
-  return hip_rc(fus::comm_fork_join(&comm->c, static_cast<hipStream_t>(stream), 0));
+  bool misuse = false;
+  const hipError_t e = fus::comm_fork_join(&comm->c, static_cast<hipStream_t>(stream), which, lazy, &misuse);
+  return misuse ? FUS_ERR_INVALID_ARGUMENT : hip_rc(e);
 }
-int fus_comm_join(fus_comm_t comm, void* stream) {
+int fus_comm_fork(fus_comm_t comm, void* stream) { return comm_fork_join_rc(comm, stream, 0, false); }
+int fus_comm_fork_lazy(fus_comm_t comm, void* stream) { return comm_fork_join_rc(comm, stream, 0, true); }
+int fus_comm_join(fus_comm_t comm, void* stream) { return comm_fork_join_rc(comm, stream, 1, false); }
+int fus_comm_arm_join(fus_comm_t comm) {
   if (!comm) return FUS_ERR_INVALID_ARGUMENT;
-  return hip_rc(fus::comm_fork_join(&comm->c, static_cast<hipStream_t>(stream), 1));
+  return hip_rc(fus::comm_arm_join(&comm->c));
+}
+int fus_comm_health(fus_comm_t comm, int64_t* failures) {
+  if (!comm || !failures) return FUS_ERR_INVALID_ARGUMENT;
+  return fus::comm_health(&comm->c, failures) == 0 ? FUS_OK : FUS_ERR_COMM;
+}
+int fus_comm_health_detail(fus_comm_t comm, int64_t* out3) {
+  if (!comm || !out3) return FUS_ERR_INVALID_ARGUMENT;
+  int64_t total = 0;
+  return fus::comm_health(&comm->c, &total, out3) == 0 ? FUS_OK : FUS_ERR_COMM;
 }
 int fus_comm_sync_timeouts(fus_comm_t comm, int64_t* out) {
   if (!comm || !out) return FUS_ERR_INVALID_ARGUMENT;
@@ -825,6 +839,7 @@ int fus_halo_create(fus_comm_t comm, int elem_bytes, int64_t nlocal, int64_t ngh
   h.nghost = nghost;
   h.direct = direct;
   ++comm->c.nhalos;
+  comm->c.halos.push_back(&h);
   const bool peer = comm->c.kind == fus::Comm::PEER;
   hipError_t e = fus::side_init(h.owners, n_owner_ranks, owner_ranks, owner_sizes, owners_idx, comm->c.stream);
   if (e == hipSuccess) e = fus::side_init(h.ghosts, n_ghost_ranks, ghost_ranks, ghost_sizes, ghosts_idx, comm->c.stream);
@@ -858,7 +873,15 @@ int fus_halo_destroy(fus_halo_t halo) {
     auto& mine = h.comm->world->halos[h.comm->rank];
     if (h.index < (int)mine.size() && mine[h.index] == &h) mine[h.index] = nullptr;
   }
-  if (h.comm) --h.comm->nhalos;
+  if (h.comm) {
+    --h.comm->nhalos;
+    auto& hv = h.comm->halos;
+    hv.erase(std::remove(hv.begin(), hv.end(), &h), hv.end());
+    if (h.comm->join_halo == &h) {
+      h.comm->join_halo = nullptr;
+      h.comm->join_armed = false;
+    }
+  }
   fus::halo_ipc_free(&h);
   fus::side_free(h.owners);
   fus::side_free(h.ghosts);
@@ -884,9 +907,9 @@ int fus_halo_ipc_connect(fus_halo_t halo, int nblobs, const void* const* blobs) 
   if (!halo || nblobs < 0 || (nblobs > 0 && !blobs) || halo->h.comm->kind != fus::Comm::PEER) return FUS_ERR_INVALID_ARGUMENT;
   return fus::halo_ipc_connect(&halo->h, nblobs, blobs) == 0 ? FUS_OK : FUS_ERR_COMM;
 }
-int fus_halo_ipc_status(fus_halo_t halo, int64_t* out4) {
-  if (!halo || !out4 || halo->h.comm->kind != fus::Comm::PEER) return FUS_ERR_INVALID_ARGUMENT;
-  return fus::halo_ipc_status(&halo->h, out4) == 0 ? FUS_OK : FUS_ERR_COMM;
+int fus_halo_ipc_status(fus_halo_t halo, int64_t* out8) {
+  if (!halo || !out8 || halo->h.comm->kind != fus::Comm::PEER) return FUS_ERR_INVALID_ARGUMENT;
+  return fus::halo_ipc_status(&halo->h, out8) == 0 ? FUS_OK : FUS_ERR_COMM;
 }
 
 #define FUS_HALO_OP(NAME, FN, DIR)                                                  \

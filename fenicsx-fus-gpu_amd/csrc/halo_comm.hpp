@@ -37,6 +37,7 @@
 #include <stdint.h>
 
 #include <cstring>
+#include <strings.h>
 #include <map>
 #include <memory>
 #include <mutex>
@@ -125,10 +126,22 @@ struct Comm {
   hipStream_t stream = nullptr;   // high priority: small exchange kernels between big operator kernels
   hipStream_t stream2 = nullptr;  // PEER: the receive kernels' stream (sends never queue behind a waiting receive)
   int nhalos = 0;                 // live halo objects: the communicator outlives them
+  std::vector<Halo*> halos;       // the live halo objects (comm_health)
   // event-free fork / join between a caller's stream and ``stream`` (comm_fork / comm_join below)
   uint64_t* sync_words = nullptr;  // device: [0] fork flag, [1] join flag, [2..] status (ST_TIMEOUTS, ST_DEAD)
   uint64_t sync_seq[2] = {0, 0};
   uint64_t sync_budget = 0;
+  // One sequence flag per direction: consecutive forks / joins of a communicator must come from ONE caller stream (two
+  // streams forking alternately would let the later stream's signal satisfy the earlier wait).  Enforced: a fork from
+  // another stream is accepted only when the communicator's stream has drained.
+  hipStream_t caller_stream = nullptr;
+  bool caller_stream_set = false;
+  // PEER: fork / join folded into the exchange kernels (fus_comm_fork_lazy / fus_comm_arm_join)
+  uint64_t gate_pending = 0;      // fork sequence number no kernel of the communicator's stream waits for yet
+  bool join_armed = false;        // the last receive kernel of the next begin / begin_group publishes the join flag
+  Halo* join_halo = nullptr;      // ... that is this halo's, in direction join_dir
+  int join_dir = 0;
+  uint64_t join_inflight = 0;     // join sequence number a posted receive kernel will publish
   std::string last_error;
 };
 
@@ -208,18 +221,76 @@ inline hipError_t comm_sync_init(Comm* c) {
   return e;
 }
 
+// the wait of a lazily posted fork that no send kernel took over: a wait kernel on the communicator's stream after all
+inline hipError_t comm_flush_gate(Comm* c) {
+  if (!c->gate_pending) return hipSuccess;
+  const uint64_t seq = c->gate_pending;
+  c->gate_pending = 0;
+  hipLaunchKernelGGL(stream_wait_kernel, dim3(1), dim3(64), 0, c->stream, c->sync_words + 0, seq, c->sync_words + 2, c->sync_budget);
+  return hipGetLastError();
+}
+
 // which: 0 fork (``stream`` -> communicator's stream), 1 join (communicator's stream -> ``stream``)
-inline hipError_t comm_fork_join(Comm* c, hipStream_t stream, int which) {
+// lazy (fork, PEER): only the signal kernel is launched; the first send kernel of the next exchange posted on the
+// communicator's stream waits for the flag itself (halo_ipc_post) -- one kernel less in the exchange chain.
+// *misuse: the single-caller-stream contract was violated (nothing was launched; last_error says what).
+inline hipError_t comm_fork_join(Comm* c, hipStream_t stream, int which, bool lazy, bool* misuse) {
+  *misuse = false;
   if (stream == c->stream) return hipSuccess;
   hipError_t e = comm_sync_init(c);
   if (e != hipSuccess) return e;
+  if (c->caller_stream_set && stream != c->caller_stream) {
+    // another caller stream: fine once everything forked so far has run (no wait kernel is pending on either side)
+    if (which == 1 || hipStreamQuery(c->stream) != hipSuccess) {
+      (void)hipGetLastError();
+      c->last_error = which == 1 ? "fus_comm_join: called with a different stream than the fus_comm_fork before it"
+                                 : "fus_comm_fork: consecutive forks of a communicator must come from one caller stream (the communicator's stream "
+                                   "still has work forked from another stream; synchronise it before changing the caller stream)";
+      *misuse = true;
+      return hipSuccess;
+    }
+  }
+  if (which == 0) {
+    c->caller_stream = stream;
+    c->caller_stream_set = true;
+  }
+  e = comm_flush_gate(c);
+  if (e != hipSuccess) return e;
+  if (which == 1 && c->join_inflight) {  // a receive kernel already on the communicator's stream publishes the flag
+    const uint64_t seq = c->join_inflight;
+    c->join_inflight = 0;
+    hipLaunchKernelGGL(stream_wait_kernel, dim3(1), dim3(64), 0, stream, c->sync_words + 1, seq, c->sync_words + 2, c->sync_budget);
+    return hipGetLastError();
+  }
+  if (which == 1) {
+    c->join_armed = false;  // armed, but no receive kernel took it (no neighbours on that side)
+    c->join_halo = nullptr;
+  }
   const uint64_t seq = ++c->sync_seq[which];
   hipStream_t from = which == 0 ? stream : c->stream, to = which == 0 ? c->stream : stream;
   hipLaunchKernelGGL(stream_signal_kernel, dim3(1), dim3(1), 0, from, c->sync_words + which, seq);
   e = hipGetLastError();
   if (e != hipSuccess) return e;
+  if (which == 0 && lazy && c->kind == Comm::PEER && c->stream2 == c->stream) {
+    c->gate_pending = seq;
+    return hipSuccess;
+  }
   hipLaunchKernelGGL(stream_wait_kernel, dim3(1), dim3(64), 0, to, c->sync_words + which, seq, c->sync_words + 2, c->sync_budget);
   return hipGetLastError();
+}
+
+// PEER: the last receive kernel of the NEXT fus_halo_*_begin / *_begin_group of this communicator also publishes the join
+// flag, so that the fus_comm_join that follows launches only the wait kernel on the caller's stream.  That exchange must be
+// the last thing enqueued on the communicator's stream before the join.  Without a receive kernel to carry it (no
+// neighbours on that side, receive kernels on a stream of their own) the join falls back to its signal kernel.
+inline hipError_t comm_arm_join(Comm* c) {
+  hipError_t e = comm_sync_init(c);
+  if (e != hipSuccess) return e;
+  if (c->kind == Comm::PEER && c->stream2 == c->stream) {
+    c->join_armed = true;
+    c->join_halo = nullptr;
+  }
+  return hipSuccess;
 }
 
 // ------------------------------------------------------------------------------------ halo plan
@@ -350,9 +421,48 @@ inline hipError_t halo_wait_readers_local(Halo* h, const Side& sside) {
 }
 
 // ------------------------------------------------------------------------------------ PEER transport, host side
+// A process that drives several ranks maps a neighbour's arena once, however many of its ranks border that neighbour
+// (opening one HIP IPC handle twice in a process is not portable): process-wide table, reference counted.
+struct IpcOpened {
+  hipIpcMemHandle_t handle;
+  void* ptr;
+  int refs;
+};
+inline std::vector<IpcOpened>& ipc_opened_table() {  // guarded by local_worlds_mutex()
+  static std::vector<IpcOpened> t;
+  return t;
+}
+inline hipError_t ipc_open_shared(const hipIpcMemHandle_t& handle, void** out) {
+  std::lock_guard<std::mutex> lock(local_worlds_mutex());
+  for (IpcOpened& o : ipc_opened_table())
+    if (!std::memcmp(&o.handle, &handle, sizeof handle)) {
+      ++o.refs;
+      *out = o.ptr;
+      return hipSuccess;
+    }
+  void* p = nullptr;
+  const hipError_t e = hipIpcOpenMemHandle(&p, handle, hipIpcMemLazyEnablePeerAccess);
+  if (e != hipSuccess) return e;
+  ipc_opened_table().push_back(IpcOpened{handle, p, 1});
+  *out = p;
+  return hipSuccess;
+}
+inline void ipc_close_shared(void* p) {
+  std::lock_guard<std::mutex> lock(local_worlds_mutex());
+  auto& t = ipc_opened_table();
+  for (size_t i = 0; i < t.size(); ++i)
+    if (t[i].ptr == p) {
+      if (--t[i].refs == 0) {
+        (void)hipIpcCloseMemHandle(p);
+        t.erase(t.begin() + (long)i);
+      }
+      return;
+    }
+}
+
 inline void halo_ipc_free(Halo* h) {
   IpcState& st = h->ipc;
-  for (void* p : st.opened) (void)hipIpcCloseMemHandle(p);
+  for (void* p : st.opened) ipc_close_shared(p);
   st.opened.clear();
   ipc_role_free(st.send_fwd);
   ipc_role_free(st.recv_fwd);
@@ -361,6 +471,8 @@ inline void halo_ipc_free(Halo* h) {
   if (st.arena) (void)hipFree(st.arena);
   if (st.status) (void)hipFree(st.status);
   if (st.ev_sent) (void)hipEventDestroy(st.ev_sent);
+  if (st.join_counter) (void)hipFree(st.join_counter);
+  st.join_counter = nullptr;
   st.arena = nullptr;
   st.status = nullptr;
   st.ev_sent = nullptr;
@@ -383,6 +495,8 @@ inline hipError_t halo_ipc_create(Halo* h) {
   if (e == hipSuccess) e = ipc_role_init(st.recv_fwd, h->owners.counts, h->owners.offsets);
   if (e == hipSuccess) e = ipc_role_init(st.send_rev, h->owners.counts, h->owners.offsets);
   if (e == hipSuccess) e = hipEventCreateWithFlags(&st.ev_sent, hipEventDisableTiming);
+  if (e == hipSuccess) e = hipMalloc(&st.join_counter, sizeof(unsigned));
+  if (e == hipSuccess) e = hipMemset(st.join_counter, 0, sizeof(unsigned));
   int khz = 100000;
   (void)hipDeviceGetAttribute(&khz, hipDeviceAttributeWallClockRate, h->comm->device);
   double seconds = 20.0;
@@ -402,10 +516,16 @@ inline int halo_ipc_export(Halo* h, void* blob) {
   IpcBlobHeader hd;
   std::memset(&hd, 0, sizeof hd);
   hd.magic = kIpcMagic;
-  hd.version = 1;
+  hd.version = kIpcBlobVersion;
   hd.rank = c->rank;
   hd.elem_bytes = h->eb;
   hd.pid = (int64_t)getpid();
+  hd.token = ipc_process_token();
+  if (hipDeviceGetPCIBusId(hd.pci_bus_id, (int)sizeof hd.pci_bus_id, c->device) != hipSuccess) {
+    (void)hipGetLastError();
+    hd.pci_bus_id[0] = 0;
+  }
+  hd.pci_bus_id[sizeof hd.pci_bus_id - 1] = 0;
   hd.base = (uint64_t)(uintptr_t)st.arena;
   hd.arena_bytes = st.arena_bytes;
   hd.off_flags = st.off_flags;
@@ -451,7 +571,7 @@ inline int halo_ipc_connect(Halo* h, int nblobs, const void* const* blobs) {
   for (int b = 0; b < nblobs; ++b) {
     if (!blobs[b]) continue;
     const auto* hd = static_cast<const IpcBlobHeader*>(blobs[b]);
-    if (hd->magic != kIpcMagic || hd->version != 1 || hd->elem_bytes != h->eb || hd->rank < 0 || hd->rank >= c->nranks) {
+    if (hd->magic != kIpcMagic || hd->version != kIpcBlobVersion || hd->elem_bytes != h->eb || hd->rank < 0 || hd->rank >= c->nranks) {
       c->last_error = "halo connect: malformed or mismatching blob";
       return -1;
     }
@@ -469,21 +589,28 @@ inline int halo_ipc_connect(Halo* h, int nblobs, const void* const* blobs) {
     }
     PeerView& v = it->second;
     if (!v.arena) {
-      if (v.hd->pid == (int64_t)getpid()) {
+      const IpcProcessToken& me = ipc_process_token();
+      if (v.hd->token.w[0] == me.w[0] && v.hd->token.w[1] == me.w[1]) {
         v.arena = reinterpret_cast<char*>((uintptr_t)v.hd->base);  // same address space (in-process ranks, self-neighbour)
         if (rank != c->rank) st.defer_recv = true;
       } else {
-        // another process (normally another GPU): refuse up front what would otherwise fault inside a kernel
-        int ndev = 0, can = 1;
-        if (hipGetDeviceCount(&ndev) == hipSuccess && v.hd->device >= 0 && v.hd->device < ndev && v.hd->device != c->device &&
-            hipDeviceCanAccessPeer(&can, c->device, v.hd->device) == hipSuccess && !can) {
-          c->last_error = "device " + std::to_string(c->device) + " has no peer access to device " + std::to_string(v.hd->device) +
+        // another process (normally another GPU): refuse up front what would otherwise fault inside a kernel.  The
+        // exporter's device is identified by its PCI bus id -- ordinals are process-local -- and looked up among the
+        // devices visible HERE; one that is not visible here cannot be checked and is left to hipIpcOpenMemHandle.
+        int ndev = 0, can = 1, peer_dev = -1;
+        if (v.hd->pci_bus_id[0] && hipGetDeviceCount(&ndev) == hipSuccess)
+          for (int d = 0; d < ndev && peer_dev < 0; ++d) {
+            char id[32] = {0};
+            if (hipDeviceGetPCIBusId(id, (int)sizeof id, d) == hipSuccess && !strcasecmp(id, v.hd->pci_bus_id)) peer_dev = d;
+          }
+        if (peer_dev >= 0 && peer_dev != c->device && hipDeviceCanAccessPeer(&can, c->device, peer_dev) == hipSuccess && !can) {
+          c->last_error = "device " + std::to_string(c->device) + " has no peer access to device " + std::string(v.hd->pci_bus_id) +
                           " (rank " + std::to_string(rank) + ")";
           return false;
         }
         (void)hipGetLastError();
         void* p = nullptr;
-        const hipError_t e = hipIpcOpenMemHandle(&p, v.hd->handle, hipIpcMemLazyEnablePeerAccess);
+        const hipError_t e = ipc_open_shared(v.hd->handle, &p);
         if (e != hipSuccess) {
           c->last_error = "hipIpcOpenMemHandle (rank " + std::to_string(rank) + "): " + hipGetErrorString(e);
           return false;
@@ -550,59 +677,90 @@ inline int halo_ipc_connect(Halo* h, int nblobs, const void* const* blobs) {
   return 0;
 }
 
+// ``on_stream``: the caller enqueues on the communicator's own stream (HaloApply's concurrent schedule): stream order is
+// all the ordering there is, and no event is recorded (an event record is a marker with a cache write-back between the
+// exchange kernels).
 template <typename T>
-inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq) {
+inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq, bool on_stream) {
   Comm* c = h->comm;
   IpcState& st = h->ipc;
   T* vec = reinterpret_cast<T*>(vecp);
   const IpcRole& rr = dir == 0 ? st.recv_fwd : st.recv_rev;
+  IpcJoin join{nullptr, 0, st.join_counter};
+  if (c->join_armed && c->join_halo == h && c->join_dir == dir) {
+    c->join_armed = false;
+    c->join_halo = nullptr;
+    if (rr.nchunks > 0 && c->stream2 == c->stream) {  // this kernel is the last of the chain: it publishes the join flag
+      join.flag = c->sync_words + 1;
+      join.seq = ++c->sync_seq[1];
+      c->join_inflight = join.seq;
+    }
+  }
   if (rr.nchunks > 0) {
     if (dir == 1)
       hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_ADD, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->ghosts.idx_d,
-                         (int64_t)0, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
+                         (int64_t)0, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
     else if (h->direct)
       hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, false>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->owners.idx_d,
-                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
+                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
     else
       hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->owners.idx_d,
-                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget);
+                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  return hipEventRecord(h->ev_done, c->stream2);
+  st.done_recorded = !on_stream;
+  return on_stream ? hipSuccess : hipEventRecord(h->ev_done, c->stream2);
 }
 
 template <typename T>
-inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir) {
+inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir, bool on_stream) {
   Comm* c = h->comm;
   IpcState& st = h->ipc;
   T* vec = reinterpret_cast<T*>(vecp);
   const uint64_t seq = ++st.seq[dir];
   const IpcRole& sr = dir == 0 ? st.send_fwd : st.send_rev;
+  // a lazily posted fork: the first send kernel on the communicator's stream waits for the fork flag itself; where there
+  // is none to carry the wait (no neighbours on this side), a wait kernel does
+  IpcGate gate{nullptr, 0, nullptr};
+  if (c->gate_pending) {
+    if (sr.nchunks > 0) {
+      gate = IpcGate{c->sync_words + 0, c->gate_pending, c->sync_words + 2};
+      c->gate_pending = 0;
+    } else {
+      const hipError_t e = comm_flush_gate(c);
+      if (e != hipSuccess) return e;
+    }
+  }
   if (sr.nchunks > 0) {
     if (dir == 0)  // owned entries listed in ghosts.idx -> the ghosting ranks
       hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->ghosts.idx_d, (int64_t)0,
-                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
     else if (h->direct)  // ghost block, already grouped by owner -> the owners
       hipLaunchKernelGGL((ipc_send_kernel<T, false>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
-                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
     else
       hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
-                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget);
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
-  hipError_t e = hipEventRecord(st.ev_sent, c->stream);
-  if (e != hipSuccess) return e;
+  st.sent_recorded = !on_stream;
+  if (!on_stream) {
+    hipError_t e = hipEventRecord(st.ev_sent, c->stream);
+    if (e != hipSuccess) return e;
+  }
   if (st.defer_recv) {  // ranks of ONE process: the receive kernel is posted by *_end (see IpcState::defer_recv)
     st.pending[dir] = seq;
     return hipSuccess;
   }
-  return halo_ipc_post_recv<T>(h, vecp, dir, seq);
+  return halo_ipc_post_recv<T>(h, vecp, dir, seq, on_stream);
 }
 
-// time-outs seen by this halo's kernels (0 = healthy); synchronises the communicator's streams
-inline int halo_ipc_status(Halo* h, int64_t* out4) {
+// failures seen by this halo's kernels (0 = healthy); synchronises the communicator's streams
+//   out8 = {failed waits (time-outs + poisoned flags read), forward exchanges posted, reverse exchanges posted, arena
+//           memory kind, time-outs, poisoned flags read (a neighbour's halo had failed), dead (0 / 1), 0}
+inline int halo_ipc_status(Halo* h, int64_t* out8) {
   Comm* c = h->comm;
   uint64_t w[ST_WORDS] = {0};
   hipError_t e = hipStreamSynchronize(c->stream);
@@ -612,10 +770,45 @@ inline int halo_ipc_status(Halo* h, int64_t* out4) {
     c->last_error = hipGetErrorString(e);
     return -1;
   }
-  out4[0] = (int64_t)w[ST_TIMEOUTS];
-  out4[1] = (int64_t)h->ipc.seq[0];
-  out4[2] = (int64_t)h->ipc.seq[1];
-  out4[3] = h->ipc.memory_kind;
+  out8[0] = (int64_t)(w[ST_TIMEOUTS] + w[ST_POISONED]);
+  out8[1] = (int64_t)h->ipc.seq[0];
+  out8[2] = (int64_t)h->ipc.seq[1];
+  out8[3] = h->ipc.memory_kind;
+  out8[4] = (int64_t)w[ST_TIMEOUTS];
+  out8[5] = (int64_t)w[ST_POISONED];
+  out8[6] = (int64_t)w[ST_DEAD];
+  out8[7] = 0;
+  return 0;
+}
+
+// Failed device-side waits of EVERY halo object of the communicator plus of its fork / join kernels (0 = healthy): what a
+// time loop checks before it trusts its result.  Synchronises the communicator's streams (one small copy per halo).
+inline int comm_health(Comm* c, int64_t* failures, int64_t* detail3 = nullptr) {
+  *failures = 0;
+  int64_t d[3] = {0, 0, 0};  // time-outs of halo waits, poisoned flags read, time-outs of fork / join waits
+  hipError_t e = hipStreamSynchronize(c->stream);
+  if (e == hipSuccess && c->stream2 && c->stream2 != c->stream) e = hipStreamSynchronize(c->stream2);
+  if (e == hipSuccess && c->sync_words) {
+    uint64_t w = 0;
+    e = hipMemcpy(&w, c->sync_words + 2 + ST_TIMEOUTS, sizeof w, hipMemcpyDeviceToHost);
+    *failures += (int64_t)w;
+    d[2] = (int64_t)w;
+  }
+  if (e == hipSuccess && c->kind == Comm::PEER)
+    for (Halo* h : c->halos) {
+      uint64_t w[ST_WORDS] = {0};
+      if (!h->ipc.status) continue;
+      e = hipMemcpy(w, h->ipc.status, sizeof w, hipMemcpyDeviceToHost);
+      if (e != hipSuccess) break;
+      *failures += (int64_t)(w[ST_TIMEOUTS] + w[ST_POISONED]);
+      d[0] += (int64_t)w[ST_TIMEOUTS];
+      d[1] += (int64_t)w[ST_POISONED];
+    }
+  if (e != hipSuccess) {
+    c->last_error = hipGetErrorString(e);
+    return -1;
+  }
+  if (detail3) std::memcpy(detail3, d, sizeof d);
   return 0;
 }
 
@@ -659,15 +852,21 @@ inline int halo_begin_group(Halo* const* hs, void* const* buffers, int nh, hipSt
       }
   if (c->kind == Comm::PEER) {
     // the caller may BE on the communicator's stream (HaloApply's concurrent schedule): then stream order is all there is
-    if (stream != c->stream || stream != c->stream2) {
+    const bool on_stream = stream == c->stream && stream == c->stream2;
+    if (!on_stream) {
+      FUS_H(comm_flush_gate(c));
       FUS_H(hipEventRecord(hs[0]->ev_ready, stream));
       if (stream != c->stream) FUS_H(hipStreamWaitEvent(c->stream, hs[0]->ev_ready, 0));
       if (stream != c->stream2 && c->stream2 != c->stream) FUS_H(hipStreamWaitEvent(c->stream2, hs[0]->ev_ready, 0));
     }
+    if (c->join_armed && !c->join_halo) {  // fus_comm_arm_join: the last receive kernel of THIS call carries the join
+      c->join_halo = hs[nh - 1];
+      c->join_dir = dir;
+    }
     for (int k = 0; k < nh; ++k) {
       Halo* h = hs[k];
-      FUS_H(h->eb == 8 ? halo_ipc_post<double>(h, static_cast<char*>(buffers[k]), dir)
-                       : halo_ipc_post<float>(h, static_cast<char*>(buffers[k]), dir));
+      FUS_H(h->eb == 8 ? halo_ipc_post<double>(h, static_cast<char*>(buffers[k]), dir, on_stream)
+                       : halo_ipc_post<float>(h, static_cast<char*>(buffers[k]), dir, on_stream));
     }
     return 0;
   }
@@ -750,13 +949,19 @@ inline int halo_end(Halo* h, void* buffer, hipStream_t stream, int dir) {
     FUS_H(hipEventRecord(h->ev_done, c->stream));
   }
   if (c->kind == Comm::PEER) {
+    const bool on_stream = stream == c->stream && stream == c->stream2;
     if (h->ipc.defer_recv && h->ipc.pending[dir]) {
       const uint64_t seq = h->ipc.pending[dir];
       h->ipc.pending[dir] = 0;
-      FUS_H(h->eb == 8 ? halo_ipc_post_recv<double>(h, vec, dir, seq) : halo_ipc_post_recv<float>(h, vec, dir, seq));
+      FUS_H(h->eb == 8 ? halo_ipc_post_recv<double>(h, vec, dir, seq, on_stream) : halo_ipc_post_recv<float>(h, vec, dir, seq, on_stream));
     }
+    if (on_stream) return 0;  // the caller is on the exchange kernels' stream: already ordered
+    // begin was called on the communicator's stream, end from elsewhere: the events were not recorded then -- now is as good
+    if (!h->ipc.sent_recorded) FUS_H(hipEventRecord(h->ipc.ev_sent, c->stream));
+    if (!h->ipc.done_recorded) FUS_H(hipEventRecord(h->ev_done, c->stream2));
+    h->ipc.sent_recorded = h->ipc.done_recorded = true;
     if (stream != c->stream) FUS_H(hipStreamWaitEvent(stream, h->ipc.ev_sent, 0));  // the send kernel has read the vector
-    if (stream == c->stream2) return 0;  // the caller is on the receive kernel's stream: already ordered
+    if (stream == c->stream2) return 0;
   }
   FUS_H(hipStreamWaitEvent(stream, h->ev_done, 0));
 #undef FUS_H

@@ -21,11 +21,21 @@
 // Flags carry sequence numbers (exchange 1, 2, ...), so nothing depends on the order in which the processes' hosts
 // issue their calls, and the hosts never synchronise with each other after the one-off exchange of the arena handles.
 // The arenas are uncached device memory (what RCCL's own peer-to-peer flag buffers are on this architecture), so a reader
-// never sees a stale cache line.  Sends and receives run on two streams of the communicator: a send never waits for remote data, so
-// exchanges posted in different orders on different ranks cannot dead-lock.
+// never sees a stale cache line.
 //
-// Every wait is bounded (FUS_IPC_SPIN_SECONDS, default 20 s of the device's wall clock): on a time-out the kernel records
-// it in the halo's status words, stops waiting for the rest of the run and drains; fus_halo_ipc_status() reports it.
+// Host-side contract (the one MPI's non-blocking collectives and RCCL have too): ALL RANKS POST THE EXCHANGES OF A
+// COMMUNICATOR IN THE SAME ORDER.  Send and receive kernels share the communicator's one stream by default, so rank A
+// posting (halo 1, halo 2) while rank B posts (halo 2, halo 1) is a cycle: A's receive 1 waits for B's send 1, which is
+// queued behind B's receive 2, which waits for A's send 2, queued behind A's receive 1.  (FUS_IPC_TWO_STREAMS=1 puts the
+// receive kernels on a stream of their own -- a send never waits for remote data -- at the price of an event edge per
+// exchange; the drivers of this repository post in program order on every rank and do not need it.)
+//
+// Every wait is bounded (FUS_IPC_SPIN_SECONDS, default 20 s of the device's wall clock) and A FAILED EXCHANGE IS LOUD ON
+// BOTH SIDES: on a time-out the kernel records it in the halo's status words, stops waiting for the rest of the run,
+// drains -- and every flag this halo publishes from then on carries the POISON bit (bit 63).  A neighbour that reads a
+// poisoned flag does not consume the arena (stale data), counts it (ST_POISONED), becomes dead itself and poisons what it
+// publishes: the failure reaches every rank connected to the one that timed out within a few exchanges, and
+// fus_halo_ipc_status() != 0 there.  The solvers / demos / C++ host check it at the end of every rk4() call and raise.
 #pragma once
 
 #include <hip/hip_runtime.h>
@@ -33,6 +43,8 @@
 #include <unistd.h>
 
 #include <algorithm>
+#include <chrono>
+#include <cstdio>
 #include <cstdlib>
 #include <cstring>
 #include <string>
@@ -65,10 +77,11 @@ inline int ipc_chunk() {
 }
 constexpr int kIpcFlagStride = 64;  // bytes between two flags: one flag per 64-byte line
 constexpr uint32_t kIpcMagic = 0x46555349u;  // "FUSI"
+constexpr uint64_t kIpcPoison = 1ull << 63;  // in a flag: the publisher's halo has failed (time-out here or upstream)
 
 // flag kinds inside an arena; slot = index of the neighbour in the owners-side (kinds 0, 1) or ghosts-side (2, 3) list
 enum IpcFlag { ARRIVED_FWD = 0, CREDIT_REV = 1, ARRIVED_REV = 2, CREDIT_FWD = 3 };
-enum IpcStatus { ST_TIMEOUTS = 0, ST_DEAD = 1, ST_WORDS = 8 };
+enum IpcStatus { ST_TIMEOUTS = 0, ST_DEAD = 1, ST_POISONED = 2, ST_WORDS = 8 };
 
 struct IpcChunk {
   int32_t nbr;    // neighbour slot on the side the kernel walks
@@ -98,30 +111,78 @@ __device__ inline uint64_t ipc_load_flag(const uint64_t* f) {
 __device__ inline void ipc_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
 // Wait until *flag >= want.  Bounded: gives up after ``budget`` wall-clock ticks, or at once if an earlier wait of this
-// halo has already timed out.
+// halo has already failed.  A poisoned flag (the publisher's halo is dead) ends the wait at once, is counted and kills this
+// halo too.  Returns 1 only if the data behind the flag may be consumed.
 __device__ inline int ipc_wait(const uint64_t* flag, uint64_t want, uint64_t* status, uint64_t budget) {
-  if (ipc_load_flag(flag) >= want) return 1;
-  if (__hip_atomic_load(&status[ST_DEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
+  uint64_t v = ipc_load_flag(flag);
+  if (!(v & kIpcPoison) && v >= want) return 1;
   const uint64_t t0 = wall_clock64();
   for (;;) {
-    if (ipc_load_flag(flag) >= want) return 1;
+    if (v & kIpcPoison) {
+      atomicAdd((unsigned long long*)&status[ST_POISONED], 1ull);
+      __hip_atomic_store(&status[ST_DEAD], (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return 0;
+    }
+    if (v >= want) return 1;
+    if (__hip_atomic_load(&status[ST_DEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return 0;
     __builtin_amdgcn_s_sleep(4);
     if (wall_clock64() - t0 > budget) {
       atomicAdd((unsigned long long*)&status[ST_TIMEOUTS], 1ull);
       __hip_atomic_store(&status[ST_DEAD], (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       return 0;
     }
+    v = ipc_load_flag(flag);
   }
 }
 
-// last workgroup of a neighbour's segment publishes ``seq`` in ``flag_out``
-__device__ inline void ipc_segment_done(unsigned* counter, int nchunks, uint64_t* flag_out, uint64_t seq) {
+// Wait (bounded) for a flag of THIS device (agent scope): the fork flag of the communicator, folded into the first send
+// kernel of an apply instead of a wait kernel of its own (halo_comm.hpp comm_fork_join).
+__device__ inline void ipc_wait_gate(const uint64_t* gate, uint64_t want, uint64_t* gate_status, uint64_t budget) {
+  if (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) >= want) return;
+  if (__hip_atomic_load(&gate_status[ST_DEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)) return;
+  const uint64_t t0 = wall_clock64();
+  while (__hip_atomic_load(gate, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) < want) {
+    __builtin_amdgcn_s_sleep(2);
+    if (wall_clock64() - t0 > budget) {
+      atomicAdd((unsigned long long*)&gate_status[ST_TIMEOUTS], 1ull);
+      __hip_atomic_store(&gate_status[ST_DEAD], (uint64_t)1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      return;
+    }
+  }
+}
+
+// last workgroup of a neighbour's segment publishes ``seq`` in ``flag_out`` -- poisoned if this halo has failed
+__device__ inline void ipc_segment_done(unsigned* counter, int nchunks, uint64_t* flag_out, uint64_t seq, const uint64_t* status) {
   const unsigned done = __hip_atomic_fetch_add(counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
   if (done == (unsigned)nchunks - 1u) {  // every other workgroup's stores were acknowledged before it counted itself
     __hip_atomic_store(counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    __hip_atomic_store(flag_out, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
+    const uint64_t dead = __hip_atomic_load(&status[ST_DEAD], __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(flag_out, dead ? (seq | kIpcPoison) : seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_SYSTEM);
   }
 }
+
+// A kernel's last workgroup publishes ``seq`` in a flag of THIS device: the join flag of the communicator, folded into the
+// last receive kernel of an apply instead of a signal kernel of its own.  Every workgroup has waited for its own stores /
+// atomics (s_waitcnt vmcnt(0)) before it counts itself.
+struct IpcJoin {
+  uint64_t* flag;     // nullptr: nothing to publish
+  uint64_t seq;
+  unsigned* counter;  // zero between launches
+};
+__device__ inline void ipc_kernel_done(const IpcJoin& j) {
+  if (!j.flag) return;
+  const unsigned done = __hip_atomic_fetch_add(j.counter, 1u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (done == gridDim.x - 1u) {
+    __hip_atomic_store(j.counter, 0u, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    __hip_atomic_store(j.flag, j.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  }
+}
+
+struct IpcGate {
+  const uint64_t* flag;  // nullptr: no gate
+  uint64_t seq;
+  uint64_t* status;      // the communicator's fork / join status words
+};
 
 template <typename T>
 __device__ inline T ipc_load_elem(const T* p);
@@ -151,11 +212,14 @@ template <typename T, bool GATHER>
 __global__ void __launch_bounds__(kIpcMaxThreads)
     ipc_send_kernel(const T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
                     const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
-                    uint64_t* status, uint64_t seq, uint64_t budget) {
+                    uint64_t* status, uint64_t seq, uint64_t budget, IpcGate gate) {
   const IpcChunk c = chunks[blockIdx.x];
   const IpcPeer p = peers[c.nbr];
   __shared__ int ok;
-  if (threadIdx.x == 0) ok = ipc_wait(p.flag_in, seq - 1, status, budget);  // the neighbour has consumed message seq-1
+  if (threadIdx.x == 0) {
+    if (gate.flag) ipc_wait_gate(gate.flag, gate.seq, gate.status, budget);  // the caller's stream has produced the vector
+    ok = ipc_wait(p.flag_in, seq - 1, status, budget);                       // the neighbour has consumed message seq-1
+  }
   __syncthreads();
   if (ok) {
     T* dst = reinterpret_cast<T*>(p.data) + (c.start - p.seg_off);
@@ -176,7 +240,7 @@ __global__ void __launch_bounds__(kIpcMaxThreads)
   }
   ipc_stores_done();  // my stores have reached the neighbour's memory before the flag can
   __syncthreads();
-  if (threadIdx.x == 0) ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq);
+  if (threadIdx.x == 0) ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq, status);
 }
 
 // MODE: UNPACK_SET (forward: ghosts overwritten) or UNPACK_ADD (reverse: partial sums added into the owners' entries)
@@ -184,7 +248,7 @@ template <typename T, int MODE, bool GATHER>
 __global__ void __launch_bounds__(kIpcMaxThreads)
     ipc_recv_kernel(T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
                     const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
-                    uint64_t* status, uint64_t seq, uint64_t budget) {
+                    uint64_t* status, uint64_t seq, uint64_t budget, IpcJoin join) {
   const IpcChunk c = chunks[blockIdx.x];
   const IpcPeer p = peers[c.nbr];
   __shared__ int ok;
@@ -214,8 +278,12 @@ __global__ void __launch_bounds__(kIpcMaxThreads)
       }
     }
   }
-  __syncthreads();  // every load of this chunk has been consumed
-  if (threadIdx.x == 0) ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq);
+  if (join.flag) ipc_stores_done();  // my stores / adds into the vector have been performed before the join flag can say so
+  __syncthreads();                   // every load of this chunk has been consumed
+  if (threadIdx.x == 0) {
+    ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq, status);
+    ipc_kernel_done(join);
+  }
 }
 
 // ------------------------------------------------------------------------------------------- host side
@@ -232,12 +300,38 @@ struct IpcRole {  // device tables of one kernel role (send or recv) over one si
   std::vector<IpcPeer> host_peers;
 };
 
+constexpr int32_t kIpcBlobVersion = 2;
+
+// Identity of THIS process, drawn once: a pid alone does not identify an address space (ranks in different PID namespaces
+// -- one container per rank -- can share a pid, and the importer would then dereference a foreign virtual address).
+struct IpcProcessToken {
+  uint64_t w[2];
+};
+inline const IpcProcessToken& ipc_process_token() {
+  static const IpcProcessToken tok = [] {
+    IpcProcessToken t{{0, 0}};
+    if (FILE* f = std::fopen("/dev/urandom", "rb")) {
+      if (std::fread(&t, sizeof t, 1, f) != 1) t = IpcProcessToken{{0, 0}};
+      std::fclose(f);
+    }
+    if (!t.w[0] && !t.w[1]) {  // no /dev/urandom: pid + a high-resolution clock + an address of this image
+      t.w[0] = ((uint64_t)getpid() << 32) ^ (uint64_t)(uintptr_t)&ipc_process_token;
+      t.w[1] = (uint64_t)std::chrono::steady_clock::now().time_since_epoch().count();
+    }
+    t.w[0] |= 1;  // never all-zero
+    return t;
+  }();
+  return tok;
+}
+
 struct IpcBlobHeader {
   uint32_t magic;
   int32_t version;
   int32_t rank;
   int32_t elem_bytes;
-  int64_t pid;
+  int64_t pid;    // informational (error messages); the address space is identified by ``token``
+  IpcProcessToken token;
+  char pci_bus_id[32];  // of the exporter's device: ordinals are process-local (HIP_VISIBLE_DEVICES per rank)
   uint64_t base;  // arena address in the exporting process (used directly when importer == exporter process)
   hipIpcMemHandle_t handle;
   int64_t arena_bytes;
@@ -264,6 +358,8 @@ struct IpcState {
   uint64_t pending[2] = {0, 0};
   uint64_t budget = 0;
   hipEvent_t ev_sent = nullptr;
+  bool sent_recorded = false, done_recorded = false;  // the events of the exchange in flight were recorded (caller not on the communicator's stream)
+  unsigned* join_counter = nullptr;  // workgroups of a receive kernel that have finished (ipc_kernel_done)
   int memory_kind = 0;  // 0 fine-grained, 1 uncached, 2 ordinary
 };
 

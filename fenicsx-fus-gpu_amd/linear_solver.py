@@ -260,11 +260,20 @@ class LinearSpectral3D(StepGraphMixin):
             try:
                 next(gen)
             except StopIteration as done:
+                # N > 1: every device-side wait of the exchange is bounded, so a late or dead neighbour cannot hang this
+                # rank -- it must not hand back a field computed from stale ghosts either (the reference would block in
+                # MPI Waitall, cuda/scatterer.py:175): raise.  One synchronisation per rk4() call.
+                self.check_halo_health("LinearSpectral3D.rk4")
                 return done.value
+
+    def check_halo_health(self, what="halo exchange"):
+        if self.halo is not None:
+            self.halo.check_health(what)
 
     def rk4_schedule(self, start_time, final_time, dt, max_steps=None):
         """``rk4`` as a generator that yields whenever this rank has posted halo exchanges (see
-        ``HaloApply.schedule``); its return value is ``(t, steps)``."""
+        ``HaloApply.schedule``); its return value is ``(t, steps)``.  A driver that advances several ranks' generators
+        itself calls ``check_halo_health()`` when they are exhausted (``rk4`` does)."""
         t, step = float(start_time), 0
         tf = float(final_time)
         if self.fused:
@@ -330,6 +339,7 @@ class LinearSpectral3D(StepGraphMixin):
         if self.halo is not None:
             self.halo.fwd(self.u)
             torch.cuda.synchronize()
+            self.check_halo_health("LinearSpectral3D.u_sol(with_ghosts=True)")
         return self.u.detach().cpu().numpy()
 
     def v_sol(self):

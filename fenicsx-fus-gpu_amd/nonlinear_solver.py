@@ -289,7 +289,12 @@ class WesterveltSpectral3D(StepGraphMixin):
             try:
                 next(gen)
             except StopIteration as done:
+                self.check_halo_health("WesterveltSpectral3D.rk4")  # a failed exchange is an error, not a field (see LinearSpectral3D.rk4)
                 return done.value
+
+    def check_halo_health(self, what="halo exchange"):
+        if self.halo is not None:
+            self.halo.check_health(what)
 
     def rk4_schedule(self, start_time, final_time, dt, max_steps=None):
         """``rk4`` as a generator that yields whenever this rank has posted halo exchanges; returns ``(t, steps)``."""

@@ -112,11 +112,17 @@ class NativeComm:
     backend); an exchange is a send kernel that stores straight into the neighbours' arenas and a receive kernel that
     waits for a sequence flag -- small kernels that run NEXT TO a chip-filling operator launch, which RCCL's
     264-register kernel does not.  With ``local=...`` the ranks of one process use the same protocol (their arenas
-    are plain pointers to each other); the closures connect at their first exchange, when every rank has been built."""
+    are plain pointers to each other); the closures connect at their first exchange, when every rank has been built.
+    ``hosted=[ranks]`` with ``local=...`` and ``transport="peer"``: THIS process drives only those ranks of the world and
+    the other ranks live in other processes of the ``torch.distributed`` group (one process driving several GPUs, or --
+    tests -- the 8-rank 2x2x2 partition on 4 processes where the pool allows no more): the processes all-gather the
+    arena handles of their ranks once per closure; neighbours of the same process are reached through plain pointers,
+    the others through HIP IPC mappings, by the same kernels.  Every process must build its closures in the same order."""
 
     _peer_local = {}  # (world_id, halo index) -> {rank: blob}: in-process PEER worlds
+    _peer_gathered = {}  # (world_id, halo index) -> {rank: blob} of ALL processes (hybrid worlds: gathered once per process)
 
-    def __init__(self, group=None, local=None, transport="rccl"):
+    def __init__(self, group=None, local=None, transport="rccl", hosted=None):
         import ctypes as C
 
         if transport not in ("rccl", "peer"):
@@ -129,9 +135,20 @@ class NativeComm:
         self._stream = None
         self._world_id = None
         self._nhalos = 0
+        self._hosted = None
         if local is not None:
             world_id, self.size, self.rank = (int(v) for v in local)
             self._world_id = world_id
+            if hosted is not None:
+                if transport != "peer":
+                    raise ValueError("hosted= needs transport='peer'")
+                self._hosted = sorted(int(r) for r in hosted)
+                if self.rank not in self._hosted:
+                    raise ValueError(f"rank {self.rank} is not among the hosted ranks {self._hosted}")
+                if len(self._hosted) < self.size:
+                    if not (dist.is_available() and dist.is_initialized()):
+                        raise _lib.FusGpuError("NativeComm(hosted=...): the other ranks' arena handles travel over torch.distributed")
+                    self._torch = TorchComm(group)
             if transport == "peer":
                 self.backend = "peer-local"
                 _lib.check(lib.fus_comm_create_peer(self.size, self.rank, C.byref(self.handle)), "fus_comm_create_peer")
@@ -194,6 +211,7 @@ class NativeComm:
                 NativeComm._peer_local[key].pop(self.rank, None)
                 if not NativeComm._peer_local[key]:
                     del NativeComm._peer_local[key]
+                    NativeComm._peer_gathered.pop(key, None)
 
     def __del__(self):
         try:
@@ -208,13 +226,38 @@ class NativeComm:
             self._stream = torch.cuda.ExternalStream(int(ptr)) if ptr else None
         return self._stream
 
-    def fork(self):
-        """Order the communicator's stream after the caller's current stream, without an event (``fus_comm_fork``)."""
-        _lib.check(self._lib.fus_comm_fork(self.handle, _lib.stream_ptr()), "fus_comm_fork", self.handle)
+    def fork(self, lazy=False):
+        """Order the communicator's stream after the caller's current stream, without an event (``fus_comm_fork``).
+        ``lazy`` (PEER transport): no wait kernel -- the first send kernel of the exchange the caller posts NEXT on the
+        communicator's stream waits for the fork flag itself (``fus_comm_fork_lazy``)."""
+        fn = self._lib.fus_comm_fork_lazy if lazy else self._lib.fus_comm_fork
+        _lib.check(fn(self.handle, _lib.stream_ptr()), "fus_comm_fork", self.handle)
+
+    def arm_join(self):
+        """PEER transport: the last receive kernel of the exchange posted next publishes the join flag, so that ``join()``
+        launches only its wait kernel (``fus_comm_arm_join``).  A no-op for the other transports."""
+        _lib.check(self._lib.fus_comm_arm_join(self.handle), "fus_comm_arm_join", self.handle)
 
     def join(self):
         """Order the caller's current stream after the communicator's stream, without an event (``fus_comm_join``)."""
         _lib.check(self._lib.fus_comm_join(self.handle, _lib.stream_ptr()), "fus_comm_join", self.handle)
+
+    def health(self):
+        """Failed device-side waits (time-outs + poisoned flags) of every live halo object of this communicator and of its
+        fork / join kernels: 0 = every exchange so far delivered (``fus_comm_health``; synchronises the exchange streams)."""
+        import ctypes as C
+
+        n = C.c_int64(0)
+        _lib.check(self._lib.fus_comm_health(self.handle, C.byref(n)), "fus_comm_health", self.handle)
+        return int(n.value)
+
+    def health_detail(self):
+        """``{"timeouts", "poisoned", "sync_timeouts"}``: what ``health()`` adds up."""
+        import ctypes as C
+
+        out = (C.c_int64 * 3)()
+        _lib.check(self._lib.fus_comm_health_detail(self.handle, out), "fus_comm_health_detail", self.handle)
+        return {"timeouts": int(out[0]), "poisoned": int(out[1]), "sync_timeouts": int(out[2])}
 
     def sync_timeouts(self):
         import ctypes as C
@@ -241,11 +284,35 @@ class NativeComm:
             if self.rank in reg and reg[self.rank] != mine:  # a new world re-uses the id: drop the old world's handles
                 reg.clear()
             reg[self.rank] = mine
-            if len(reg) < self.size:
+            hosted = self._hosted if self._hosted is not None else list(range(self.size))
+            if any(r not in reg for r in hosted):
                 if lazy_ok:
                     return False
-                raise _lib.FusGpuError(f"PEER halo {index}: only ranks {sorted(reg)} of {self.size} have built their closure")
-            blobs = [reg[r] for r in range(self.size)]
+                raise _lib.FusGpuError(f"PEER halo {index}: only ranks {sorted(reg)} of {hosted} have built their closure")
+            if len(hosted) < self.size:
+                # hybrid world: the rank of this process that completes the set all-gathers the processes' blobs (a
+                # collective: every process builds its closures in the same order); the others find them cached
+                key = (self._world_id, index)
+                got = NativeComm._peer_gathered.get(key)
+                if got is None or any(got.get(r) != reg[r] for r in hosted):
+                    import struct
+
+                    payload = b"".join(struct.pack("<q", len(reg[r])) + reg[r] for r in hosted)
+                    got = {}
+                    for chunk in self._torch.allgather_bytes(payload):
+                        off = 0
+                        while off < len(chunk):
+                            (n_,) = struct.unpack_from("<q", chunk, off)
+                            b = chunk[off + 8: off + 8 + n_]
+                            got[struct.unpack_from("<Iiii", b)[2]] = b  # IpcBlobHeader: magic, version, rank, ...
+                            off += 8 + n_
+                    NativeComm._peer_gathered[key] = got
+                missing = [r for r in range(self.size) if r not in got]
+                if missing:
+                    raise _lib.FusGpuError(f"PEER halo {index}: no process hosts rank(s) {missing}")
+                blobs = [got[r] for r in range(self.size)]
+            else:
+                blobs = [reg[r] for r in range(self.size)]
         elif self._torch is not None:
             blobs = self._torch.allgather_bytes(mine)
         else:
@@ -297,11 +364,18 @@ class _NativeScatter:
 
             keep = [arr(o_ranks, np.int32), arr(o_size, np.int64), arr(o_idx, np.int64),
                     arr(g_ranks, np.int32), arr(g_size, np.int64), arr(g_idx, np.int64)]
-            _lib.check(
-                lib.fus_halo_create(comm.handle, 8 if self.dtype == torch.float64 else 4, self.N, int(len(o_idx)),
-                                    len(o_ranks), keep[0][1], keep[1][1], keep[2][1],
-                                    len(g_ranks), keep[3][1], keep[4][1], keep[5][1], C.byref(self.handle)),
-                "fus_halo_create", comm.handle)
+            rc = lib.fus_halo_create(comm.handle, 8 if self.dtype == torch.float64 else 4, self.N, int(len(o_idx)),
+                                     len(o_ranks), keep[0][1], keep[1][1], keep[2][1],
+                                     len(g_ranks), keep[3][1], keep[4][1], keep[5][1], C.byref(self.handle))
+            # PEER, one process per rank: building a closure continues with a collective (the all-gather of the arena
+            # handles).  A rank whose object could not be created (out of memory, a bad plan) must not leave the others
+            # inside that all-gather: agree on the outcome first, so that the failure is raised on every rank here.
+            if getattr(comm, "transport", "rccl") == "peer" and comm._world_id is None and comm._torch is not None and comm.size > 1:
+                if not comm._torch.all_ok(rc == 0) and rc == 0:
+                    lib.fus_halo_destroy(self.handle)
+                    self.handle = None
+                    raise _lib.FusGpuError("fus_halo_create failed on another rank: no halo object is built on any rank")
+            _lib.check(rc, "fus_halo_create", comm.handle)
             self._index = comm._nhalos
             comm._nhalos += 1
         self.nghost = None
@@ -325,10 +399,11 @@ class _NativeScatter:
         import ctypes as C
 
         if getattr(self.comm, "transport", "rccl") != "peer":
-            return {"timeouts": 0}
-        out = (C.c_int64 * 4)()
+            return {"failures": 0, "timeouts": 0, "poisoned": 0, "dead": False}
+        out = (C.c_int64 * 8)()
         _lib.check(self._lib.fus_halo_ipc_status(self.handle, out), "fus_halo_ipc_status", self.comm.handle)
-        return {"timeouts": int(out[0]), "forward_posted": int(out[1]), "reverse_posted": int(out[2]),
+        return {"failures": int(out[0]), "timeouts": int(out[4]), "poisoned": int(out[5]), "dead": bool(out[6]),
+                "forward_posted": int(out[1]), "reverse_posted": int(out[2]),
                 "arena_memory": ("fine-grained", "uncached", "ordinary")[int(out[3])]}
 
     def begin(self, buffer):
@@ -576,6 +651,7 @@ class HaloApply:
         # stream on a real partition (profiles/r01f_host_overhead.log); to be re-measured on 8 GPUs.
         self.side_stream = os.environ.get("FUS_HALO_SIDE_STREAM", "0") == "1"
         self._lib_sync = os.environ.get("FUS_HALO_EVENT_SYNC", "0") != "1"  # 1: fork / join the side stream with events
+        self._fold_sync = os.environ.get("FUS_HALO_FOLD_SYNC", "1") != "0"  # 0: fork / join as kernels of their own (A/B runs)
         self._hs = None
 
     def neighbour_ranks(self):
@@ -659,8 +735,10 @@ class HaloApply:
             if self._events is None:
                 self._events = (torch.cuda.Event(), torch.cuda.Event())
             ev_start, ev_side = self._events
+            # PEER: fork and join are folded into the first send / last receive kernel of the chain (two kernels fewer)
+            fold = lib_sync and getattr(self.comm, "transport", None) == "peer" and self._fold_sync
             if lib_sync:
-                self.comm.fork()
+                self.comm.fork(lazy=fold and len(forward) > 0)
             else:
                 ev_start.record(main)
                 side.wait_event(ev_start)
@@ -674,6 +752,8 @@ class HaloApply:
                 part("boundary")
                 if boundary_terms is not None:
                     boundary_terms()
+                if fold and len(reverse) > 0:
+                    self.comm.arm_join()
                 rv = begin_all(reverse)
             yield "reverse"
             with torch.cuda.stream(side):
@@ -795,11 +875,20 @@ class HaloApply:
         return ("lead1", "interior1", "boundary", "lead2", "interior2")
 
     def health(self):
-        """PEER transport: device-side time-outs of both closures (0 = healthy); synchronises the exchange streams."""
-        n = 0
-        for sc in (self.fwd, self.rev):
-            if hasattr(sc, "status"):
-                n += int(sc.status().get("timeouts", 0))
+        """Failed device-side waits (time-outs, poisoned flags of failed neighbours) of EVERY closure of this communicator
+        and of its fork / join kernels (0 = every exchange so far delivered); synchronises the exchange streams."""
         if isinstance(self.comm, NativeComm) and self.comm.handle:
-            n += self.comm.sync_timeouts()
-        return n
+            return self.comm.health()
+        return 0
+
+    def check_health(self, what="halo exchange"):
+        """Raise if any exchange of this communicator failed on this rank (a device-side wait gave up, or a neighbour's
+        failure reached this rank through a poisoned flag).  The reference would block in MPI Waitall
+        (cuda/scatterer.py:175); here every wait is bounded, so a failure must be made loud instead."""
+        n = self.health()
+        if n:
+            d = self.comm.health_detail() if hasattr(self.comm, "health_detail") else {}
+            raise _lib.FusGpuError(
+                f"{what}: {n} device-side wait(s) of the halo exchange failed on rank {self.comm.rank} ({d.get('timeouts', '?')} time-out(s) after "
+                f"FUS_IPC_SPIN_SECONDS, {d.get('poisoned', '?')} flag(s) poisoned by a neighbour's failed exchange, {d.get('sync_timeouts', '?')} "
+                "fork / join time-out(s)): ghost data is stale, the result is INVALID")

@@ -48,10 +48,14 @@ extern "C" {
  *      fus_rk4_stage_* is a 4-valued stage kind, planned applies return FUS_ERR_PLAN_MISMATCH for a workspace that
  *      was not built and registered through this library at that address, fus_comm_destroy refuses while halo
  *      objects of the communicator are alive; new: the PEER halo transport (fus_comm_create_peer, fus_halo_ipc_*).
+ *   3  fus_halo_ipc_status fills EIGHT words (time-outs and poisoned flags separately); a failed PEER exchange poisons the
+ *      flags it publishes, so its neighbours fail too instead of consuming stale data; fus_comm_fork / fus_comm_join
+ *      enforce their one-caller-stream contract (FUS_ERR_INVALID_ARGUMENT); new: fus_comm_fork_lazy, fus_comm_arm_join,
+ *      fus_comm_health; the PEER blob identifies the exporting process by a random token and its device by PCI bus id.
  * There are deliberately NO fus_cpu_* twins of the entry points (SURVEY.md 8b proposed them): a CPU path inside the
  * product would be a silent fallback; the CPU restatement of the reference is test infrastructure and lives outside the product tree.
  */
-#define FUS_ABI_VERSION 2
+#define FUS_ABI_VERSION 3
 /* Library / device queries. */
 int fus_abi_version(void);
 /* First 16 hex digits of the SHA-256 of the sources (the .hip and .hpp files of csrc/ and this header, concatenated in sorted path order)
@@ -361,8 +365,17 @@ int fus_unpack_rev_f32(const float* in, float* out, const int64_t* index, int64_
  * has -> fus_halo_ipc_connect) and an exchange is then two small kernels per rank: a send kernel that stores straight
  * into the neighbours' arenas (xGMI stores) and publishes a sequence flag, a receive kernel that waits for the flag
  * and stores / adds into the vector (csrc/halo_ipc.hpp).  Unlike RCCL's send/recv kernel they fit next to a
- * chip-filling operator launch, so the exchange really runs under interior-cell work.  No host-side contract between
- * ranks; every device-side wait is bounded (FUS_IPC_SPIN_SECONDS, default 20) and reported by fus_halo_ipc_status.
+ * chip-filling operator launch, so the exchange really runs under interior-cell work.
+ * Host-side contract of this transport (the one MPI's non-blocking collectives and RCCL have): ALL RANKS POST THE
+ * EXCHANGES OF A COMMUNICATOR IN THE SAME ORDER -- send and receive kernels share the communicator's one stream, so two
+ * ranks posting (halo 1, halo 2) and (halo 2, halo 1) wait for each other (FUS_IPC_TWO_STREAMS=1 lifts this: receive
+ * kernels on a stream of their own).  Nothing else: no per-exchange hand-shake between the hosts.
+ * Every device-side wait is bounded (FUS_IPC_SPIN_SECONDS, default 20 s).  A wait that gives up is counted, the halo
+ * object stops waiting (is "dead") and every flag it publishes from then on is POISONED: a neighbour that reads one does
+ * not consume the (stale) arena, counts it and dies too -- a failed exchange spreads to every rank connected to it within a
+ * few exchanges instead of producing a wrong field.  fus_halo_ipc_status / fus_comm_health report it; a time loop MUST
+ * check fus_comm_health() == 0 before it trusts its result (the reference would block in MPI Waitall,
+ * cuda/scatterer.py:175).
  * fus_comm_destroy fails (FUS_ERR_COMM) while halo objects of the communicator are alive.
  */
 #define FUS_UNIQUE_ID_BYTES 128
@@ -384,10 +397,30 @@ void* fus_comm_stream(fus_comm_t comm); /* the hipStream_t the exchanges run on 
  *                  communicator's stream: 2.4 us on ``stream`` where an event record costs 7 next to chip-filling launches);
  *   fus_comm_join: the reverse direction.
  * fus_comm_sync_timeouts: waits of these kernels that gave up (FUS_IPC_SPIN_SECONDS); synchronises the communicator's stream.
+ * There is ONE sequence flag per direction and communicator, so consecutive forks (and their joins) of a communicator must
+ * come from ONE caller stream, as a time loop's do: a fork from another stream is accepted only once the communicator's
+ * stream has drained, a join from another stream than its fork never (FUS_ERR_INVALID_ARGUMENT, nothing launched).
+ *
+ * PEER transport, two kernels fewer per apply in the exchange chain:
+ *   fus_comm_fork_lazy: as fus_comm_fork, but no wait kernel -- the FIRST send kernel of the next fus_halo_*_begin[_group]
+ *                  posted on the communicator's stream waits for the fork flag itself.  The caller must post that
+ *                  exchange next, before anything else on the communicator's stream (where no send kernel can carry the
+ *                  wait -- no neighbours on that side, another transport -- a wait kernel is launched after all).
+ *   fus_comm_arm_join:  the LAST receive kernel of the next fus_halo_*_begin[_group] of this communicator publishes the
+ *                  join flag; the fus_comm_join after it then launches only the wait kernel on the caller's stream.  That
+ *                  exchange must be the last work on the communicator's stream before the join (falls back to the signal
+ *                  kernel where no receive kernel can carry it).
+ * fus_comm_health: failed device-side waits (time-outs + poisoned flags) of every live halo object of the communicator
+ *                  and of its fork / join kernels; 0 = every exchange so far delivered.  Synchronises the communicator's streams.
  */
 int fus_comm_fork(fus_comm_t comm, void* stream);
+int fus_comm_fork_lazy(fus_comm_t comm, void* stream);
 int fus_comm_join(fus_comm_t comm, void* stream);
+int fus_comm_arm_join(fus_comm_t comm);
 int fus_comm_sync_timeouts(fus_comm_t comm, int64_t* out);
+int fus_comm_health(fus_comm_t comm, int64_t* failures);
+/* the same, split: out3 = {time-outs of exchange waits, poisoned flags read (a neighbour had failed), time-outs of fork / join waits} */
+int fus_comm_health_detail(fus_comm_t comm, int64_t* out3);
 const char* fus_comm_last_error(fus_comm_t comm /* NULL: errors raised before a communicator existed */);
 int fus_comm_destroy(fus_comm_t comm);
 
@@ -414,13 +447,14 @@ int fus_halo_destroy(fus_halo_t halo); /* before fus_comm_destroy of its communi
  * (any order; the blobs of non-neighbours are ignored; a rank that is its own neighbour passes its own blob).
  * The blobs are plain bytes (valid on this host only: they hold HIP IPC handles).  Destroy the halo objects only
  * after the last exchange has completed on every rank.
- * fus_halo_ipc_status: out4 = {device-side time-outs so far (0 = healthy), forward exchanges posted, reverse
- * exchanges posted, arena memory kind (0 fine-grained, 1 uncached, 2 ordinary)}; synchronises the communicator's streams.
+ * fus_halo_ipc_status: out8 = {failed device-side waits so far = time-outs + poisoned flags read (0 = healthy), forward
+ * exchanges posted, reverse exchanges posted, arena memory kind (0 fine-grained, 1 uncached, 2 ordinary), time-outs,
+ * poisoned flags read (a neighbour's halo object had failed), dead (0 / 1), 0}; synchronises the communicator's streams.
  */
 int64_t fus_halo_ipc_blob_bytes(fus_halo_t halo);
 int fus_halo_ipc_export(fus_halo_t halo, void* blob);
 int fus_halo_ipc_connect(fus_halo_t halo, int nblobs, const void* const* blobs);
-int fus_halo_ipc_status(fus_halo_t halo, int64_t* out4);
+int fus_halo_ipc_status(fus_halo_t halo, int64_t* out8);
 /*
  * forward: buffer[nlocal + g] = owner's value, for every ghost g          (scatter_forward, overwrite)
  * reverse: owner's buffer[i] += every ghosting rank's partial sum of i     (scatter_reverse, add)

@@ -15,6 +15,14 @@ modes
                                    skew between the ranks: every ghost value and every owned sum checked exactly each time
   deadpeer                         the owner rank never posts its exchange: the ghosting rank's receive must give up after
                                    FUS_IPC_SPIN_SECONDS and report a time-out instead of hanging
+  solver_deadpeer                  the linear solver on two processes; rank 1 stops stepping after 2 steps: rank 0's rk4() must
+                                   RAISE (not return a field), and rank 1, stepping again later, must raise too (poisoned flags)
+  hybrid <P> <nx> <ny> <nz> <gx> <gy> <gz> <ghost_order> <ranks_per_process> <apply|solver>
+                                   a world of gx*gy*gz ranks on world = that / ranks_per_process PROCESSES, each driving its
+                                   ranks in lock step (the 8-rank 2x2x2 partition on 4 processes: rank 0 ghosted by 7 ranks,
+                                   rank 7 ghosting from 7; face / edge / corner segments; neighbours of the same process
+                                   through plain pointers, the others through HIP IPC mappings).  apply: HaloApply == the
+                                   serial C oracle; solver: the fused linear solver on the partition == the one-rank solver
 Prints PEER_WORKER_OK <rank> on success; any failure is a non-zero exit."""
 import os
 import sys
@@ -30,7 +38,9 @@ def main():
     mode, rank, world, port = sys.argv[1], int(sys.argv[2]), int(sys.argv[3]), sys.argv[4]
     args = sys.argv[5:]
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=port, RANK=str(rank), WORLD_SIZE=str(world))
-    os.environ.setdefault("FUS_IPC_SPIN_SECONDS", "1" if mode == "deadpeer" else "10")
+    os.environ.setdefault("FUS_IPC_SPIN_SECONDS", {"deadpeer": "1", "solver_deadpeer": "2", "hybrid": "60"}.get(mode, "10"))
+    # (hybrid: 4 processes x 2 ranks x (launch + exchange stream) on ONE card is more hardware queues than the card has, so the
+    # processes' queues are time-sliced and a hand-off between two processes can cost scheduling quanta, not microseconds)
     import torch
     import torch.distributed as dist
 
@@ -42,6 +52,12 @@ def main():
     dev = torch.device("cuda", 0)
     dist.init_process_group("gloo", rank=rank, world_size=world)
     scat, boxmesh, utils = pkg("scatterer"), pkg("boxmesh"), pkg("utils")
+    if mode == "hybrid":
+        hybrid(args, rank, world, dev)
+        dist.barrier()
+        dist.destroy_process_group()
+        print(f"PEER_WORKER_OK {rank}", flush=True)
+        return
     comm = scat.NativeComm(transport="peer")
     assert comm.backend == "peer" and comm.size == world and comm.rank == rank
 
@@ -191,12 +207,160 @@ def main():
             assert time.perf_counter() - t0 < 0.5
         dist.barrier()
         fwd.close()
+    elif mode == "solver_deadpeer":
+        import time
+
+        lib_mod = pkg("_lib")
+        d = np.load(os.path.join(ROOT, "tests", "golden", "rk4_P2_4x2x2_pert_2ranks.npz"))
+        ls = pkg("linear_solver")
+        P, shape, grid = int(d["P"]), tuple(int(v) for v in d["shape"]), tuple(int(v) for v in d["grid"])
+        mesh = boxmesh.BoxMesh(P, shape, grid=grid, rank=rank, length=tuple(float(v) for v in d["lengths"]), perturb=float(d["perturb"]),
+                               seed=int(d["seed"]))
+        s = ls.LinearSpectral3D(mesh, np.float64, speed_of_sound=float(d["c0"]), density=float(d["rho0"]), source_frequency=float(d["f0"]),
+                                source_amplitude=float(d["p0"]), comm=comm, fused=True)
+        s.init()
+        dt = float(d["dt"])
+        if rank == 0:
+            t0 = time.perf_counter()
+            try:
+                s.rk4(0.0, 1.0, dt, max_steps=6)  # the neighbour leaves the loop after 2 steps
+            except lib_mod.FusGpuError as e:
+                assert "INVALID" in str(e) and "rank 0" in str(e), str(e)
+            else:
+                raise AssertionError("rk4() returned a field although the neighbour stopped exchanging")
+            assert time.perf_counter() - t0 < 20.0  # one bounded wait (2 s), then no waiting at all
+            st = s.halo.rev.status()
+            assert s.halo.health() >= 1 and (st["timeouts"] >= 1 or s.halo.fwd.status()["timeouts"] >= 1 or s.fwd_v.status()["timeouts"] >= 1)
+            dist.barrier()  # (A) rank 0 has failed
+            dist.barrier()  # (B) rank 1 has seen it
+        else:
+            _, steps = s.rk4(0.0, 1.0, dt, max_steps=2)  # healthy so far: every exchange had its partner
+            assert steps == 2 and s.halo.health() == 0
+            dist.barrier()  # (A)
+            try:
+                s.rk4(2 * dt, 1.0, dt, max_steps=1)  # the first flag it reads from rank 0 is poisoned
+            except lib_mod.FusGpuError as e:
+                assert "INVALID" in str(e), str(e)
+            else:
+                raise AssertionError("the neighbour's failure did not reach this rank")
+            st = [sc.status() for sc in (s.halo.fwd, s.halo.rev, s.fwd_v)]
+            assert sum(x["poisoned"] for x in st) >= 1 and sum(x["timeouts"] for x in st) == 0, st
+            dist.barrier()  # (B)
+        del s
     else:
         raise SystemExit(f"unknown mode {mode}")
     comm.close()
     dist.barrier()
     dist.destroy_process_group()
     print(f"PEER_WORKER_OK {rank}", flush=True)
+
+
+def hybrid(args, proc, nproc, dev):
+    """``ranks_per_process`` ranks of the world in each process, driven in lock step (generators), PEER transport."""
+    import torch
+    import torch.distributed as dist
+
+    from conftest import build_problem, pkg, ref_field, rel_l2
+    from halo_cpu import global_cell_constants
+    from oracle.oracle_c import OracleLib
+
+    scat, boxmesh, utils, ops, gll, pre, ls = (pkg(m) for m in ("scatterer", "boxmesh", "utils", "operators", "gll", "precompute", "linear_solver"))
+    P = int(args[0])
+    cells, grid = tuple(int(v) for v in args[1:4]), tuple(int(v) for v in args[4:7])
+    ghost_order = args[7] if args[7] in ("owner", "lex") else int(args[7])
+    rpp = int(args[8])
+    R = int(np.prod(grid))
+    assert R == nproc * rpp
+    mine = list(range(proc * rpp, (proc + 1) * rpp))
+    meshes = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r, perturb=0.16, seed=3, ghost_order=ghost_order) for r in range(R)]
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    # what the 2x2x2 partition is about: rank 0 is ghosted by 7 ranks, rank 7 ghosts dofs of 7 owners (3 faces, 3 edges, 1
+    # corner: segments of many chunks next to one-element ones)
+    if grid == (2, 2, 2):
+        assert len(gd[0][3]) == 7 and len(od[R - 1][3]) == 7 and min(int(v) for v in od[R - 1][1]) == 1
+    what = args[9]
+
+    def lockstep(gens):
+        live = list(gens)
+        while live:
+            nxt = []
+            for g in live:
+                try:
+                    next(g)
+                    nxt.append(g)
+                except StopIteration:
+                    pass
+            live = nxt
+
+    if what == "apply":
+        pts, wts, D = gll.tabulate_1d(P)
+        n = P + 1
+        w3, dg = gll.tensor_weights_3d(wts), pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))
+        op = ops.stiffness_operator(P, D.flatten(), np.float64)
+        comms, halos, ranks = [], [], []
+        for r in mine:
+            mesh = meshes[r]
+            G = np.zeros((mesh.ncells, n**3, 6))
+            pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), mesh.ncells, dg, w3)
+            x = ref_field(mesh.dof_coordinates())
+            x[mesh.nlocal:] = -777.0
+            ranks.append(dict(mesh=mesh, x=torch.from_numpy(x).to(dev), y=torch.zeros(mesh.ndofs, dtype=torch.float64, device=dev),
+                              cc=torch.from_numpy(global_cell_constants(mesh)).to(dev), G=torch.from_numpy(G).to(dev),
+                              dm=torch.from_numpy(mesh.dofmap).to(dev)))
+            comms.append(scat.NativeComm(local=(4242, R, r), transport="peer", hosted=mine))
+        for r, rk, comm in zip(mine, ranks, comms):  # closures in the same order in every process: rank-local index 0, 1, ...
+            halos.append(scat.HaloApply(rk["mesh"], op, comm, np.float64, plan=(od[r], gd[r]), schedule="concurrent"))
+
+        for rep in range(3):
+            for rk in ranks:
+                rk["y"].zero_()
+            lockstep([h.apply_schedule(rk["x"], rk["cc"], rk["y"], rk["G"], rk["dm"]) for h, rk in zip(halos, ranks)])
+        torch.cuda.synchronize()
+        assert all(h.health() == 0 for h in halos)
+        pb = build_problem(P, cells, perturb=0.16, seed=3)
+        ms = pb["mesh"]
+        y_ser = np.zeros(ms.ndofs)
+        OracleLib().stiffness_apply(P, pb["D"], pb["x"], global_cell_constants(ms), y_ser, pb["G"], ms.dofmap)
+        for r, rk in zip(mine, ranks):
+            m = rk["mesh"]
+            lex = m.global_lexicographic_ids()
+            err = rel_l2(rk["y"].cpu().numpy()[: m.nlocal], y_ser[lex[: m.nlocal]])
+            assert err < 1e-12, f"rank {r}: partitioned apply vs serial oracle {err}"
+            assert np.allclose(rk["x"].cpu().numpy(), pb["x"][lex], rtol=0, atol=1e-12), f"rank {r}: ghosts not refreshed"
+        dist.barrier()
+        del halos
+        return
+    # the fused linear solver on the same partition (set-up reverse scatter, grouped forward scatters of (u_n, v_n), reverse
+    # of b, concurrent schedule with the fork / join folded into the exchange kernels) == the one-rank solver
+    L = (0.012, 0.012, 0.012)
+    kw = dict(speed_of_sound=1500.0, density=1000.0, source_frequency=0.5e6, source_amplitude=60000.0)
+    smesh = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r, length=L, perturb=0.12, seed=5, ghost_order=ghost_order) for r in range(R)]
+    od2, gd2 = utils.compute_scatterer_data_all([m.index_map for m in smesh])
+    comms2 = [scat.NativeComm(local=(4343, R, r), transport="peer", hosted=mine) for r in mine]
+    solvers = [ls.LinearSpectral3D(smesh[r], np.float64, comm=c, fused=True, halo_plan=(od2[r], gd2[r]), defer_setup_exchange=True, **kw)
+               for r, c in zip(mine, comms2)]
+    lockstep([s_._setup for s_ in solvers])
+    one = boxmesh.BoxMesh(P, cells, length=L, perturb=0.12, seed=5)
+    h = ls.time_step_parameters(one, P, 1500.0, 0.5e6, L[0])
+    dts, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L[0])
+    for s_ in solvers:
+        s_.init()
+    lockstep([s_.rk4_schedule(0.0, tf, dts, max_steps=5) for s_ in solvers])
+    torch.cuda.synchronize()
+    for s_ in solvers:
+        s_.check_halo_health("hybrid solver")
+    assert all(s_.halo.schedule_kind == "concurrent" for s_ in solvers)
+    ref = ls.LinearSpectral3D(one, np.float64, fused=True, **kw)
+    ref.init()
+    ref.rk4(0.0, tf, dts, max_steps=5)
+    u_ref = ref.u_sol()
+    assert np.abs(u_ref).max() > 0
+    for r, s_ in zip(mine, solvers):
+        lex = smesh[r].global_lexicographic_ids()[: smesh[r].nlocal]
+        e = rel_l2(s_.u_sol(), u_ref[lex])
+        assert e < 1e-11, f"rank {r}: partitioned solver vs one-rank solver {e}"
+    dist.barrier()
+    del solvers
 
 
 if __name__ == "__main__":

@@ -33,7 +33,7 @@ def test_library_exports_every_declared_symbol():
 def test_host_only_entry_points():
     lib_mod = pkg("_lib")
     lib = lib_mod.load()
-    assert lib.fus_abi_version() == lib_mod.ABI_VERSION == 2  # include/fus_gpu.h FUS_ABI_VERSION
+    assert lib.fus_abi_version() == lib_mod.ABI_VERSION == 3  # include/fus_gpu.h FUS_ABI_VERSION
     assert lib.fus_error_string(0) == b"ok"
     assert b"degree" in lib.fus_error_string(-2)
     assert lib.fus_stiffness_plan_bytes(4, 157464) > 0

@@ -299,8 +299,8 @@ def _run_peer_world(world, mode, args, timeout=300):
         for p in procs:
             if p.poll() is None:
                 p.kill()
-    for r, (p, out) in enumerate(zip(procs, outs)):
-        assert p.returncode == 0 and f"PEER_WORKER_OK {r}" in out, f"rank {r} (exit {p.returncode}):\n{out[-3000:]}"
+    bad = [r for r, (p, out) in enumerate(zip(procs, outs)) if p.returncode != 0 or f"PEER_WORKER_OK {r}" not in out]
+    assert not bad, "\n".join(f"---- process {r} (exit {procs[r].returncode}):\n{outs[r][-1500:]}" for r in bad)
 
 
 @pytest.mark.parametrize("dtype", ["float64", "float32"])
@@ -415,6 +415,30 @@ def test_peer_transport_dead_peer_times_out_instead_of_hanging(gpu):
     counted (``status()["timeouts"]``) after FUS_IPC_SPIN_SECONDS and its kernels drain; later exchanges of that halo do
     not wait at all."""
     _run_peer_world(2, "deadpeer", [])
+
+
+def test_peer_transport_solver_raises_when_a_neighbour_stops(gpu):
+    """A timed-out exchange must be LOUD (ADVICE medium): rank 1 leaves the time loop after two steps;
+    rank 0's ``LinearSpectral3D.rk4`` raises instead of handing back a pressure field computed from stale ghosts, and the
+    failure reaches rank 1 through poisoned flags: its next ``rk4`` raises too, with no time-out of its own."""
+    _run_peer_world(2, "solver_deadpeer", [], timeout=300)
+
+
+@pytest.mark.parametrize("what", ["apply", "solver"])
+@pytest.mark.parametrize("P,cells,grid,ghost_order,rpp", [
+    (4, (4, 4, 4), (2, 2, 2), 7, 2),
+    (2, (6, 4, 4), (2, 2, 2), "owner", 2),
+], ids=["P4-permuted", "P2-direct-uneven"])
+def test_peer_transport_8_ranks_2x2x2_on_4_processes(gpu, P, cells, grid, ghost_order, rpp, what):
+    """The exact 8-rank configuration of BASELINE config 4 (2x2x2 blocks: rank 0 ghosted by 7 ranks, rank 7 ghosting from 7
+    owners; face, (P n + 1)-element edge and 1-element corner segments) over the PEER transport with REAL processes.  The
+    pool's process guard allows at most 6 processes on the card, so the 8 ranks run on 4 processes of 2 ranks each:
+    neighbours of the same process are reached through plain pointers, the others through HIP IPC mappings, by the same
+    kernels.  apply: HaloApply (concurrent schedule, fork / join folded into the exchange kernels) == the serial C oracle;
+    solver: 5 steps of the fused linear solver on the partition == the one-rank solver.  (More hardware queues than the
+    card has: the processes' queues are time-sliced, so the device-side waits get 60 s here.)"""
+    R = int(np.prod(grid))
+    _run_peer_world(R // rpp, "hybrid", [P, *cells, *grid, ghost_order, rpp, what], timeout=600)
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
@@ -556,3 +580,82 @@ def test_grouped_exchange_two_vectors_in_process_ranks(gpu, ghost_order, transpo
         for r in range(R):
             assert np.allclose(du[r].cpu().numpy(), eu[r], rtol=0, atol=1e-13)
             assert np.allclose(dv[r].cpu().numpy(), ev[r], rtol=0, atol=1e-13)
+
+
+def test_peer_failed_exchange_poisons_the_neighbour(gpu, monkeypatch):
+    """In-process world of two ranks.  The ghosting rank posts its forward exchange alone: its receive gives up after
+    FUS_IPC_SPIN_SECONDS (time-out, halo dead) and the credit it returns is POISONED.  When the owner posts later, its send
+    reads the poisoned credit: it counts it, does not deliver, dies too -- ``health()`` != 0 on both ranks -- and the
+    ghosts of the first rank were never overwritten with stale arena contents."""
+    torch = gpu
+    monkeypatch.setenv("FUS_IPC_SPIN_SECONDS", "1")
+    scat, boxmesh, utils = pkg("scatterer"), pkg("boxmesh"), pkg("utils")
+    meshes = [boxmesh.BoxMesh(2, (4, 2, 2), grid=(2, 1, 1), rank=r) for r in range(2)]
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = next(_world_ids)
+    comms = [scat.NativeComm(local=(wid, 2, r), transport="peer") for r in range(2)]
+    fwd = [scat.scatter_forward(comms[r], od[r], gd[r], meshes[r].nlocal, np.float64) for r in range(2)]
+    dev = torch.device("cuda", 0)
+    b0 = torch.arange(meshes[0].ndofs, dtype=torch.float64, device=dev)
+    b1 = torch.full((meshes[1].ndofs,), -5.0, dtype=torch.float64, device=dev)
+    # a healthy exchange first (sequence 1)
+    fwd[0].begin(b0), fwd[1].begin(b1)
+    fwd[0].end(b0), fwd[1].end(b1)
+    torch.cuda.synchronize()
+    assert comms[0].health() == 0 and comms[1].health() == 0
+    assert torch.equal(b1[meshes[1].nlocal:], b0[torch.from_numpy(np.asarray(gd[0][0])).to(dev)])
+    b1[meshes[1].nlocal:] = -9.0  # consuming the arena's stale message 1 would overwrite these
+    good = b1.clone()
+    # sequence 2: rank 1 alone
+    fwd[1].begin(b1)
+    fwd[1].end(b1)
+    torch.cuda.synchronize()
+    st1 = fwd[1].status()
+    assert st1["timeouts"] >= 1 and st1["dead"] and comms[1].health() >= 1
+    assert torch.equal(b1, good)  # nothing was consumed from the arena
+    # rank 0 posts its sequence 2 now: the credit it waits for is poisoned
+    fwd[0].begin(b0)
+    fwd[0].end(b0)
+    torch.cuda.synchronize()
+    st0 = fwd[0].status()
+    assert st0["poisoned"] >= 1 and st0["timeouts"] == 0 and st0["dead"] and comms[0].health() >= 1
+    for sc in fwd:
+        sc.close()
+    for c in comms:
+        c.close()
+
+
+def test_fork_join_enforce_one_caller_stream(gpu):
+    """``fus_comm_fork`` / ``fus_comm_join`` have ONE sequence flag per direction: consecutive forks of a communicator must
+    come from one caller stream.  Enforced: a join from another stream than its fork, and a fork
+    from another stream while the communicator's stream still has forked work, are refused (FUS_ERR_INVALID_ARGUMENT,
+    nothing launched); a change of the caller stream once the communicator's stream has drained is fine."""
+    torch = gpu
+    scat, lib_mod = pkg("scatterer"), pkg("_lib")
+    comm = scat.NativeComm(transport="peer")
+    side = comm.stream()
+    s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
+    big = torch.zeros(1 << 28, dtype=torch.float64, device="cuda")  # 2 GiB: a fill takes ~0.5 ms
+    with torch.cuda.stream(s_a):
+        comm.fork()
+        with torch.cuda.stream(side):
+            for _ in range(40):
+                big.add_(1.0)  # ~40 ms of work on the communicator's stream, ordered after the fork
+    with torch.cuda.stream(s_b):
+        with pytest.raises(lib_mod.FusGpuError):
+            comm.join()  # not the stream that forked
+        with pytest.raises(lib_mod.FusGpuError):
+            comm.fork()  # the communicator's stream is still busy with work forked from s_a
+    with torch.cuda.stream(s_a):
+        comm.join()
+    torch.cuda.synchronize()
+    assert float(big[0].item()) == 40.0
+    with torch.cuda.stream(s_b):  # drained: another caller stream may take over
+        comm.fork()
+        with torch.cuda.stream(side):
+            big.add_(1.0)
+        comm.join()
+    torch.cuda.synchronize()
+    assert float(big[-1].item()) == 41.0 and comm.health() == 0
+    del big
+    comm.close()

@@ -414,6 +414,45 @@ def test_config2_full_size(gpu, oracle_c):
         _check(y.cpu().numpy(), y_ref, np.float64, f"{name}, config 2")
 
 
+def test_config1_default_kernels(gpu, oracle_c):
+    """BASELINE config 1 at its stated size (numba-cpu/time_operators.py: P = 2, 18^3 cells, 50 653 dofs) on the SHIPPED
+    default kernels -- planned stiffness, planned cell mass, facet mass of all six faces -- against the oracle
+    (config 1 was exercised on the plan-free variants only)."""
+    import torch
+
+    dev, ops = gpu
+    boxmesh, gll, pre = pkg("boxmesh"), pkg("gll"), pkg("precompute")
+    P, N = 2, 18
+    pb = build_problem(P, N, perturb=0.16)
+    mesh = pb["mesh"]
+    assert mesh.ndofs == 50653 and mesh.ncells == 5832
+    n = P + 1
+    assert ops._USE_PLAN
+    x_d, cc_d, dm = dev.to_device(pb["x"]), dev.to_device(pb["cc"]), dev.to_device(mesh.dofmap)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap, threads=4)
+    y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+    ops.stiffness_operator(P, pb["D"].flatten(), np.float64)(x_d, cc_d, y, dev.to_device(pb["G"]), dm)
+    _check(y.cpu().numpy(), y_ref, np.float64, "planned stiffness, config 1")
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.mass_apply(pb["x"], pb["cc"], y_ref, pb["detJ"], mesh.dofmap)
+    y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+    ops.mass_operator(n**3, np.float64)(x_d, cc_d, y, dev.to_device(pb["detJ"]), dm)
+    _check(y.cpu().numpy(), y_ref, np.float64, "planned cell mass, config 1")
+    bd = mesh.boundary_facets()
+    assert bd.shape[0] == 6 * N * N
+    dF = np.zeros((bd.shape[0], n * n))
+    pre.compute_boundary_facets_scaled_jacobian_determinant(dF, (mesh.x_dofs, mesh.x_g), bd, pre.tabulate_facet_gradients(pb["pts"]),
+                                                            gll.tensor_weights_2d(pb["wts"]))
+    fdm = mesh.facet_dofmap(bd)
+    fc = 1.0 + 0.25 * np.random.default_rng(5).standard_normal(bd.shape[0])
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.mass_apply(pb["x"], fc, y_ref, dF, fdm)
+    y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+    ops.mass_operator(n * n, np.float64)(x_d, dev.to_device(fc), y, dev.to_device(dF), dev.to_device(fdm))
+    _check(y.cpu().numpy(), y_ref, np.float64, "facet mass, config 1")
+
+
 def test_full_size_config3(gpu, oracle_c):
     """BASELINE config 3 at full size (P = 4, 54^3 perturbed cells, 10 218 313 dofs): the planned
     and the plan-free kernel against the oracle (all host cores), plus size-independent

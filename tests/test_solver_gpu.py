@@ -473,3 +473,73 @@ def test_westervelt_solver_graph_replay_matches_rk4(mode):
     assert sa == 31 and s1 == 7 and s1 + s2 == sa and abs(t2 - ta) < 1e-18 and len(b._graphs) == 1
     assert np.max(np.abs(a.u_sol())) > 0
     assert rel_l2(b.u_sol(), a.u_sol()) < 1e-13 and rel_l2(b.v_sol(), a.v_sol()) < 1e-13
+
+
+def test_config3_full_size_rk4_fused_vs_reference_sequence():
+    """BASELINE config 3 at FULL size (demo_linear_box: P = 4, 54^3 perturbed cells, 10 218 313 dofs, general G): 5 RK4 steps
+    of the fused path (one vector kernel per stage, facet terms in one launch, solution kept in (u0, v0)) against the
+    reference's own launch sequence (cuda/demo_linear_box.py:487-566: 12 launches per stage) through the reference-compatible
+    operators -- rel l2 <= 1e-12 -- plus the in-kernel-geometry variant, plus one invariant: with the source switched off the
+    field stays exactly zero (the discrete operator maps 0 to 0: no stray contribution from plan slots or facets)."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls = pkg("boxmesh"), pkg("linear_solver")
+    P, N, L = 4, 54, 0.12
+    mesh = boxmesh.BoxMesh(P, N, length=L, perturb=0.16, seed=0)
+    assert mesh.ndofs == 10218313
+    h = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    res = {}
+    for name, kw in (("reference", dict(fused=False)), ("fused", dict(fused=True)), ("fused-geom", dict(fused=True, in_kernel_geometry=True))):
+        s = ls.LinearSpectral3D(mesh, np.float64, **kw)
+        assert not s.affine
+        s.init()
+        t, steps = s.rk4(0.0, tf, dt, max_steps=5)
+        assert steps == 5
+        res[name] = (s.u_sol(), s.v_sol())
+        del s
+        torch.cuda.empty_cache()
+    assert np.max(np.abs(res["reference"][0])) > 0
+    for name in ("fused", "fused-geom"):
+        assert rel_l2(res[name][0], res["reference"][0]) < 1e-12, name
+        assert rel_l2(res[name][1], res["reference"][1]) < 1e-12, name
+    s = ls.LinearSpectral3D(mesh, np.float64, fused=True, source_amplitude=0.0)
+    s.init()
+    s.rk4(0.0, tf, dt, max_steps=2)
+    assert float(s.u.abs().max().item()) == 0.0 and float(s.v.abs().max().item()) == 0.0
+
+
+def test_config5_full_degree_westervelt_fused_vs_reference_sequence():
+    """BASELINE config 5's operator shape at a size one GPU holds comfortably (demo_nonlinear_bowl: Westervelt, P = 6, bowl-warped
+    trilinear cells; 36^3 cells = 10 077 696 dofs): 3 RK4 steps of the fused path -- general G and G formed in the kernel --
+    against the reference's launch sequence (four cell kernels per stage, cuda/demo_nonlinear_bowl.py:603-632)."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, nls = pkg("boxmesh"), pkg("linear_solver"), pkg("nonlinear_solver")
+    P, N, L = 6, 36, 0.06
+
+    def bowl(xg):
+        out = xg.copy()
+        yy, zz = xg[:, 1] / L - 0.5, xg[:, 2] / L - 0.5
+        out[:, 0] = xg[:, 0] + 0.15 * (L / N) * 4 * (yy * yy + zz * zz) * (1.0 - xg[:, 0] / L)
+        return out
+
+    mesh = boxmesh.BoxMesh(P, N, length=L, warp=bowl)
+    assert mesh.ndofs == (P * N + 1) ** 3
+    h = ls.time_step_parameters(mesh, P, 1480.0, 1.1e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 1480.0, 1.1e6, L)
+    res = {}
+    for name, kw in (("reference", dict(fused=False)), ("fused", dict(fused=True)), ("fused-geom", dict(fused=True, in_kernel_geometry=True))):
+        s = nls.WesterveltSpectral3D(mesh, np.float64, **kw)
+        s.init()
+        _, steps = s.rk4(0.0, tf, dt, max_steps=3)
+        assert steps == 3
+        res[name] = (s.u_sol(), s.v_sol())
+        del s
+        torch.cuda.empty_cache()
+    assert np.max(np.abs(res["reference"][0])) > 0
+    for name in ("fused", "fused-geom"):
+        assert rel_l2(res[name][0], res["reference"][0]) < 1e-11, name
+        assert rel_l2(res[name][1], res["reference"][1]) < 1e-11, name
