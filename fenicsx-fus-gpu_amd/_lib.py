@@ -51,6 +51,8 @@ def _signatures():
         "fus_comm_last_error": [_vp],
         "fus_comm_fork": [_vp, _vp],
         "fus_comm_fork_lazy": [_vp, _vp],
+        "fus_comm_fork_ex": [_vp, _vp, _int],
+        "fus_comm_fork_flush": [_vp],
         "fus_comm_join": [_vp, _vp],
         "fus_comm_arm_join": [_vp],
         "fus_comm_health": [_vp, _vp],

@@ -354,19 +354,9 @@ class BoxMesh:
         """``[6, n^2]`` local dofs in the closure of each local facet (stand-in
         for ``basix_element.entity_closure_dofs[2]``,
         numba-cpu/test_operators.py:127-129), ordered like ``facet_points``."""
-        n = self.n
-        from .precompute import HEX_FACET_AXIS_SIDE
+        from .dolfinx_adaptor import local_facet_dofs
 
-        out = np.empty((6, n * n), dtype=np.int32)
-        a_, b_ = np.meshgrid(np.arange(n), np.arange(n), indexing="ij")
-        a_, b_ = a_.reshape(-1), b_.reshape(-1)
-        for f, (axis, side) in enumerate(HEX_FACET_AXIS_SIDE):
-            idx = [None, None, None]
-            free = [a for a in range(3) if a != axis]
-            idx[free[0]], idx[free[1]] = a_, b_
-            idx[axis] = np.full(n * n, side * (n - 1))
-            out[f] = idx[0] * n * n + idx[1] * n + idx[2]
-        return out
+        return local_facet_dofs(self.P)
 
     def boundary_facets(self, faces=None) -> np.ndarray:
         """``boundary_data[i] = (cell, local_facet)`` for this rank's cells on

@@ -687,7 +687,7 @@ int fus_comm_create(const void* id, int nranks, int rank, fus_comm_t* out) {
   c->c.kind = fus::Comm::RCCL;
   c->c.rank = rank;
   c->c.nranks = nranks;
-  hipError_t e = fus::comm_make_stream(&c->c);
+  hipError_t e = fus::comm_make_stream_and_sync(&c->c);
   if (e != hipSuccess) {
     delete c;
     return hip_rc(e);
@@ -711,7 +711,7 @@ int fus_comm_create_peer(int nranks, int rank, fus_comm_t* out) {
   c->c.kind = fus::Comm::PEER;
   c->c.rank = rank;
   c->c.nranks = nranks;
-  hipError_t e = fus::comm_make_stream(&c->c);
+  hipError_t e = fus::comm_make_stream_and_sync(&c->c);
   if (e != hipSuccess) {
     if (c->c.stream) (void)hipStreamDestroy(c->c.stream);
     delete c;
@@ -738,7 +738,7 @@ int fus_comm_create_local(int world_id, int nranks, int rank, fus_comm_t* out) {
   c->c.rank = rank;
   c->c.nranks = nranks;
   c->c.world = w;
-  hipError_t e = fus::comm_make_stream(&c->c);
+  hipError_t e = fus::comm_make_stream_and_sync(&c->c);
   if (e != hipSuccess) {
     delete c;
     return hip_rc(e);
@@ -751,14 +751,22 @@ int fus_comm_rank(fus_comm_t comm) { return comm ? comm->c.rank : FUS_ERR_INVALI
 int fus_comm_size(fus_comm_t comm) { return comm ? comm->c.nranks : FUS_ERR_INVALID_ARGUMENT; }
 void* fus_comm_stream(fus_comm_t comm) { return comm ? comm->c.stream : nullptr; }
 
-static int comm_fork_join_rc(fus_comm_t comm, void* stream, int which, bool lazy) {
+static int comm_fork_join_rc(fus_comm_t comm, void* stream, int which, bool lazy, bool attach = false) {
   if (!comm) return FUS_ERR_INVALID_ARGUMENT;
   bool misuse = false;
-  const hipError_t e = fus::comm_fork_join(&comm->c, static_cast<hipStream_t>(stream), which, lazy, &misuse);
+  const hipError_t e = fus::comm_fork_join(&comm->c, static_cast<hipStream_t>(stream), which, lazy, &misuse, attach);
   return misuse ? FUS_ERR_INVALID_ARGUMENT : hip_rc(e);
 }
 int fus_comm_fork(fus_comm_t comm, void* stream) { return comm_fork_join_rc(comm, stream, 0, false); }
 int fus_comm_fork_lazy(fus_comm_t comm, void* stream) { return comm_fork_join_rc(comm, stream, 0, true); }
+int fus_comm_fork_ex(fus_comm_t comm, void* stream, int flags) {
+  if (flags & ~(FUS_FORK_LAZY | FUS_FORK_ATTACH)) return FUS_ERR_INVALID_ARGUMENT;
+  return comm_fork_join_rc(comm, stream, 0, (flags & FUS_FORK_LAZY) != 0, (flags & FUS_FORK_ATTACH) != 0);
+}
+int fus_comm_fork_flush(fus_comm_t comm) {
+  if (!comm) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::comm_flush_attached(&comm->c));
+}
 int fus_comm_join(fus_comm_t comm, void* stream) { return comm_fork_join_rc(comm, stream, 1, false); }
 int fus_comm_arm_join(fus_comm_t comm) {
   if (!comm) return FUS_ERR_INVALID_ARGUMENT;
@@ -794,6 +802,7 @@ int fus_comm_destroy(fus_comm_t comm) {
     comm->c.last_error = "fus_comm_destroy: " + std::to_string(comm->c.nhalos) + " halo object(s) of this communicator are still alive";
     return FUS_ERR_COMM;
   }
+  (void)fus::comm_flush_attached(&comm->c);  // a fork signal still waiting for a launch to carry it must not outlive its flag
   if (comm->c.stream) (void)hipStreamSynchronize(comm->c.stream);
   if (comm->c.stream2) (void)hipStreamSynchronize(comm->c.stream2);
   if (comm->c.nccl) (void)fus::rccl().CommDestroy(comm->c.nccl);

@@ -102,8 +102,9 @@ __global__ void __launch_bounds__(256)
     mass_plan_kernel(const T* __restrict__ x, const T* __restrict__ entity_constants, T* __restrict__ y,
                      const T* __restrict__ detJ, const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
                      const uint16_t* __restrict__ slot, int N, int epb, int64_t nent, uint32_t inv_n,
-                     const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
+                     const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+  launch_signal_publish(sig);
   const int M = N * epb;
   PlanAcc* sy = reinterpret_cast<PlanAcc*>(smem_raw);  // partial sums in double also for fp32 (stiffness_plan.hpp)
   T* sx = reinterpret_cast<T*>(sy + M);
@@ -172,9 +173,10 @@ inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* d
   const uint32_t inv_n = (uint32_t)((0x100000000ull + (uint64_t)N - 1) / (uint64_t)N);  // ceil(2^32 / N), N >= 2
   const size_t lds = (size_t)M * (sizeof(PlanAcc) + sizeof(T));
   const dim3 grid((unsigned)v.nbatch), block(256);
+  const LaunchSignal sig = take_launch_signal(stream);
 #define FUS_MASS_LAUNCH(E)                                                                                        \
   hipLaunchKernelGGL((mass_plan_kernel<T, E>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \
-                     N, epb, nent, inv_n, ordered ? v.order : nullptr, use_runs ? v.runs : nullptr)
+                     N, epb, nent, inv_n, ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig)
   const int ept = (M + 255) / 256;
   if (ept <= 1) FUS_MASS_LAUNCH(1);
   else if (ept <= 2) FUS_MASS_LAUNCH(2);

@@ -31,6 +31,9 @@
 #pragma once
 
 #include <hip/hip_runtime.h>
+
+#include <mutex>
+#include <vector>
 #include <stdint.h>
 
 #include <type_traits>
@@ -38,6 +41,72 @@
 #include "stiffness.hpp"
 
 namespace fus {
+
+// A planned operator launch can carry a FORK SIGNAL: the first workgroup of the launch stores ``seq`` in ``flag`` (device
+// scope).  Every kernel enqueued before it on the stream has completed when any workgroup of it starts, so this is what a
+// one-thread signal kernel in front of the launch would publish -- without that kernel's 2.4 us on the caller's stream
+// (halo_comm.hpp: fork / join without events; fus_comm_fork_ex FUS_FORK_ATTACH).
+struct LaunchSignal {
+  uint64_t* flag;  // nullptr: nothing to publish
+  uint64_t seq;
+};
+__device__ inline void launch_signal_publish(const LaunchSignal& s) {
+  if (s.flag != nullptr && blockIdx.x == 0 && threadIdx.x == 0)
+    __hip_atomic_store(s.flag, s.seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+// host side: the signal waiting for the next planned launch on a stream (at most one per stream)
+struct PendingLaunchSignal {
+  hipStream_t stream;
+  LaunchSignal sig;
+};
+inline std::vector<PendingLaunchSignal>& pending_launch_signals() {
+  static std::vector<PendingLaunchSignal> v;
+  return v;
+}
+inline std::mutex& pending_launch_signals_mutex() {
+  static std::mutex m;
+  return m;
+}
+inline LaunchSignal take_launch_signal(hipStream_t stream) {
+  std::lock_guard<std::mutex> lock(pending_launch_signals_mutex());
+  auto& v = pending_launch_signals();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].stream == stream) {
+      const LaunchSignal s = v[i].sig;
+      v.erase(v.begin() + (long)i);
+      return s;
+    }
+  return LaunchSignal{nullptr, 0};
+}
+// Post a signal for the next planned launch on ``stream``.  A signal already waiting on that stream is handed back (the
+// caller publishes it with a signal kernel): at most one per stream, and ANY later launch on the stream may carry it --
+// "everything enqueued on the stream before the fork has completed" holds when any later kernel of the stream starts.
+inline LaunchSignal post_launch_signal(hipStream_t stream, uint64_t* flag, uint64_t seq) {
+  std::lock_guard<std::mutex> lock(pending_launch_signals_mutex());
+  auto& v = pending_launch_signals();
+  LaunchSignal old{nullptr, 0};
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].stream == stream) {
+      old = v[i].sig;
+      v.erase(v.begin() + (long)i);
+      break;
+    }
+  v.push_back(PendingLaunchSignal{stream, LaunchSignal{flag, seq}});
+  return old;
+}
+// the signal still waiting to be carried for ``flag`` (no planned launch has come), with its stream; {nullptr} if none
+inline LaunchSignal take_launch_signal_of(const uint64_t* flag, hipStream_t* stream) {
+  std::lock_guard<std::mutex> lock(pending_launch_signals_mutex());
+  auto& v = pending_launch_signals();
+  for (size_t i = 0; i < v.size(); ++i)
+    if (v[i].sig.flag == flag) {
+      const LaunchSignal s = v[i].sig;
+      *stream = v[i].stream;
+      v.erase(v.begin() + (long)i);
+      return s;
+    }
+  return LaunchSignal{nullptr, 0};
+}
 
 constexpr int64_t kPlanMagic = 0x46555350314c414eLL;  // "FUSP1LAN"
 constexpr int kPlanMaxRuns = 128;                      // runs of a batch: one per thread of (at least) two waves

@@ -15,9 +15,10 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                                  const T* __restrict__ G, const int32_t* __restrict__ nu,
                                  const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
                                  const T* __restrict__ dphi, int64_t ncell, const T* __restrict__ wratio,
-                                 const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
+                                 const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
+  launch_signal_publish(sig);
 
   __shared__ T sD[n2];
   __shared__ T su[CPB * S];
@@ -105,7 +106,7 @@ inline hipError_t launch_stiffness_plan_affine(const T* x, const T* cc, T* y, co
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_affine_kernel<T, P, CPB, ALIAS, PADLDS, MINW>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, wratio,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr);
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, take_launch_signal(stream));
   return hipGetLastError();
 }
 

@@ -137,9 +137,10 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                                const T* __restrict__ pts, const T* __restrict__ wts,
                                const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
                                const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell,
-                               const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
+                               const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
+  launch_signal_publish(sig);
   constexpr int VPT = (CPB * 24 + BLOCK - 1) / BLOCK;  // vertex coordinates staged per thread (1 for P >= 4)
 
   __shared__ T sD[n2];
@@ -268,7 +269,7 @@ inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, cons
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr);
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, take_launch_signal(stream));
   return hipGetLastError();
 }
 

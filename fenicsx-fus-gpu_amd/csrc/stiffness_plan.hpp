@@ -164,10 +164,11 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
                           const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
                           const T* __restrict__ dphi, int64_t ncell, int xcd_remap,
-                          const int32_t* __restrict__ order, const int32_t* __restrict__ runs) {
+                          const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
   static_assert(GPRE >= 1 && GPRE <= n, "GPRE: slabs of G held in registers");
+  launch_signal_publish(sig);
 
   __shared__ T sD[n2];
   __shared__ T su[CPB * S];
@@ -259,7 +260,7 @@ inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* 
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GPRE>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr);
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, take_launch_signal(stream));
   return hipGetLastError();
 }
 

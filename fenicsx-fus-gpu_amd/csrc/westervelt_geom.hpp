@@ -19,8 +19,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
                                 const T* __restrict__ wts, const int32_t* __restrict__ nu,
                                 const int32_t* __restrict__ udofs, const uint16_t* __restrict__ slot,
                                 const T* __restrict__ dphi, int64_t ncell, const int32_t* __restrict__ order,
-                                const int32_t* __restrict__ runs) {
+                                const int32_t* __restrict__ runs, LaunchSignal sig) {
   constexpr int n = P + 1, n2 = n * n, Nd = n2 * n;
+  launch_signal_publish(sig);
   constexpr int S = lds_cell_stride<T, P>();
   constexpr int BLOCK = col_block_threads<P, CPB>();
   constexpr int M = CPB * Nd;
@@ -198,7 +199,7 @@ inline hipError_t launch_westervelt_cell_geom(const T* u, const T* v, const T* c
   constexpr int threads = col_block_threads<P, CPB>();
   hipLaunchKernelGGL((westervelt_cell_geom_kernel<T, P, CPB, 1, MASS>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u,
                      v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, pv.nu, pv.udofs, pv.slot, dphi, ncell,
-                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr);
+                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr, take_launch_signal(stream));
   return hipGetLastError();
 }
 

@@ -110,8 +110,10 @@ class LinearSpectral3D(StepGraphMixin):
 
         # ---- geometry precompute (reference: numba on the host, cuda/demo_linear_box.py:245-317) --
         nc = mesh.ncells
-        bd1 = mesh.boundary_facets([2])  # x = 0: source
-        bd2 = mesh.boundary_facets([3])  # x = L: absorbing
+        # the two tagged facet sets (cuda/demo_linear_box.py:230-243, cuda/utils.py:81-114): a structured box names them by its
+        # faces (x = 0: source, x = L: absorbing), a mesh handed over as arrays (dolfinx_adaptor.ArrayMesh) by its facet tags
+        bd1 = mesh.boundary_facets([getattr(mesh, "source_tag", 2)])
+        bd2 = mesh.boundary_facets([getattr(mesh, "absorbing_tag", 3)])
         D, G_d, detJ_d, (dF1_d, dF2_d) = device_geometry(mesh, P, ft, dev, (bd1, bd2))
         self.D = D
         rho = np.full(nc, self.rho0, dtype=ft)

@@ -49,7 +49,8 @@ class WesterveltSpectral3D(StepGraphMixin):
         dev = torch.device("cuda", torch.cuda.current_device())
         self.dev = dev
         nc = mesh.ncells
-        bd1, bd2 = mesh.boundary_facets([2]), mesh.boundary_facets([3])
+        # tagged facet sets: source / absorbing (a structured box: its x = 0 / x = L faces; dolfinx_adaptor.ArrayMesh: facet tags)
+        bd1, bd2 = mesh.boundary_facets([getattr(mesh, "source_tag", 2)]), mesh.boundary_facets([getattr(mesh, "absorbing_tag", 3)])
         D, G_d, detJ_d, (dF1_d, dF2_d) = device_geometry(mesh, P, ft, dev, (bd1, bd2))
         rho, c = np.full(nc, self.rho0), np.full(nc, self.c0)
         beta, delta = np.full(nc, self.beta), np.full(nc, self.delta)

@@ -226,12 +226,16 @@ class NativeComm:
             self._stream = torch.cuda.ExternalStream(int(ptr)) if ptr else None
         return self._stream
 
-    def fork(self, lazy=False):
-        """Order the communicator's stream after the caller's current stream, without an event (``fus_comm_fork``).
+    def fork(self, lazy=False, attach=False):
+        """Order the communicator's stream after the caller's current stream, without an event (``fus_comm_fork_ex``).
         ``lazy`` (PEER transport): no wait kernel -- the first send kernel of the exchange the caller posts NEXT on the
-        communicator's stream waits for the fork flag itself (``fus_comm_fork_lazy``)."""
-        fn = self._lib.fus_comm_fork_lazy if lazy else self._lib.fus_comm_fork
-        _lib.check(fn(self.handle, _lib.stream_ptr()), "fus_comm_fork", self.handle)
+        communicator's stream waits for the fork flag itself.  ``attach``: no signal kernel -- the next PLANNED operator
+        launch on the caller's stream publishes the flag when it starts (``fork_flush()`` if none follows)."""
+        _lib.check(self._lib.fus_comm_fork_ex(self.handle, _lib.stream_ptr(), (1 if lazy else 0) | (2 if attach else 0)), "fus_comm_fork", self.handle)
+
+    def fork_flush(self):
+        """Publish an attached fork signal that no planned launch has carried (``fus_comm_fork_flush``)."""
+        _lib.check(self._lib.fus_comm_fork_flush(self.handle), "fus_comm_fork_flush", self.handle)
 
     def arm_join(self):
         """PEER transport: the last receive kernel of the exchange posted next publishes the join flag, so that ``join()``
@@ -652,6 +656,8 @@ class HaloApply:
         self.side_stream = os.environ.get("FUS_HALO_SIDE_STREAM", "0") == "1"
         self._lib_sync = os.environ.get("FUS_HALO_EVENT_SYNC", "0") != "1"  # 1: fork / join the side stream with events
         self._fold_sync = os.environ.get("FUS_HALO_FOLD_SYNC", "1") != "0"  # 0: fork / join as kernels of their own (A/B runs)
+        self._attach_sync = os.environ.get("FUS_HALO_ATTACH_SYNC", "1") != "0"  # 0: the fork's signal as a kernel of its own
+        self._warm = set()  # interior cell ranges (by the pointers of their per-cell arrays) that have been applied once
         self._hs = None
 
     def neighbour_ranks(self):
@@ -737,15 +743,26 @@ class HaloApply:
             ev_start, ev_side = self._events
             # PEER: fork and join are folded into the first send / last receive kernel of the chain (two kernels fewer)
             fold = lib_sync and getattr(self.comm, "transport", None) == "peer" and self._fold_sync
+            # ... and the fork's signal rides on the interior launch itself (planned kernels publish the fork flag when their
+            # first workgroup starts).  The flag then depends on the HOST reaching that launch, so nothing that can
+            # synchronise the device may sit between the fork and the launch: the launch follows the fork at once (the
+            # forward exchange is posted after it; it still runs under the interior kernel), and only once this cell
+            # range has been applied before -- its batch plan exists, no first-use set-up inside the launch call.
+            a_, b_ = self.ranges["interior"]
+            warm_key = ("interior",) + tuple(t.data_ptr() for t in percell)
+            attach = lib_sync and self._attach_sync and self._apply_fn is None and b_ > a_ and warm_key in self._warm
             if lib_sync:
-                self.comm.fork(lazy=fold and len(forward) > 0)
+                self.comm.fork(lazy=fold and len(forward) > 0, attach=attach)
             else:
                 ev_start.record(main)
                 side.wait_event(ev_start)
+            part("interior")
+            if attach:
+                self.comm.fork_flush()  # a launch that could not carry the signal (plan-free kernel): a signal kernel after all
+            self._warm.add(warm_key)
             with torch.cuda.stream(side):
                 fw = begin_all(forward)
             yield "forward"
-            part("interior")
             with torch.cuda.stream(side):
                 for sc, vec, wk in fw:
                     sc.end(vec, wk)

@@ -410,11 +410,21 @@ void* fus_comm_stream(fus_comm_t comm); /* the hipStream_t the exchanges run on 
  *                  join flag; the fus_comm_join after it then launches only the wait kernel on the caller's stream.  That
  *                  exchange must be the last work on the communicator's stream before the join (falls back to the signal
  *                  kernel where no receive kernel can carry it).
+ *   fus_comm_fork_ex(flags): FUS_FORK_LAZY as fus_comm_fork_lazy; FUS_FORK_ATTACH (any transport): no signal kernel on
+ *                  ``stream`` either -- the NEXT PLANNED operator launch on ``stream`` (fus_stiffness_apply_planned*,
+ *                  fus_mass_apply_planned_*, fus_westervelt_cell_apply_planned*) publishes the fork flag when its first
+ *                  workgroup starts, which is when everything enqueued on ``stream`` before it has completed: 2.4 us less on
+ *                  the caller's stream.  If no such launch follows (an empty cell range, a plan-free kernel) call
+ *                  fus_comm_fork_flush (the next fus_comm_fork* / fus_comm_join / fus_comm_destroy does it too).
  * fus_comm_health: failed device-side waits (time-outs + poisoned flags) of every live halo object of the communicator
  *                  and of its fork / join kernels; 0 = every exchange so far delivered.  Synchronises the communicator's streams.
  */
 int fus_comm_fork(fus_comm_t comm, void* stream);
 int fus_comm_fork_lazy(fus_comm_t comm, void* stream);
+#define FUS_FORK_LAZY 1
+#define FUS_FORK_ATTACH 2
+int fus_comm_fork_ex(fus_comm_t comm, void* stream, int flags);
+int fus_comm_fork_flush(fus_comm_t comm);
 int fus_comm_join(fus_comm_t comm, void* stream);
 int fus_comm_arm_join(fus_comm_t comm);
 int fus_comm_sync_timeouts(fus_comm_t comm, int64_t* out);

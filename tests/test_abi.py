@@ -94,8 +94,7 @@ def test_c_abi_demo_plain_cpp_host():
     import subprocess
 
     exe = os.path.join(ROOT, "examples", "c_abi_demo")
-    if not os.path.exists(exe):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)  # rebuilds if a source or the header is newer
     r = subprocess.run([exe], capture_output=True, text=True, timeout=120)
     assert r.returncode == 0 and "C_ABI_DEMO_OK" in r.stdout, r.stdout + r.stderr
 
@@ -148,8 +147,7 @@ def test_c_abi_linear_box_plain_cpp_host(tmp_path, geometry, warp):
     import fusgpu_loader
 
     exe = os.path.join(ROOT, "examples", "c_abi_linear_box")
-    if not os.path.exists(exe):
-        subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
+    subprocess.run(["make", "-C", os.path.join(ROOT, "examples")], check=True, capture_output=True)
     P, N, steps, L = 4, 6, 30, 0.12
     out = str(tmp_path / "u.bin")
     r = subprocess.run([exe, str(P), str(N), str(steps), str(geometry), str(warp), out], capture_output=True, text=True, timeout=300)

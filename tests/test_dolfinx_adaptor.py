@@ -219,3 +219,139 @@ def test_duck_typed_index_map_end_to_end_on_reference_plans(oracle_c, fixture):
     for m, y in zip(meshes, ys):
         lex = m.global_lexicographic_ids()
         assert rel_l2(y[: m.nlocal], y_ser[lex[: m.nlocal]]) < 1e-13
+
+
+# ---------------------------------------------------------------------------------------------- ArrayMesh
+def scrambled_array_mesh(P, cells, grid=(1, 1, 1), rank=0, seed=0, L=0.012, perturb=0.12, warp=None, ghost_order="owner"):
+    """A BoxMesh's rank handed over the way a dolfinx driver would: cells in random order, vertices randomly renumbered,
+    the two tagged facet sets as ``(cell, local facet)`` pairs in THAT cell numbering (tags 1 = source, 2 = absorbing, like
+    the reference's meshes) -- plain arrays only.  Returns (ArrayMesh, BoxMesh)."""
+    boxmesh, ad = pkg("boxmesh"), pkg("dolfinx_adaptor")
+    box = boxmesh.BoxMesh(P, cells, grid=grid, rank=rank, length=L, perturb=perturb, seed=5, warp=warp, ghost_order=ghost_order)
+    rng = np.random.default_rng(1000 * seed + rank)
+    cperm = rng.permutation(box.ncells)  # new cell c is box cell cperm[c]
+    inv = np.empty(box.ncells, dtype=np.int64)
+    inv[cperm] = np.arange(box.ncells)
+    vperm = rng.permutation(box.x_g.shape[0])  # new vertex v is box vertex vperm[v]
+    vinv = np.empty_like(vperm)
+    vinv[vperm] = np.arange(vperm.size)
+    tags = {}
+    for tag, face in ((1, 2), (2, 3)):
+        bd = box.boundary_facets([face])
+        tags[tag] = np.stack([inv[bd[:, 0]], bd[:, 1]], axis=1) if bd.shape[0] else np.zeros((0, 2), np.int32)
+    am = ad.ArrayMesh(P, box.dofmap[cperm], vinv[box.x_dofs[cperm]], box.x_g[vperm], index_map=box.index_map if np.prod(grid) > 1 else None,
+                      facet_tags=tags, ndofs_global=box.ndofs_global)
+    return am, box
+
+
+@pytest.mark.parametrize("grid,rank", [((1, 1, 1), 0), ((2, 1, 1), 0), ((2, 1, 1), 1), ((2, 2, 1), 3)])
+def test_array_mesh_invariants(grid, rank):
+    """ArrayMesh from scrambled plain arrays: same cells, geometry and facet dofmaps as the structured mesh it came from,
+    ghost-touching cells first, facet cells remapped with the cells."""
+    am, box = scrambled_array_mesh(3, (4, 4, 2), grid=grid, rank=rank, seed=3)
+    assert am.ncells == box.ncells and am.nlocal == box.nlocal and am.ndofs == box.ndofs
+    assert sorted(map(tuple, am.dofmap)) == sorted(map(tuple, box.dofmap))
+    nb = am.num_boundary_cells
+    assert nb == box.num_boundary_cells
+    assert (am.dofmap[:nb] >= am.nlocal).any(axis=1).all() and not (am.dofmap[nb:] >= am.nlocal).any()
+    # geometry follows the cells: the vertex coordinates of every cell are those of the box cell with the same dofs
+    key = {tuple(row): c for c, row in enumerate(box.dofmap)}
+    for c in range(am.ncells):
+        cb = key[tuple(am.dofmap[c])]
+        assert np.array_equal(am.x_g[am.x_dofs[c]], box.x_g[box.x_dofs[cb]])
+    for tag, face in ((1, 2), (2, 3)):
+        fa, fb = am.facet_dofmap(am.boundary_facets([tag])), box.facet_dofmap(box.boundary_facets([face]))
+        assert fa.shape == fb.shape and sorted(map(tuple, fa)) == sorted(map(tuple, fb))
+    assert am.boundary_facets([99]).shape == (0, 2)
+    ad = pkg("dolfinx_adaptor")
+    with pytest.raises(ValueError):
+        ad.ArrayMesh(3, am.dofmap[:, :10], am.x_dofs, am.x_g)
+    with pytest.raises(ValueError):
+        ad.ArrayMesh(3, am.dofmap, am.x_dofs, am.x_g, facet_tags={1: np.array([[am.ncells, 0]])})
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("solver", ["linear-fused", "linear-reference", "linear-in-kernel-geometry", "westervelt-fused", "westervelt-geom"])
+def test_solvers_step_an_array_mesh_one_rank(solver):
+    """the solver classes on a mesh handed over as plain arrays (randomly renumbered cells and vertices,
+    tagged facets as (cell, local facet) pairs) reproduce the structured-mesh run: owned field equal to 1e-12 (the dof
+    numbering is the same, so the fields compare entry by entry)."""
+    import torch
+
+    torch.cuda.set_device(0)
+    ls, nls = pkg("linear_solver"), pkg("nonlinear_solver")
+    P, cells, L = (3, (5, 4, 3), 0.012)
+    warp = None
+    if solver.startswith("westervelt"):
+        def warp(xg):  # noqa: E306  (the bowl of BASELINE config 5 at test size)
+            out = xg.copy()
+            y, z = xg[:, 1] / L - 0.5, xg[:, 2] / L - 0.5
+            out[:, 0] = xg[:, 0] + 0.15 * L * (y * y + z * z) * (1.0 - xg[:, 0] / L)
+            return out
+    am, box = scrambled_array_mesh(P, cells, seed=2, L=L, warp=warp)
+    c0, f0 = (1480.0, 1.1e6) if solver.startswith("westervelt") else (1500.0, 0.5e6)
+    h = ls.time_step_parameters(box, P, c0, f0, L)
+    assert abs(ls.time_step_parameters(am, P, c0, f0, L) - h) < 1e-15
+    dt, tf, _ = ls.snap_time_step(h, P, c0, f0, L)
+    out = []
+    for mesh in (box, am):
+        if solver.startswith("linear"):
+            s = ls.LinearSpectral3D(mesh, np.float64, fused=solver != "linear-reference", in_kernel_geometry=solver.endswith("geometry"))
+        else:
+            s = nls.WesterveltSpectral3D(mesh, np.float64, fused=True, in_kernel_geometry=solver.endswith("geom"))
+        s.init()
+        _, steps = s.rk4(0.0, tf, dt, max_steps=10)
+        assert steps == 10
+        out.append((s.u_sol(), s.v_sol()))
+    assert np.max(np.abs(out[0][0])) > 0
+    assert rel_l2(out[1][0], out[0][0]) < 1e-12 and rel_l2(out[1][1], out[0][1]) < 1e-12
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("transport", ["local", "peer"])
+def test_linear_solver_steps_array_meshes_two_in_process_ranks(transport):
+    """Two in-process ranks, each an ArrayMesh (scrambled cells / vertices, ghosts NOT numbered owner by owner, duck-typed
+    index map): the partitioned fused solver over the asynchronous transports == the one-rank structured solver."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, scat, utils = pkg("boxmesh"), pkg("linear_solver"), pkg("scatterer"), pkg("utils")
+    P, cells, L, grid = 3, (4, 4, 3), 0.012, (2, 1, 1)
+    pairs = [scrambled_array_mesh(P, cells, grid=grid, rank=r, seed=4, L=L, ghost_order=9) for r in range(2)]
+    meshes = [am for am, _ in pairs]
+    serial = boxmesh.BoxMesh(P, cells, length=L, perturb=0.12, seed=5)
+    h = ls.time_step_parameters(serial, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = next(_world_ids)
+    comms = [scat.NativeComm(local=(wid, 2, r), transport="peer" if transport == "peer" else "rccl") for r in range(2)]
+    solvers = [ls.LinearSpectral3D(meshes[r], np.float64, comm=comms[r], fused=True, halo_plan=(od[r], gd[r]), defer_setup_exchange=True)
+               for r in range(2)]
+
+    def lockstep(gens):
+        live = list(gens)
+        while live:
+            nxt = []
+            for g in live:
+                try:
+                    next(g)
+                    nxt.append(g)
+                except StopIteration:
+                    pass
+            live = nxt
+
+    lockstep([s._setup for s in solvers])
+    for s in solvers:
+        s.init()
+    lockstep([s.rk4_schedule(0.0, tf, dt, max_steps=8) for s in solvers])
+    torch.cuda.synchronize()
+    for s in solvers:
+        s.check_halo_health()
+    ref = ls.LinearSpectral3D(serial, np.float64, fused=True)
+    ref.init()
+    ref.rk4(0.0, tf, dt, max_steps=8)
+    u_ref = ref.u_sol()
+    assert np.max(np.abs(u_ref)) > 0
+    for (am, box), s in zip(pairs, solvers):
+        lex = box.global_lexicographic_ids()[: box.nlocal]
+        assert rel_l2(s.u_sol(), u_ref[lex]) < 1e-11
