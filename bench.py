@@ -952,6 +952,9 @@ def main():
                          "libfusgpu.so (default); native = grouped ncclSend/ncclRecv issued by libfusgpu.so; torch = "
                          "torch.distributed all_to_all_single.  A transport that does not come up on every rank or "
                          "fails the run's halo check is replaced by the next one (peer -> native -> torch)")
+    ap.add_argument("--exclusive", action="store_true",
+                    help="--mode mass: the batch plan carries exclusive-dof marks (plain load + store instead of an atomic for dofs "
+                         "one batch touches alone; opt-in, measured slower from P = 4 up: profiles/r04d_ab_mass_exclusive_marks.log)")
     ap.add_argument("--no-aux", action="store_true", help="default mode at N = 1: skip the mass and RK4-step lines of 'aux'")
     args = ap.parse_args()
 
@@ -1084,7 +1087,7 @@ def main():
         def op(x_, cc_, y_, detJ_, dm_):
             dmo(x_, y_)
     elif mass:
-        op = ops.mass_operator(n**3, dt)
+        op = ops.mass_operator(n**3, dt, exclusive=args.exclusive)
     else:
         op = ops.stiffness_operator(P, D.flatten(), dt)
 

@@ -270,16 +270,33 @@ public:
       *v = new DeviceArray<double>((size_t)ndofs);
       FUS_CHECK(fus_fill_f64(0.0, (*v)->p, ndofs, nullptr));
     }
-    // lumped mass m = M(1/(rho c^2)) 1, then 1/m (one rank: no reverse scatter)
+    // Ghost-dof exchange, where the reference's C++ driver has its scatter calls (cpp/common/Linear.hpp:120,193,196,212): a
+    // communicator of the PEER transport and one halo object per vector exchanged.  This host runs ONE rank, whose halo plan
+    // has no neighbours -- the calls are then no-ops inside the library -- but the loop has the N-rank shape: an N-rank host
+    // passes fus_comm_create_peer(nranks, rank), the (owners_data, ghosts_data) of cuda/utils.py:8-78 to fus_halo_create and
+    // all-gathers the blobs of fus_halo_ipc_export with MPI.
+    FUS_CHECK(fus_comm_create_peer(1, 0, &comm));
+    for (fus_halo_t* h : {&halo_u, &halo_v, &halo_b}) {
+      FUS_CHECK(fus_halo_create(comm, 8, ndofs, 0, 0, nullptr, nullptr, nullptr, 0, nullptr, nullptr, nullptr, h));
+      std::vector<char> blob((size_t)fus_halo_ipc_blob_bytes(*h));
+      FUS_CHECK(fus_halo_ipc_export(*h, blob.data()));
+      const void* blobs[1] = {blob.data()};
+      FUS_CHECK(fus_halo_ipc_connect(*h, 1, blobs));
+    }
+    // lumped mass m = M(1/(rho c^2)) 1, reverse-scattered, then 1/m (cpp/common/Linear.hpp:113-121)
     DeviceArray<double> ones((size_t)ndofs), m((size_t)ndofs);
     FUS_CHECK(fus_fill_f64(1.0, ones.p, ndofs, nullptr));
     FUS_CHECK(fus_fill_f64(0.0, m.p, ndofs, nullptr));
     FUS_CHECK(fus_mass_apply_f64(ones.p, d_cell_coeff1.p, m.p, d_detJ.p, d_dofmap->p, Nd, ncell, nullptr));
+    FUS_CHECK(fus_halo_reverse(halo_b, m.p, nullptr));
     FUS_CHECK(fus_pointwise_divide_f64(ones.p, m.p, d_minv->p, ndofs, nullptr));
     HIP_OK(hipDeviceSynchronize());
   }
 
   ~LinearSpectral3D() {
+    for (fus_halo_t h : {halo_u, halo_v, halo_b})
+      if (h) fus_halo_destroy(h);  // before their communicator
+    if (comm) fus_comm_destroy(comm);
     if (d_plan) fus_plan_release(d_plan->p);
     delete d_plan;
     for (auto* a : {d_dofmap, d_xdofs, d_fdm1, d_fdm2}) delete a;
@@ -310,8 +327,11 @@ public:
     final_time = L / c0 + 2.0 / freq;
   }
 
-  /// b += K(-1/rho) u_n + M_f1(g / rho) 1 + M_f2(-1/(rho c)) v_n
-  void apply_operator(double tn, const double* u_n, const double* v_n) {
+  /// b += K(-1/rho) u_n + M_f1(g / rho) 1 + M_f2(-1/(rho c)) v_n, between the forward scatters of (u_n, v_n) and the reverse
+  /// scatter of b (cpp/common/Linear.hpp:193-212; cuda/demo_linear_box.py:537-553)
+  void apply_operator(double tn, double* u_n, double* v_n) {
+    FUS_CHECK(fus_halo_forward(halo_u, u_n, nullptr));
+    FUS_CHECK(fus_halo_forward(halo_v, v_n, nullptr));
     switch (geometry) {
       case 0:
         FUS_CHECK(fus_stiffness_apply_planned_affine_f64(u_n, d_cell_coeff2->p, d_b->p, d_G->p, d_wratio->p, d_plan->p, d_D->p, P,
@@ -326,6 +346,7 @@ public:
     }
     FUS_CHECK(fus_facet_terms_f64(d_b->p, d_facet_coeff1->p, source_value(tn), nullptr, 0.0, d_detJ_f1->p, d_fdm1->p, nf1, v_n,
                                   d_facet_coeff2->p, d_detJ_f2->p, d_fdm2->p, nf2, n * n, nullptr));
+    FUS_CHECK(fus_halo_reverse(halo_b, d_b->p, nullptr));
   }
 
   /// Runge-Kutta 4 (cpp/common/Linear.hpp:241-348); returns the number of steps taken
@@ -356,6 +377,12 @@ public:
     FUS_CHECK(fus_copy_f64(d_u0->p, d_u->p, ndofs, nullptr));
     FUS_CHECK(fus_copy_f64(d_v0->p, d_v->p, ndofs, nullptr));
     HIP_OK(hipDeviceSynchronize());
+    // Every device-side wait of the exchange is bounded, so a late or dead neighbour cannot hang this rank; it must not let
+    // the loop hand back a field computed from stale ghosts either (MPI would have blocked): a failed exchange is an error.
+    int64_t failed = 0;
+    FUS_CHECK(fus_comm_health(comm, &failed));
+    if (failed != 0)
+      throw std::runtime_error(std::to_string(failed) + " device-side wait(s) of the halo exchange failed: the pressure field is INVALID");
     return step;
   }
 
@@ -374,6 +401,8 @@ private:
   DeviceArray<double>*d_u = nullptr, *d_v = nullptr, *d_u0 = nullptr, *d_v0 = nullptr, *d_un = nullptr, *d_ku = nullptr;
   DeviceArray<double>*d_b = nullptr, *d_minv = nullptr;
   DeviceArray<unsigned char>* d_plan = nullptr;
+  fus_comm_t comm = nullptr;
+  fus_halo_t halo_u = nullptr, halo_v = nullptr, halo_b = nullptr;
 };
 
 int main(int argc, char** argv) {

@@ -35,6 +35,7 @@ def _signatures():
         "fus_plan_build": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_plan_build_ordered": [_vp, _vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_plan_release": [_vp],
+        "fus_plan_mark_exclusive": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_stiffness_plan_build": [_vp, _int, _i64, _vp, _i64, _vp],
         # communicator + halo exchange (csrc/halo_comm.hpp)
         "fus_comm_unique_id": [_vp],

@@ -55,22 +55,24 @@ struct PlanInfo {
   int N = 0, epb = 0;
   int64_t nent = 0;
   bool ordered = false;
+  bool exclusive = false;  // fus_plan_mark_exclusive has run: the plan carries exclusive-dof marks
 };
 std::mutex g_plans_mu;
 std::unordered_map<const void*, PlanInfo> g_plans;
 
 void plan_register(const void* ws, int N, int epb, int64_t nent, bool ordered) {
   std::lock_guard<std::mutex> lk(g_plans_mu);
-  g_plans[ws] = PlanInfo{N, epb, nent, ordered};
+  g_plans[ws] = PlanInfo{N, epb, nent, ordered, false};
 }
 // true if ``ws`` holds a plan for exactly this shape; ``ordered`` out
-bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered) {
+bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, bool* exclusive = nullptr) {
   std::lock_guard<std::mutex> lk(g_plans_mu);
   auto it = g_plans.find(ws);
   if (it == g_plans.end()) return false;
   const PlanInfo& p = it->second;
   if (p.N != N || p.epb != epb || p.nent != nent) return false;
   *ordered = p.ordered;
+  if (exclusive) *exclusive = p.exclusive;
   return true;
 }
 
@@ -332,9 +334,9 @@ int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const v
   if (nent < 0 || N < 2 || epb < 1 || (int64_t)N * epb > fus::kPlanMaxEntries) return FUS_ERR_INVALID_ARGUMENT;
   if (nent == 0) return FUS_OK;
   if (!x || !consts || !y || !detJ || !ws || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, N, epb, nent, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>(N)));
+  bool ord = false, excl = false;
+  if (!plan_check(ws, N, epb, nent, &ord, &excl)) return FUS_ERR_PLAN_MISMATCH;
+  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>(N), excl));
 }
 
 }  // namespace
@@ -470,6 +472,19 @@ int fus_plan_build_ordered(const int32_t* dofmap, const int32_t* entity_order, i
     if (e != hipSuccess) return hip_rc(e);
   }
   plan_register(workspace, N, entities_per_batch, nent, entity_order != nullptr);
+  return FUS_OK;
+}
+
+int fus_plan_mark_exclusive(void* workspace, int N, int entities_per_batch, int64_t nent, int32_t* dof_use_count,
+                            int64_t ndofs, void* stream) {
+  if (!workspace || !dof_use_count || ndofs < 0) return FUS_ERR_INVALID_ARGUMENT;
+  bool ord = false;
+  if (!plan_check(workspace, N, entities_per_batch, nent, &ord)) return FUS_ERR_PLAN_MISMATCH;
+  const hipError_t e = fus::launch_plan_mark_exclusive(workspace, N, entities_per_batch, nent, dof_use_count, ndofs,
+                                                       static_cast<hipStream_t>(stream));
+  if (e != hipSuccess) return hip_rc(e);
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  g_plans[workspace].exclusive = true;
   return FUS_OK;
 }
 

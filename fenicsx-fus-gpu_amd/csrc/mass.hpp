@@ -97,12 +97,15 @@ inline hipError_t launch_facet_terms(T* y, const T* cA1, T sA1, const T* cA2, T 
 // entity, epb entities per batch).  Per batch: gather x once per distinct dof into LDS, every
 // (entity, local dof) entry multiplies and pre-reduces into LDS, one global atomic per distinct
 // dof with consecutive lanes on ascending addresses.  EPT = entries per thread (upper bound).
-template <typename T, int EPT>
+// EXCL: the plan carries exclusive-dof marks (plan.hpp): a marked dof is touched by this workgroup alone, so its sum is
+// finished with a plain load (issued with the x gather) + store instead of a memory-side atomic.
+template <typename T, int EPT, bool EXCL>
 __global__ void __launch_bounds__(256)
     mass_plan_kernel(const T* __restrict__ x, const T* __restrict__ entity_constants, T* __restrict__ y,
                      const T* __restrict__ detJ, const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
                      const uint16_t* __restrict__ slot, int N, int epb, int64_t nent, uint32_t inv_n,
-                     const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig) {
+                     const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig,
+                     const uint32_t* __restrict__ excl, int excl_words) {
   extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
   launch_signal_publish(sig);
   const int M = N * epb;
@@ -141,6 +144,17 @@ __global__ void __launch_bounds__(256)
   T xv[EPT];
 #pragma unroll
   for (int r = 0; r < EPT; ++r) xv[r] = x[mydof[r]];
+  [[maybe_unused]] T yv[EXCL ? EPT : 1];
+  [[maybe_unused]] bool mine[EXCL ? EPT : 1];
+  if constexpr (EXCL) {
+    const uint32_t* ex = excl + batch * (int64_t)excl_words;
+#pragma unroll
+    for (int r = 0; r < EPT; ++r) {
+      const int s = tid + r * 256;
+      mine[r] = s < nu_b && ((ex[s >> 5] >> (s & 31)) & 1u);
+      yv[r] = mine[r] ? y[mydof[r]] : T(0);
+    }
+  }
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int s = tid + r * 256;
@@ -159,13 +173,23 @@ __global__ void __launch_bounds__(256)
 #pragma unroll
   for (int r = 0; r < EPT; ++r) {
     const int s = tid + r * 256;
-    if (s < nu_b) unsafeAtomicAdd(y + mydof[r], (T)sy[s]);
+    if (s < nu_b) {
+      if constexpr (EXCL) {
+        if (mine[r])
+          y[mydof[r]] = yv[r] + (T)sy[s];
+        else
+          unsafeAtomicAdd(y + mydof[r], (T)sy[s]);
+      } else {
+        unsafeAtomicAdd(y + mydof[r], (T)sy[s]);
+      }
+    }
   }
 }
 
 template <typename T>
 inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* detJ, const void* workspace, int N,
-                                   int epb, int64_t nent, hipStream_t stream, bool ordered = false, bool use_runs = false) {
+                                   int epb, int64_t nent, hipStream_t stream, bool ordered = false, bool use_runs = false,
+                                   bool exclusive = false) {
   if (nent <= 0) return hipSuccess;
   const int M = N * epb;
   if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
@@ -174,9 +198,14 @@ inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* d
   const size_t lds = (size_t)M * (sizeof(PlanAcc) + sizeof(T));
   const dim3 grid((unsigned)v.nbatch), block(256);
   const LaunchSignal sig = take_launch_signal(stream);
-#define FUS_MASS_LAUNCH(E)                                                                                        \
-  hipLaunchKernelGGL((mass_plan_kernel<T, E>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \
-                     N, epb, nent, inv_n, ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig)
+#define FUS_MASS_LAUNCH(E)                                                                                               \
+  if (exclusive)                                                                                                         \
+    hipLaunchKernelGGL((mass_plan_kernel<T, E, true>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \
+                       N, epb, nent, inv_n, ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig, v.excl,      \
+                       (int)v.excl_words);                                                                               \
+  else                                                                                                                   \
+    hipLaunchKernelGGL((mass_plan_kernel<T, E, false>), grid, block, lds, stream, x, consts, y, detJ, v.nu, v.udofs, v.slot, \
+                       N, epb, nent, inv_n, ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig, nullptr, 0)
   const int ept = (M + 255) / 256;
   if (ept <= 1) FUS_MASS_LAUNCH(1);
   else if (ept <= 2) FUS_MASS_LAUNCH(2);

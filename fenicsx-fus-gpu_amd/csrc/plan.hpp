@@ -27,6 +27,11 @@
 //   order  int32 [nent]             optional cell order: batch b holds the entities order[b*CPB ..]
 //                                   (set-up-time locality reordering WITHOUT moving G / detJ / constants:
 //                                   the apply kernels index those arrays through it); unused otherwise
+//   excl   uint32[nbatch][ceil(CPB*Nd/32)]  optional (fus_plan_mark_exclusive): bit s of batch b = the batch's distinct
+//                                   dof number s is touched by NO other batch of this plan (and by nothing else the caller
+//                                   declared): its partial sum is finished with a plain load + store instead of an atomic --
+//                                   the float-atomic request rate of the chip (~20 G 64-byte requests/s), not HBM, bounds
+//                                   the low-intensity kernels (mass: 92 % of that rate, profiles/r03_mass_counters.json)
 // Nd = (P+1)^3; the last batch may be ragged (cells >= ncell are never touched).
 #pragma once
 
@@ -132,6 +137,8 @@ struct PlanView {
   int32_t* runs;
   uint16_t* slot;
   int32_t* order;
+  uint32_t* excl;
+  int64_t excl_words;  // per batch
   int64_t bytes;
 };
 
@@ -152,6 +159,9 @@ inline PlanView plan_view_generic(void* workspace, int N, int epb, int64_t nent)
   off += align256(v.nbatch * v.entries * (int64_t)sizeof(uint16_t));
   v.order = reinterpret_cast<int32_t*>(base + off);
   off += align256(nent * (int64_t)sizeof(int32_t));
+  v.excl = reinterpret_cast<uint32_t*>(base + off);
+  v.excl_words = (v.entries + 31) / 32;
+  off += align256(v.nbatch * v.excl_words * (int64_t)sizeof(uint32_t));
   v.bytes = off;
   return v;
 }
@@ -318,6 +328,51 @@ inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* 
                                     int allow_runs = 1) {
   constexpr int n = P + 1;
   return launch_plan_build_generic(dofmap, n * n * n, plan_cells_per_batch<P>(), ncell, workspace, stream, allow_runs);
+}
+
+// ---- exclusive-dof marks (optional second pass over a built plan) ------------------------------------------------------
+// use[dof] += 1 for every (batch, distinct dof) of the plan.  ``use`` comes in holding what ELSE touches each dof (0 for a
+// launch that runs alone): dofs with use == 1 afterwards belong to exactly one batch and to nothing else.
+__global__ void __launch_bounds__(256)
+    plan_count_uses_kernel(const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs, int64_t entries, int32_t* use,
+                           int64_t ndofs) {
+  const int64_t batch = blockIdx.x;
+  const int nu_b = nu[batch] & 0xffff;
+  const int32_t* ud = udofs + batch * entries;
+  for (int s = threadIdx.x; s < nu_b; s += 256) {
+    const int32_t d = ud[s];
+    if (d >= 0 && d < ndofs) atomicAdd(&use[d], 1);
+  }
+}
+__global__ void __launch_bounds__(256)
+    plan_mark_exclusive_kernel(const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs, int64_t entries,
+                               const int32_t* __restrict__ use, int64_t ndofs, uint32_t* __restrict__ excl, int64_t words) {
+  const int64_t batch = blockIdx.x;
+  const int nu_b = nu[batch] & 0xffff;
+  const int32_t* ud = udofs + batch * entries;
+  uint32_t* ex = excl + batch * words;
+  for (int64_t w = threadIdx.x; w < words; w += 256) {
+    uint32_t bits = 0;
+    for (int b = 0; b < 32; ++b) {
+      const int64_t s = w * 32 + b;
+      if (s < nu_b) {
+        const int32_t d = ud[s];
+        if (d >= 0 && d < ndofs && use[d] == 1) bits |= 1u << b;
+      }
+    }
+    ex[w] = bits;
+  }
+}
+inline hipError_t launch_plan_mark_exclusive(void* workspace, int N, int epb, int64_t nent, int32_t* use, int64_t ndofs,
+                                             hipStream_t stream) {
+  if (nent <= 0) return hipSuccess;
+  PlanView v = plan_view_generic(workspace, N, epb, nent);
+  hipLaunchKernelGGL(plan_count_uses_kernel, dim3((unsigned)v.nbatch), dim3(256), 0, stream, v.nu, v.udofs, v.entries, use, ndofs);
+  hipError_t e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(plan_mark_exclusive_kernel, dim3((unsigned)v.nbatch), dim3(256), 0, stream, v.nu, v.udofs, v.entries, use, ndofs,
+                     v.excl, v.excl_words);
+  return hipGetLastError();
 }
 
 // Distinct dofs owned by this thread (slots tid, tid + BLOCK, ...), for both plan encodings.

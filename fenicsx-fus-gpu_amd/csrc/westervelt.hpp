@@ -283,6 +283,17 @@ __global__ void __launch_bounds__(256)
 // ``w`` (optional): the combined stiffness input of the NEXT cell pass, w = u_n' + kappa v_n', for media where
 // c4 = kappa c3 in every cell (then K(c3) u + K(c4) v = K(c3)(u + kappa v): one plain stiffness apply, one
 // gather, one forward halo exchange less); for kind LAST it is formed from the new (u0, v0).
+// non-temporal accesses for the arrays the vector pass only streams (everything but the next cell pass's inputs un / ku / w
+// and b): nothing of them is read again before ~1 GB of other data has gone through the caches (rk4.hpp)
+template <typename T>
+__device__ __forceinline__ T nt_ld(const T* p) {
+  return __builtin_nontemporal_load(p);
+}
+template <typename T>
+__device__ __forceinline__ void nt_st(T* p, T v) {
+  __builtin_nontemporal_store(v, p);
+}
+
 template <typename T>
 __global__ void __launch_bounds__(256)
     rk4_stage_nl2_kernel(T bw, T aw, int kind, const T* __restrict__ m0, const T* __restrict__ w2,
@@ -294,36 +305,36 @@ __global__ void __launch_bounds__(256)
     if (i < nlocal) {
       T un_new, vn_new;
       if (kind == 2) {  // FIRST: stage inputs are (u0, v0); u == u0, v == v0, ku == v0
-        const T u0i = u0[i], v0i = v0[i];
-        const T kv = (b[i] + w5[i] * v0i * v0i) / (m0[i] + w2[i] * u0i);
-        u[i] = u0i + bw * v0i;
-        v[i] = v0i + bw * kv;
+        const T u0i = nt_ld(u0 + i), v0i = nt_ld(v0 + i);
+        const T kv = (b[i] + nt_ld(w5 + i) * v0i * v0i) / (nt_ld(m0 + i) + nt_ld(w2 + i) * u0i);
+        nt_st(u + i, u0i + bw * v0i);
+        nt_st(v + i, v0i + bw * kv);
         un_new = u0i + aw * v0i;
         vn_new = v0i + aw * kv;
         un[i] = un_new;
         ku[i] = vn_new;
       } else {
         const T uni = un[i], kui = ku[i];
-        const T kv = (b[i] + w5[i] * kui * kui) / (m0[i] + w2[i] * uni);
+        const T kv = (b[i] + nt_ld(w5 + i) * kui * kui) / (nt_ld(m0 + i) + nt_ld(w2 + i) * uni);
         if (kind == 3) {  // LAST: the next stage's inputs are the new (u0, v0)
-          un_new = u[i] + bw * kui;
-          vn_new = v[i] + bw * kv;
-          u0[i] = un_new;
-          v0[i] = vn_new;
+          un_new = nt_ld(u + i) + bw * kui;
+          vn_new = nt_ld(v + i) + bw * kv;
+          nt_st(u0 + i, un_new);
+          nt_st(v0 + i, vn_new);
         } else {
-          const T ui = u[i] + bw * kui;
-          const T vi = v[i] + bw * kv;
-          u[i] = ui;
-          v[i] = vi;
+          const T ui = nt_ld(u + i) + bw * kui;
+          const T vi = nt_ld(v + i) + bw * kv;
+          nt_st(u + i, ui);
+          nt_st(v + i, vi);
           T u0i, v0i;
           if (kind == 1) {
             u0i = ui;
             v0i = vi;
-            u0[i] = ui;
-            v0[i] = vi;
+            nt_st(u0 + i, ui);
+            nt_st(v0 + i, vi);
           } else {
-            u0i = u0[i];
-            v0i = v0[i];
+            u0i = nt_ld(u0 + i);
+            v0i = nt_ld(v0 + i);
           }
           un_new = u0i + aw * kui;
           vn_new = v0i + aw * kv;

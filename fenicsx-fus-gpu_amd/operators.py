@@ -78,11 +78,16 @@ class _PlanCache:
         held, self._recording = self._recording or [], None
         return held
 
-    def get(self, dofmap: torch.Tensor):
-        """-> (workspace tensor, entities_per_batch)"""
+    def get(self, dofmap: torch.Tensor, exclusive_ndofs=None, external_use=None):
+        """-> (workspace tensor, entities_per_batch).  ``exclusive_ndofs`` (length of the vectors the plan is applied to):
+        the plan also carries EXCLUSIVE-DOF MARKS (``fus_plan_mark_exclusive``: a dof touched by exactly one batch is finished
+        with a plain load + store instead of a float atomic), a separate cache entry from the unmarked plan of the same
+        dofmap.  ``external_use``: device int32[ndofs], what else adds into each dof while a launch with this plan runs
+        (default: nothing -- the launch runs alone or only next to launches of the same stream)."""
         lib = _lib.load()
         nent, N = dofmap.shape
-        key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index)
+        key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index,
+               None if exclusive_ndofs is None else (int(exclusive_ndofs), None if external_use is None else (external_use.data_ptr(), external_use._version)))
         hit = self._plans.get(key)
         if hit is None:
             epb = lib.fus_plan_entities_per_batch(N)
@@ -115,6 +120,14 @@ class _PlanCache:
                     if distinct_dofs(ws2) < 0.97 * distinct_dofs(ws):
                         ws, ws2, self.last_order = ws2, ws, order
                     lib.fus_plan_release(ws2.data_ptr())  # the plan that was not kept
+            if exclusive_ndofs is not None:
+                use = (external_use.to(torch.int32).clone() if external_use is not None
+                       else torch.zeros(int(exclusive_ndofs), dtype=torch.int32, device=dofmap.device))
+                if use.numel() != int(exclusive_ndofs):
+                    raise ValueError("external_use must have one entry per dof")
+                _lib.check(lib.fus_plan_mark_exclusive(ws.data_ptr(), N, epb, nent, use.data_ptr(), int(exclusive_ndofs), _lib.stream_ptr()),
+                           "fus_plan_mark_exclusive")
+                del use  # a temporary: the caching allocator hands its memory out again in stream order
             if len(self._plans) >= self.capacity:  # bounded: drop the oldest plan
                 old = self._plans.pop(next(iter(self._plans)))
                 lib.fus_plan_release(old[0].data_ptr())
@@ -145,7 +158,7 @@ class _Launchable:
 
 
 # --------------------------------------------------------------------------- mass
-def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None):
+def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, exclusive=False):
     lib = _lib.load()
     dt = x.dtype if isinstance(x, torch.Tensor) else None
     _req(x, dt, "x")
@@ -163,7 +176,7 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None):
     if nent == 0:
         return
     if _USE_PLAN and 2 <= n_per <= 4096 and nent * n_per >= _MASS_PLAN_MIN_ENTRIES:  # plan batches hold <= 4096 entries
-        ws, epb = _PLANS.get(entity_dofmap)
+        ws, epb = _PLANS.get(entity_dofmap, exclusive_ndofs=y.numel() if exclusive else None)
         fn = getattr(lib, f"fus_mass_apply_planned_{_lib.suffix(dt)}")
         _lib.check(
             fn(x.data_ptr(), entity_constants.data_ptr(), y.data_ptr(), entity_detJ.data_ptr(), ws.data_ptr(),
@@ -180,14 +193,21 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None):
 
 
 class _MassOperator(_Launchable):
-    def __call__(self, N: int, float_type):
+    def __call__(self, N: int, float_type, exclusive=False):
+        """``mass_operator(N, float_type)`` -> ``operator(x, entity_constants, y, entity_detJ, entity_dofmap)``
+        (numba-cpu/operators.py:19-68).  ``exclusive=True`` (keyword, no reference counterpart): the batch plan carries
+        exclusive-dof marks -- a dof that exactly one batch of entities touches is finished with a plain load + store
+        instead of a float atomic (the apply is bound by the chip's float-atomic request rate).  The caller
+        guarantees that NOTHING ELSE adds into ``y`` while the launch runs (launches on the same stream are fine; another
+        stream's launch or a halo receive adding into the same ``y`` concurrently is not): the drivers use it for the
+        stand-alone applies of set-up (lumped mass, diagonals), not inside the overlapped stage."""
         tdt = _lib.torch_dtype(float_type)
         N = int(N)
 
         def operator(x, entity_constants, y, entity_detJ, entity_dofmap):
             if isinstance(x, torch.Tensor) and x.dtype != tdt:
                 raise TypeError(f"x: expected dtype {tdt}, got {x.dtype}")
-            _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N)
+            _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N, exclusive=exclusive)
 
         return operator
 

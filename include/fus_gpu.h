@@ -200,6 +200,19 @@ int fus_plan_build(const int32_t* entity_dofmap, int ndof_per_entity, int entiti
 int fus_plan_build_ordered(const int32_t* entity_dofmap, const int32_t* entity_order, int ndof_per_entity,
                            int entities_per_batch, int64_t nent, void* workspace, int64_t workspace_bytes,
                            void* stream);
+/*
+ * Optional second pass over a BUILT plan: mark the dofs that exactly one batch of the plan touches.  The planned mass apply
+ * then finishes the sums of marked dofs with a plain load + store instead of a memory-side float atomic (the low-intensity
+ * kernels are bound by the chip's float-atomic request rate, not by HBM: csrc/plan.hpp).
+ *   dof_use_count  device int32[ndofs]; on entry what ELSE adds into each dof while a launch with this plan runs (0
+ *                  everywhere for a launch that runs alone; >= 1 for dofs that another launch on another stream, or a
+ *                  halo receive, adds into concurrently); on exit increased by this plan's (batch, dof) incidences.
+ * A dof is marked iff its count is exactly 1 afterwards.  THE CALLER GUARANTEES that, while a launch with a marked plan
+ * runs, nothing he did not declare adds into the marked dofs of y (consecutive launches on ONE stream are always fine).
+ * No reference counterpart (its kernels issue one atomic per (entity, dof), cuda/operators.py:66-70).
+ */
+int fus_plan_mark_exclusive(void* workspace, int ndof_per_entity, int entities_per_batch, int64_t nent,
+                            int32_t* dof_use_count, int64_t ndofs, void* stream);
 /* Forget a workspace (before freeing it): drops its entry of the registry the planned applies check. */
 int fus_plan_release(const void* workspace);
 int fus_mass_apply_planned_f64(const double* x, const double* entity_constants, double* y, const double* entity_detJ,

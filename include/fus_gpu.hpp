@@ -83,6 +83,28 @@ struct Abi<float> {
   }
 };
 
+// a device allocation owned by a functor: released when the functor's constructor throws after it, too (a member that is
+// fully constructed is destroyed then; a raw pointer freed by the class's own destructor is not).  The stream the geometry
+// kernel was enqueued on is drained first: the kernel may still be writing the buffer.
+template <typename T>
+struct DeviceBuffer {
+  T* p = nullptr;
+  hipStream_t stream = nullptr;
+  DeviceBuffer() = default;
+  DeviceBuffer(const DeviceBuffer&) = delete;
+  DeviceBuffer& operator=(const DeviceBuffer&) = delete;
+  void allocate(size_t count, hipStream_t s, const char* what) {
+    stream = s;
+    check_hip(hipMalloc(&p, sizeof(T) * count), what);
+  }
+  ~DeviceBuffer() {
+    if (p) {
+      (void)hipStreamSynchronize(stream);
+      (void)hipFree(p);
+    }
+  }
+};
+
 // the batch plan of a dofmap (device workspace owned by the functor; registered with the library at this address)
 struct Plan {
   void* ws = nullptr;
@@ -120,11 +142,11 @@ public:
   static constexpr int Nd = (P + 1) * (P + 1) * (P + 1);
   /// dofmap: device int32[ncells][(P+1)^3], tensor-product local order; the scaled Jacobian determinant is computed here
   MassSpectral3D(const int32_t* dofmap, int64_t ncells, const Geometry<T>& geo, hipStream_t stream = nullptr) : Nc(ncells) {
-    check_abi();
-    check_hip(hipMalloc(&detJ_own_, sizeof(T) * (size_t)Nc * Nd), "hipMalloc(detJ)");
-    check(detail::Abi<T>::geometry(geo.x_g, geo.x_dofs, geo.dphi_p1, geo.weights, Nd, Nc, nullptr, detJ_own_, stream),
+    check_abi();  // before anything is allocated
+    detJ_own_.allocate((size_t)Nc * Nd, stream, "hipMalloc(detJ)");
+    check(detail::Abi<T>::geometry(geo.x_g, geo.x_dofs, geo.dphi_p1, geo.weights, Nd, Nc, nullptr, detJ_own_.p, stream),
           "fus_geometry_factors (detJ)");
-    detJ_ = detJ_own_;
+    detJ_ = detJ_own_.p;
     plan_.build(dofmap, Nd, Nc, stream);
   }
   /// with the factors the caller already has (device T[ncells][(P+1)^3])
@@ -134,9 +156,6 @@ public:
   }
   MassSpectral3D(const MassSpectral3D&) = delete;
   MassSpectral3D& operator=(const MassSpectral3D&) = delete;
-  ~MassSpectral3D() {
-    if (detJ_own_) (void)hipFree(detJ_own_);
-  }
   /// y += M x   (x, y: device vectors of nlocal + nghost entries; coeffs: device T[ncells])
   void operator()(const T* x, const T* coeffs, T* y, hipStream_t stream = nullptr) const {
     check(detail::Abi<T>::mass(x, coeffs, y, detJ_, plan_.ws, Nd, plan_.epb, Nc, stream), "fus_mass_apply_planned");
@@ -146,7 +165,7 @@ public:
 private:
   int64_t Nc;
   const T* detJ_ = nullptr;
-  T* detJ_own_ = nullptr;
+  detail::DeviceBuffer<T> detJ_own_;  // members are released in reverse order, also when the constructor throws
   detail::Plan plan_;
 };
 
@@ -161,11 +180,11 @@ public:
   /// dphi: device T[(P+1)][(P+1)] 1-D GLL derivative table [q][i]; G is computed here (device twin of precompute.hpp:101-213)
   StiffnessSpectral3D(const int32_t* dofmap, int64_t ncells, const Geometry<T>& geo, const T* dphi, hipStream_t stream = nullptr)
       : Nc(ncells), dphi_(dphi) {
-    check_abi();
-    check_hip(hipMalloc(&G_own_, sizeof(T) * (size_t)Nc * Nd * 6), "hipMalloc(G)");
-    check(detail::Abi<T>::geometry(geo.x_g, geo.x_dofs, geo.dphi_p1, geo.weights, Nd, Nc, G_own_, nullptr, stream),
+    check_abi();  // before anything is allocated
+    G_own_.allocate((size_t)Nc * Nd * 6, stream, "hipMalloc(G)");
+    check(detail::Abi<T>::geometry(geo.x_g, geo.x_dofs, geo.dphi_p1, geo.weights, Nd, Nc, G_own_.p, nullptr, stream),
           "fus_geometry_factors (G)");
-    G_ = G_own_;
+    G_ = G_own_.p;
     plan_.build(dofmap, Nd, Nc, stream);
   }
   /// with the factors the caller already has (device T[ncells][(P+1)^3][6])
@@ -176,9 +195,6 @@ public:
   }
   StiffnessSpectral3D(const StiffnessSpectral3D&) = delete;
   StiffnessSpectral3D& operator=(const StiffnessSpectral3D&) = delete;
-  ~StiffnessSpectral3D() {
-    if (G_own_) (void)hipFree(G_own_);
-  }
   /// y += K x
   void operator()(const T* x, const T* coeffs, T* y, hipStream_t stream = nullptr) const {
     check(detail::Abi<T>::stiffness(x, coeffs, y, G_, plan_.ws, dphi_, P, Nc, stream), "fus_stiffness_apply_planned");
@@ -188,7 +204,7 @@ public:
 private:
   int64_t Nc;
   const T* G_ = nullptr;
-  T* G_own_ = nullptr;
+  detail::DeviceBuffer<T> G_own_;
   const T* dphi_ = nullptr;
   detail::Plan plan_;
 };

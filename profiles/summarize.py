@@ -105,6 +105,50 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
             "kernel_src_sha": bench_py.kernel_src_sha(("plan.hpp", "mass.hpp")),
             "atomic_requests_per_launch": counters.get("TCC_EA0_ATOMIC_sum", {}).get("mean_per_launch")}
         json.dump(latest, open(latest_path, "w"), indent=1)
+for a_ in sys.argv[3:]:
+    # --aux=rk4_step / --aux=rk4_step_in_kernel_geometry: HBM bytes of one fused RK4 step = sum over the step's kernels of
+    # (mean per-launch bytes) x (launches per step: 4 of each), from the FETCH_SIZE / WRITE_SIZE passes of a --mode rk4 run
+    if a_.startswith("--aux=rk4_step"):
+        key = a_[6:]
+        per = {}
+        for sub, name in (("pmc_fetch", "fetch"), ("pmc_write", "write")):
+            pth = os.path.join(src, sub, f"{name}_counter_collection.csv")
+            for r in csv.DictReader(open(pth)):
+                for kn in ("stiffness_plan_geom_kernel", "stiffness_plan_kernel", "facet_terms_kernel", "rk4_stage_kernel"):
+                    if kn + "<" in r["Kernel_Name"] or r["Kernel_Name"].split("(")[0].endswith(kn):
+                        per.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
+                        break
+        breakdown, total = {}, 0.0
+        for kn, c in per.items():
+            if "FETCH_SIZE" in c and "WRITE_SIZE" in c:
+                b = (2 * sum(c["FETCH_SIZE"]) / len(c["FETCH_SIZE"]) + sum(c["WRITE_SIZE"]) / len(c["WRITE_SIZE"])) * 1024
+                breakdown[kn] = {"hbm_bytes_per_launch": b, "launches_profiled": len(c["FETCH_SIZE"])}
+                total += 4 * b
+        sys.path.insert(0, ROOT)
+        import bench as bench_py
+
+        geo = "geometry" in key
+        files = ("plan.hpp", "stiffness.hpp", "stiffness_plan.hpp") + (("stiffness_geom.hpp",) if geo else ()) + ("mass.hpp", "rk4.hpp")
+        latest_path = os.path.join(out, "traffic_latest.json")
+        latest = json.load(open(latest_path))
+        latest.setdefault("aux", {})[key] = {
+            "P": bench["config"]["degree"], "ncell": bench["config"].get("cells_per_gpu"), "dtype": bench.get("dtype", "f64"),
+            "hbm_bytes_per_step": total, "breakdown": {k: round(v["hbm_bytes_per_launch"]) for k, v in breakdown.items()},
+            "source": f"profiles/{_tag_for_files}_counters.json", "lib_sha": res["lib_sha"], "kernel_src_files": list(files),
+            "kernel_src_sha": bench_py.kernel_src_sha(files)}
+        json.dump(latest, open(latest_path, "w"), indent=1)
+        res["rk4_step"] = {"hbm_bytes_per_step": total, "breakdown": breakdown,
+                           "algorithmic_bytes_per_step": (bench.get("roofline") or {}).get("algorithmic_bytes_per_step")}
+# the K dispatches of the timed region, in order (is the first launch after the synchronise slower than the steady state?)
+if os.path.exists(tr):
+    seq = sorted((int(r["Start_Timestamp"]), int(r["End_Timestamp"])) for r in csv.DictReader(open(tr)) if kernel_key in r["Kernel_Name"])
+    K = int(bench.get("steps") or 0)
+    W = int(bench.get("warmup") or 0)
+    if K and len(seq) >= W + K:
+        region = seq[W:W + K]
+        res["timed_region_dispatches"] = {"duration_us": [round((e - b) / 1e3, 1) for b, e in region],
+                                          "start_to_start_us": [round((region[i + 1][0] - region[i][0]) / 1e3, 1) for i in range(K - 1)],
+                                          "span_us_per_launch": (region[-1][1] - region[0][0]) / 1e3 / K}
 if "TCC_EA0_ATOMIC_sum" in counters and stats:
     res["atomic_requests_per_s"] = counters["TCC_EA0_ATOMIC_sum"]["mean_per_launch"] / (stats["avg_ns"] * 1e-9)
 if "SQ_LDS_BANK_CONFLICT" in counters and "SQ_LDS_IDX_ACTIVE" in counters:

@@ -910,3 +910,58 @@ def test_maximum_size_beyond_32bit_offsets(gpu, oracle_c):
     opg(x, cc, y_g, None, dm)
     assert float((y_g - y_full).norm()) < 1e-11 * nrm
     ops._PLANS.clear()
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P,cells", [(4, 12), (2, 20), (6, (6, 5, 4))], ids=["P4", "P2", "P6"])
+def test_mass_exclusive_dof_marks(gpu, oracle_c, P, cells, dtype):
+    """``mass_operator(N, T, exclusive=True)``: dofs that exactly one batch of the plan touches are finished with a plain load +
+    store instead of an atomic.  Same result as the oracle; accumulates into y like the unmarked apply (two launches back to
+    back on one stream); cell and facet entities; with every dof declared as used elsewhere nothing is marked."""
+    import torch
+
+    dev, ops = gpu
+    pb = build_problem(P, cells, dtype=dtype, perturb=0.16)
+    mesh = pb["mesh"]
+    n = P + 1
+    x64, cc64, dj64 = pb["x"].astype(np.float64), pb["cc"].astype(np.float64), pb["detJ"].astype(np.float64)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.mass_apply(x64, cc64, y_ref, dj64, mesh.dofmap)
+    x_d, cc_d, dj_d, dm = (dev.to_device(a) for a in (pb["x"], pb["cc"], pb["detJ"], mesh.dofmap))
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    op = ops.mass_operator(n**3, dtype, exclusive=True)
+    y = torch.zeros(mesh.ndofs, dtype=tdt, device="cuda")
+    op(x_d, cc_d, y, dj_d, dm)
+    _check(y.cpu().numpy(), y_ref, dtype, "exclusive-marks cell mass")
+    op(x_d, cc_d, y, dj_d, dm)  # accumulates: the plain load of the second launch sees the first launch's store
+    _check(y.cpu().numpy(), 2 * y_ref, dtype, "exclusive-marks cell mass, second launch")
+    # the marks themselves: some dofs are exclusive (cell interiors at least), the batches' shared faces are not
+    ws, epb = ops._PLANS.get(dm, exclusive_ndofs=mesh.ndofs)
+    lib = pkg("_lib").load()
+    nbatch = (mesh.ncells + epb - 1) // epb
+    nbytes = int(lib.fus_plan_bytes(n**3, epb, mesh.ncells))
+    words = (epb * n**3 + 31) // 32
+    excl = ws[nbytes - ((nbatch * words * 4 + 255) // 256 * 256):][: nbatch * words * 4].view(torch.int32).cpu().numpy().view(np.uint32)
+    marked = int(sum(bin(int(w)).count("1") for w in excl))
+    nu = (ws[256:256 + 4 * nbatch].view(torch.int32).cpu().numpy() & 0xFFFF).sum()
+    assert marked >= mesh.ncells * (P - 1) ** 3 and marked < nu  # every cell-interior dof; not the shared faces
+    # everything declared as used elsewhere: no marks, same result
+    ext = torch.ones(mesh.ndofs, dtype=torch.int32, device="cuda")
+    ws2, _ = ops._PLANS.get(dm, exclusive_ndofs=mesh.ndofs, external_use=ext)
+    excl2 = ws2[nbytes - ((nbatch * words * 4 + 255) // 256 * 256):][: nbatch * words * 4]
+    assert int(excl2.to(torch.int64).sum().item()) == 0
+    # boundary facets (N = n^2)
+    gll, pre = pkg("gll"), pkg("precompute")
+    bd = mesh.boundary_facets()
+    dF = np.zeros((bd.shape[0], n * n))
+    pre.compute_boundary_facets_scaled_jacobian_determinant(dF, (mesh.x_dofs.astype(np.int32), mesh.x_g.astype(np.float64)), bd,
+                                                            pre.tabulate_facet_gradients(gll.gll_points_weights(P)[0]),
+                                                            gll.tensor_weights_2d(gll.gll_points_weights(P)[1]))
+    fdm = mesh.facet_dofmap(bd)
+    fc = 1.0 + 0.25 * np.random.default_rng(5).standard_normal(bd.shape[0])
+    if bd.shape[0] * n * n >= ops._MASS_PLAN_MIN_ENTRIES:
+        y_ref = np.zeros(mesh.ndofs)
+        oracle_c.mass_apply(x64, fc, y_ref, dF, fdm)
+        y = torch.zeros(mesh.ndofs, dtype=tdt, device="cuda")
+        ops.mass_operator(n * n, dtype, exclusive=True)(x_d, dev.to_device(fc.astype(dtype)), y, dev.to_device(dF.astype(dtype)), dev.to_device(fdm))
+        _check(y.cpu().numpy(), y_ref, dtype, "exclusive-marks facet mass")
