@@ -177,3 +177,39 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
         hc = out["config"]["halo_check"]
         assert hc["ok"] is True and hc["forward_wrong_ghosts"] == 0 and hc["reverse_sum"] == hc["global_ghosts"] > 0
         assert out["config"]["halo_schedule"] == "concurrent"
+
+
+@pytest.mark.gpu
+def test_scatter_mode_line():
+    """``bench.py --mode scatter``: the reference's third timing script (numba-cpu/time_scatterer.py:126-210) at N = 1 -- a rank
+    that is its own neighbour with config-4-shaped messages, per transport and direction both protocols, the numpy oracle
+    beside them."""
+    r = subprocess.run([sys.executable, BENCH, "--mode", "scatter", "--steps", "10", "--cells", "12"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["metric"] == "scatter_forward_reverse_us" and out["higher_is_better"] is False
+    tr = out["scatter"]["transports"]
+    for kind in ("peer", "native", "torch"):
+        assert kind in tr and "error" not in tr[kind], tr.get(kind)
+        for d in ("scatter_forward", "scatter_reverse"):
+            assert tr[kind][d]["us_per_call_stream"] > 0 and tr[kind][d]["us_per_call_sync_mean"] > 0
+    assert tr["peer"]["scatter_forward"]["failed_waits"] == 0
+    assert out["cpu_baseline"]["scatter_reverse"]["us_per_call_mean"] > 0
+
+
+@pytest.mark.gpu
+def test_default_line_carries_the_aux_entries():
+    """The driver's default command at a small size: the headline line with every ``aux`` entry of DESIGN.md section 6 (mass, its
+    cached-diagonal form, sustained applies, in-kernel geometry, the RK4 step with and without in-kernel geometry -- with its
+    CPU oracle leg --, scatter)."""
+    r = subprocess.run([sys.executable, BENCH, "--steps", "5", "--warmup", "2", "--cells", "12"], env=_env(), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    aux = out["aux"]
+    for k in ("mass", "mass_cached_diagonal", "sustained", "stiffness_in_kernel_geometry", "rk4_step", "rk4_step_in_kernel_geometry", "scatter"):
+        assert aux.get(k) is not None, k
+    assert aux["sustained"]["applies"] >= 2000 and len(aux["sustained"]["window_ms_per_apply"]) == 10
+    assert aux["rk4_step"]["cpu_baseline"]["value"] > 0 and aux["rk4_step"]["cpu_baseline"]["single_thread_value"] > 0
+    assert aux["rk4_step"]["roofline"]["algorithmic_bytes_per_step"] > 0
+    assert aux["stiffness_in_kernel_geometry"]["roofline"]["algorithmic_bytes_per_cell"] == 2100
+    assert out["cpu_baseline"]["value"] > 0 and out["roofline"]["frac"] > 0
