@@ -1172,7 +1172,7 @@ def main():
             halo = None
         if halo is None:
             raise SystemExit(f"no halo transport passed the halo check on rank {rank}: {tried}")
-    y_d.zero_()
+    ops.fill(0.0, y_d)  # the library's fill: streaming stores, no dirty lines left in the memory-side cache for the first timed launches to write back
     # Timed region: EXACTLY K steps issued back to back, bracketed by barrier + device synchronise on
     # both sides (wall clock -> value) and by ONE HIP-event pair on the launch stream (device time of
     # the region -> average launch duration -> roofline).  Nothing else is enqueued inside the region:

@@ -109,6 +109,7 @@ TUNE_XCD_REMAP = 2
 TUNE_MASS_VARIANT = 3
 TUNE_PLAN_VARIANT = 4
 TUNE_PLAN_RUNS = 5
+TUNE_VECTOR_STREAM = 6
 
 ABI_VERSION = 3  # include/fus_gpu.h FUS_ABI_VERSION
 

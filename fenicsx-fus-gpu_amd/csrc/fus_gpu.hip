@@ -387,6 +387,10 @@ int fus_set_tuning(int key, int value) {
     case FUS_TUNE_MASS_VARIANT: g_mass_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_VARIANT: g_plan_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_RUNS: g_plan_runs = value; return FUS_OK;
+    case FUS_TUNE_VECTOR_STREAM:
+      if (value < 0 || value > 2) return FUS_ERR_INVALID_ARGUMENT;
+      fus::vector_stream_mode() = value;
+      return FUS_OK;
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }
@@ -398,6 +402,7 @@ int fus_get_tuning(int key) {
     case FUS_TUNE_MASS_VARIANT: return g_mass_variant;
     case FUS_TUNE_PLAN_VARIANT: return g_plan_variant;
     case FUS_TUNE_PLAN_RUNS: return g_plan_runs;
+    case FUS_TUNE_VECTOR_STREAM: return fus::vector_stream_mode();
   }
   return FUS_ERR_INVALID_ARGUMENT;
 }

@@ -21,6 +21,8 @@
 
 #include <type_traits>
 
+#include "vecops.hpp"
+
 namespace fus {
 
 // ``kind`` (the ABI's ``new_step`` argument):
@@ -67,10 +69,12 @@ __device__ __forceinline__ Rk4Out<T> rk4_update(int kind, T bw, T aw, const Rk4I
 }
 
 // W dofs per thread as ONE 16-byte access per array where the arrays are 16-byte aligned (W = 2 doubles / 4 floats), scalar
-// otherwise; the streaming arrays (everything but un, the next operator input, and b) with non-temporal loads / stores: the
-// pass re-reads nothing it touches before ~1 GB of other data has gone through the caches (profiles/r04g_ab_nontemporal.log:
-// 132 -> 123 us per stage at 10.2 M dofs).
-template <typename T, int W>
+// otherwise.  NT (vectors far larger than the caches: vecops.hpp vector_stream): EVERY access non-temporal.  The loads: the
+// pass re-reads nothing before ~1 GB of other data has gone through the caches.  The stores -- un, ku and b included, although
+// the next kernel reads them: a line written with a plain store stays dirty in the memory-side Infinity Cache and is written
+// back WHILE THE OPERATOR RUNS (its launch takes 251-272 us after a plain-store vector pass against 219-222 us after a busy
+// wait or a read-only stream: profiles/r04i_interleave_probe.log); re-reading 82 MB of un from HBM is the cheaper side.
+template <typename T, int W, bool NT>
 __global__ void __launch_bounds__(256)
     rk4_stage_kernel(T bw, T aw, int kind, const T* __restrict__ minv, T* __restrict__ b, T* __restrict__ u,
                      T* __restrict__ v, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ ku,
@@ -82,10 +86,10 @@ __global__ void __launch_bounds__(256)
     if (i + W <= nlocal) {
       T rb[W], rm[W], ru[W], rv[W], ru0[W], rv0[W], rku[W];
       auto ld = [&](const T* p, T(&r)[W], bool nt) {
-        V t = nt ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p + i)) : *reinterpret_cast<const V*>(p + i);
+        V t = (NT && nt) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p + i)) : *reinterpret_cast<const V*>(p + i);
         __builtin_memcpy(r, &t, sizeof(V));
       };
-      ld(b, rb, false);
+      ld(b, rb, true);
       ld(minv, rm, true);
       const bool rd_uv = kind != 2, rd_0 = kind == 0 || kind == 2, rd_ku = kind != 2;
       if (rd_uv) {
@@ -106,7 +110,7 @@ __global__ void __launch_bounds__(256)
       auto st = [&](T* p, const T(&r)[W], bool nt) {
         V t;
         __builtin_memcpy(&t, r, sizeof(V));
-        if (nt)
+        if (NT && nt)
           __builtin_nontemporal_store(t, reinterpret_cast<V*>(p + i));
         else
           *reinterpret_cast<V*>(p + i) = t;
@@ -114,8 +118,8 @@ __global__ void __launch_bounds__(256)
       if (kind != 3) {
         st(u, ou, true);
         st(v, ov, true);
-        st(un, oun, false);
-        st(ku, oku, false);
+        st(un, oun, true);
+        st(ku, oku, true);
       }
       if (kind == 1 || kind == 3) {
         st(u0, ou0, true);
@@ -124,7 +128,7 @@ __global__ void __launch_bounds__(256)
       T z[W];
 #pragma unroll
       for (int k = 0; k < W; ++k) z[k] = T(0);
-      st(b, z, false);
+      st(b, z, true);
     } else {  // the last owned dofs (nlocal not a multiple of W) and the ghost block of b
       for (int64_t j = i; j < i + W && j < ntotal; ++j) {
         if (j < nlocal) {
@@ -153,12 +157,19 @@ inline hipError_t launch_rk4_stage(T bw, T aw, int new_step, const T* minv, T* b
   const int64_t work = aligned ? (ntotal + W - 1) / W : ntotal;
   int64_t nblocks = (work + 255) / 256;
   if (nblocks > 4096) nblocks = 4096;
-  if (aligned)
-    hipLaunchKernelGGL((rk4_stage_kernel<T, W>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, new_step, minv, b, u, v, u0,
-                       v0, ku, un, nlocal, ntotal);
+  const bool nt = vector_stream(ntotal * (int64_t)sizeof(T));
+#define FUS_RK4(W_, NT_) \
+  hipLaunchKernelGGL((rk4_stage_kernel<T, W_, NT_>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, new_step, minv, b, u, v, \
+                     u0, v0, ku, un, nlocal, ntotal)
+  if (aligned && nt)
+    FUS_RK4(W, true);
+  else if (aligned)
+    FUS_RK4(W, false);
+  else if (nt)
+    FUS_RK4(1, true);
   else
-    hipLaunchKernelGGL((rk4_stage_kernel<T, 1>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, new_step, minv, b, u, v, u0,
-                       v0, ku, un, nlocal, ntotal);
+    FUS_RK4(1, false);
+#undef FUS_RK4
   return hipGetLastError();
 }
 

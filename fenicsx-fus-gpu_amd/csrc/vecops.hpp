@@ -8,6 +8,36 @@
 
 namespace fus {
 
+// Streaming accesses.  A vector kernel on operands far larger than the caches re-reads nothing it touches, and -- what
+// matters -- every line it WRITES with a plain store stays dirty in the 256 MB memory-side Infinity Cache and is written
+// back while the NEXT kernel runs: the headline apply takes 219-222 us after nothing / a busy wait / a 1 GiB read-only
+// stream, 287 us after a 1 GiB fill, 263 us after a 1 GiB copy, 251-272 us after the RK4 vector pass
+// (tools/interleave_probe.py, profiles/r04i_interleave_probe.log).  Non-temporal stores go to memory without lingering.
+// mode: 0 never, 1 auto (operands > kStreamBytes), 2 always  (fus_set_tuning FUS_TUNE_VECTOR_STREAM)
+constexpr int64_t kStreamBytes = 24ll << 20;
+inline int& vector_stream_mode() {
+  static int m = 1;
+  return m;
+}
+inline bool vector_stream(int64_t operand_bytes) {
+  const int m = vector_stream_mode();
+  return m == 2 || (m == 1 && operand_bytes > kStreamBytes);
+}
+template <bool NT, typename V>
+__device__ __forceinline__ V ld_stream(const V* p) {
+  if constexpr (NT)
+    return __builtin_nontemporal_load(p);
+  else
+    return *p;
+}
+template <bool NT, typename V>
+__device__ __forceinline__ void st_stream(V* p, V v) {
+  if constexpr (NT)
+    __builtin_nontemporal_store(v, p);
+  else
+    *p = v;
+}
+
 template <typename T>
 struct vec16;
 template <>
@@ -58,24 +88,34 @@ __device__ __forceinline__ float4 apply2(const float4& a, const float4& b, const
   return float4{op(a.x, b.x), op(a.y, b.y), op(a.z, b.z), op(a.w, b.w)};
 }
 
-// out[i] = op(a[i], b[i]);  USE_A / USE_B say which inputs are actually read.
-template <typename T, typename Op, bool USE_A, bool USE_B, bool VEC>
+// out[i] = op(a[i], b[i]);  USE_A / USE_B say which inputs are actually read.  NT: streaming (non-temporal) accesses.
+template <typename T, typename Op, bool USE_A, bool USE_B, bool VEC, bool NT>
 __global__ void __launch_bounds__(256)
     ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n, Op op) {
   using V = typename vec16<T>::type;
   constexpr int W = vec16<T>::W;
+  typedef T VN __attribute__((ext_vector_type(W)));  // native vector: what the non-temporal builtins take
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if constexpr (VEC) {
     const int64_t nv = n / W;
-    const V* av = reinterpret_cast<const V*>(a);
-    const V* bv = reinterpret_cast<const V*>(b);
-    V* ov = reinterpret_cast<V*>(out);
+    const VN* av = reinterpret_cast<const VN*>(a);
+    const VN* bv = reinterpret_cast<const VN*>(b);
+    VN* ov = reinterpret_cast<VN*>(out);
     for (int64_t i = gid; i < nv; i += stride) {
       V va{}, vb{};
-      if constexpr (USE_A) va = av[i];
-      if constexpr (USE_B) vb = bv[i];
-      ov[i] = apply2(va, vb, op);
+      if constexpr (USE_A) {
+        const VN t = ld_stream<NT>(av + i);
+        __builtin_memcpy(&va, &t, sizeof(V));
+      }
+      if constexpr (USE_B) {
+        const VN t = ld_stream<NT>(bv + i);
+        __builtin_memcpy(&vb, &t, sizeof(V));
+      }
+      const V r = apply2(va, vb, op);
+      VN t;
+      __builtin_memcpy(&t, &r, sizeof(V));
+      st_stream<NT>(ov + i, t);
     }
     const int64_t i = nv * W + gid;  // tail
     if (i < n) {
@@ -87,9 +127,9 @@ __global__ void __launch_bounds__(256)
   } else {
     for (int64_t i = gid; i < n; i += stride) {
       T sa = T(0), sb = T(0);
-      if constexpr (USE_A) sa = a[i];
-      if constexpr (USE_B) sb = b[i];
-      out[i] = op(sa, sb);
+      if constexpr (USE_A) sa = ld_stream<NT>(a + i);
+      if constexpr (USE_B) sb = ld_stream<NT>(b + i);
+      st_stream<NT>(out + i, op(sa, sb));
     }
   }
 }
@@ -98,35 +138,27 @@ __global__ void __launch_bounds__(256)
 // numba-cpu/operators.py:19-68 is diagonal, M(c) x = (M(c) 1) (.) x, so a driver that applies the same M(c) many times
 // assembles w = M(c) 1 once (one gather-scale-scatter apply) and applies 3 vector touches per dof afterwards instead of
 // 47.6 B/dof of gather / scatter.  Opt-in (operators.diagonal_mass_operator), its own bytes contract.
-template <typename T, bool VEC>
+template <typename T, bool VEC, bool NT>
 __global__ void __launch_bounds__(256) muladd_kernel(const T* __restrict__ w, const T* __restrict__ x, T* __restrict__ y, int64_t n) {
-  using V = typename vec16<T>::type;
   constexpr int W = vec16<T>::W;
+  typedef T VN __attribute__((ext_vector_type(W)));
   const int64_t stride = (int64_t)gridDim.x * 256;
   const int64_t gid = (int64_t)blockIdx.x * 256 + threadIdx.x;
   if constexpr (VEC) {
     const int64_t nv = n / W;
-    const V* wv = reinterpret_cast<const V*>(w);
-    const V* xv = reinterpret_cast<const V*>(x);
-    V* yv = reinterpret_cast<V*>(y);
+    const VN* wv = reinterpret_cast<const VN*>(w);
+    const VN* xv = reinterpret_cast<const VN*>(x);
+    VN* yv = reinterpret_cast<VN*>(y);
     for (int64_t i = gid; i < nv; i += stride) {
-      const V a = wv[i], b = xv[i];
-      V c = yv[i];
-      if constexpr (W == 2) {
-        c.x += a.x * b.x;
-        c.y += a.y * b.y;
-      } else {
-        c.x += a.x * b.x;
-        c.y += a.y * b.y;
-        c.z += a.z * b.z;
-        c.w += a.w * b.w;
-      }
-      yv[i] = c;
+      const VN a = ld_stream<NT>(wv + i), b = ld_stream<NT>(xv + i);
+      VN c = ld_stream<NT>(yv + i);
+      c += a * b;  // element-wise
+      st_stream<NT>(yv + i, c);
     }
     const int64_t i = nv * W + gid;
     if (i < n) y[i] += w[i] * x[i];
   } else {
-    for (int64_t i = gid; i < n; i += stride) y[i] += w[i] * x[i];
+    for (int64_t i = gid; i < n; i += stride) st_stream<NT>(y + i, ld_stream<NT>(y + i) + ld_stream<NT>(w + i) * ld_stream<NT>(x + i));
   }
 }
 
@@ -138,10 +170,15 @@ inline hipError_t launch_muladd(const T* w, const T* x, T* y, int64_t n, hipStre
   const int64_t work = aligned ? (n + W - 1) / W : n;
   int64_t nblocks = (work + 255) / 256;
   if (nblocks > 2048) nblocks = 2048;
-  if (aligned)
-    hipLaunchKernelGGL((muladd_kernel<T, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
+  const bool nt = vector_stream(n * (int64_t)sizeof(T));
+  if (aligned && nt)
+    hipLaunchKernelGGL((muladd_kernel<T, true, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
+  else if (aligned)
+    hipLaunchKernelGGL((muladd_kernel<T, true, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
+  else if (nt)
+    hipLaunchKernelGGL((muladd_kernel<T, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
   else
-    hipLaunchKernelGGL((muladd_kernel<T, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
+    hipLaunchKernelGGL((muladd_kernel<T, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
   return hipGetLastError();
 }
 
@@ -154,12 +191,18 @@ inline hipError_t launch_ew(const T* a, const T* b, T* out, int64_t n, Op op, hi
   const int64_t work = aligned ? (n + W - 1) / W : n;
   int64_t nblocks = (work + 255) / 256;
   if (nblocks > 2048) nblocks = 2048;
-  if (aligned)
-    hipLaunchKernelGGL((ew_kernel<T, Op, USE_A, USE_B, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, a, b,
-                       out, n, op);
+  const bool nt = vector_stream(n * (int64_t)sizeof(T));
+#define FUS_EW(VEC_, NT_) \
+  hipLaunchKernelGGL((ew_kernel<T, Op, USE_A, USE_B, VEC_, NT_>), dim3((unsigned)nblocks), dim3(256), 0, stream, a, b, out, n, op)
+  if (aligned && nt)
+    FUS_EW(true, true);
+  else if (aligned)
+    FUS_EW(true, false);
+  else if (nt)
+    FUS_EW(false, true);
   else
-    hipLaunchKernelGGL((ew_kernel<T, Op, USE_A, USE_B, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, a, b,
-                       out, n, op);
+    FUS_EW(false, false);
+#undef FUS_EW
   return hipGetLastError();
 }
 

@@ -18,6 +18,7 @@
 #include <stdint.h>
 
 #include "stiffness_plan.hpp"
+#include "vecops.hpp"
 
 namespace fus {
 
@@ -283,18 +284,9 @@ __global__ void __launch_bounds__(256)
 // ``w`` (optional): the combined stiffness input of the NEXT cell pass, w = u_n' + kappa v_n', for media where
 // c4 = kappa c3 in every cell (then K(c3) u + K(c4) v = K(c3)(u + kappa v): one plain stiffness apply, one
 // gather, one forward halo exchange less); for kind LAST it is formed from the new (u0, v0).
-// non-temporal accesses for the arrays the vector pass only streams (everything but the next cell pass's inputs un / ku / w
-// and b): nothing of them is read again before ~1 GB of other data has gone through the caches (rk4.hpp)
-template <typename T>
-__device__ __forceinline__ T nt_ld(const T* p) {
-  return __builtin_nontemporal_load(p);
-}
-template <typename T>
-__device__ __forceinline__ void nt_st(T* p, T v) {
-  __builtin_nontemporal_store(v, p);
-}
-
-template <typename T>
+// NT (vectors far larger than the caches): every access non-temporal -- see rk4.hpp: what matters is that no line this pass
+// writes stays dirty in the memory-side cache to be written back while the next cell pass runs.
+template <typename T, bool NT>
 __global__ void __launch_bounds__(256)
     rk4_stage_nl2_kernel(T bw, T aw, int kind, const T* __restrict__ m0, const T* __restrict__ w2,
                          const T* __restrict__ w5, T* __restrict__ b, T* __restrict__ u, T* __restrict__ v,
@@ -302,49 +294,51 @@ __global__ void __launch_bounds__(256)
                          T kappa, T* __restrict__ w, int64_t nlocal, int64_t ntotal) {
   const int64_t stride = (int64_t)gridDim.x * 256;
   for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < ntotal; i += stride) {
+    auto L = [&](const T* p) { return ld_stream<NT>(p + i); };
+    auto S = [&](T* p, T val) { st_stream<NT>(p + i, val); };
     if (i < nlocal) {
       T un_new, vn_new;
       if (kind == 2) {  // FIRST: stage inputs are (u0, v0); u == u0, v == v0, ku == v0
-        const T u0i = nt_ld(u0 + i), v0i = nt_ld(v0 + i);
-        const T kv = (b[i] + nt_ld(w5 + i) * v0i * v0i) / (nt_ld(m0 + i) + nt_ld(w2 + i) * u0i);
-        nt_st(u + i, u0i + bw * v0i);
-        nt_st(v + i, v0i + bw * kv);
+        const T u0i = L(u0), v0i = L(v0);
+        const T kv = (L(b) + L(w5) * v0i * v0i) / (L(m0) + L(w2) * u0i);
+        S(u, u0i + bw * v0i);
+        S(v, v0i + bw * kv);
         un_new = u0i + aw * v0i;
         vn_new = v0i + aw * kv;
-        un[i] = un_new;
-        ku[i] = vn_new;
+        S(un, un_new);
+        S(ku, vn_new);
       } else {
-        const T uni = un[i], kui = ku[i];
-        const T kv = (b[i] + nt_ld(w5 + i) * kui * kui) / (nt_ld(m0 + i) + nt_ld(w2 + i) * uni);
+        const T uni = L(un), kui = L(ku);
+        const T kv = (L(b) + L(w5) * kui * kui) / (L(m0) + L(w2) * uni);
         if (kind == 3) {  // LAST: the next stage's inputs are the new (u0, v0)
-          un_new = nt_ld(u + i) + bw * kui;
-          vn_new = nt_ld(v + i) + bw * kv;
-          nt_st(u0 + i, un_new);
-          nt_st(v0 + i, vn_new);
+          un_new = L(u) + bw * kui;
+          vn_new = L(v) + bw * kv;
+          S(u0, un_new);
+          S(v0, vn_new);
         } else {
-          const T ui = nt_ld(u + i) + bw * kui;
-          const T vi = nt_ld(v + i) + bw * kv;
-          nt_st(u + i, ui);
-          nt_st(v + i, vi);
+          const T ui = L(u) + bw * kui;
+          const T vi = L(v) + bw * kv;
+          S(u, ui);
+          S(v, vi);
           T u0i, v0i;
           if (kind == 1) {
             u0i = ui;
             v0i = vi;
-            nt_st(u0 + i, ui);
-            nt_st(v0 + i, vi);
+            S(u0, ui);
+            S(v0, vi);
           } else {
-            u0i = nt_ld(u0 + i);
-            v0i = nt_ld(v0 + i);
+            u0i = L(u0);
+            v0i = L(v0);
           }
           un_new = u0i + aw * kui;
           vn_new = v0i + aw * kv;
-          un[i] = un_new;
-          ku[i] = vn_new;
+          S(un, un_new);
+          S(ku, vn_new);
         }
       }
-      if (w != nullptr) w[i] = un_new + kappa * vn_new;
+      if (w != nullptr) S(w, un_new + kappa * vn_new);
     }
-    b[i] = T(0);
+    S(b, T(0));
   }
 }
 
@@ -355,8 +349,12 @@ inline hipError_t launch_rk4_stage_nl2(T bw, T aw, int kind, const T* m0, const 
   if (ntotal <= 0) return hipSuccess;
   int64_t nblocks = (ntotal + 255) / 256;
   if (nblocks > 4096) nblocks = 4096;
-  hipLaunchKernelGGL((rk4_stage_nl2_kernel<T>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5, b,
-                     u, v, u0, v0, ku, un, kappa, w, nlocal, ntotal);
+  if (vector_stream(ntotal * (int64_t)sizeof(T)))
+    hipLaunchKernelGGL((rk4_stage_nl2_kernel<T, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5,
+                       b, u, v, u0, v0, ku, un, kappa, w, nlocal, ntotal);
+  else
+    hipLaunchKernelGGL((rk4_stage_nl2_kernel<T, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5,
+                       b, u, v, u0, v0, ku, un, kappa, w, nlocal, ntotal);
   return hipGetLastError();
 }
 

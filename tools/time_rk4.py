@@ -25,6 +25,9 @@ def main():
     import fusgpu_loader
 
     torch.cuda.set_device(0)
+    if os.environ.get("FUS_VECTOR_STREAM") is not None:  # A/B: non-temporal accesses in the vector kernels off (0) / auto (1) / always (2)
+        lib_mod = fusgpu_loader.submodule("_lib")
+        lib_mod.set_tuning(lib_mod.TUNE_VECTOR_STREAM, int(os.environ["FUS_VECTOR_STREAM"]))
     boxmesh, ls = fusgpu_loader.submodule("boxmesh"), fusgpu_loader.submodule("linear_solver")
     L = 0.12
     mesh = boxmesh.BoxMesh(a.degree, a.cells, length=L)
