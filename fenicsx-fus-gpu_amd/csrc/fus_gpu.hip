@@ -388,7 +388,7 @@ int fus_set_tuning(int key, int value) {
     case FUS_TUNE_PLAN_VARIANT: g_plan_variant = value; return FUS_OK;
     case FUS_TUNE_PLAN_RUNS: g_plan_runs = value; return FUS_OK;
     case FUS_TUNE_VECTOR_STREAM:
-      if (value < 0 || value > 2) return FUS_ERR_INVALID_ARGUMENT;
+      if (value < 0 || value > 4) return FUS_ERR_INVALID_ARGUMENT;
       fus::vector_stream_mode() = value;
       return FUS_OK;
   }

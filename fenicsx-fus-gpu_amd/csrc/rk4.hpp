@@ -74,7 +74,7 @@ __device__ __forceinline__ Rk4Out<T> rk4_update(int kind, T bw, T aw, const Rk4I
 // the next kernel reads them: a line written with a plain store stays dirty in the memory-side Infinity Cache and is written
 // back WHILE THE OPERATOR RUNS (its launch takes 251-272 us after a plain-store vector pass against 219-222 us after a busy
 // wait or a read-only stream: profiles/r04i_interleave_probe.log); re-reading 82 MB of un from HBM is the cheaper side.
-template <typename T, int W, bool NT>
+template <typename T, int W, int NT>
 __global__ void __launch_bounds__(256)
     rk4_stage_kernel(T bw, T aw, int kind, const T* __restrict__ minv, T* __restrict__ b, T* __restrict__ u,
                      T* __restrict__ v, T* __restrict__ u0, T* __restrict__ v0, T* __restrict__ ku,
@@ -86,7 +86,7 @@ __global__ void __launch_bounds__(256)
     if (i + W <= nlocal) {
       T rb[W], rm[W], ru[W], rv[W], ru0[W], rv0[W], rku[W];
       auto ld = [&](const T* p, T(&r)[W], bool nt) {
-        V t = (NT && nt) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p + i)) : *reinterpret_cast<const V*>(p + i);
+        V t = (NT == 1 && nt) ? __builtin_nontemporal_load(reinterpret_cast<const V*>(p + i)) : *reinterpret_cast<const V*>(p + i);
         __builtin_memcpy(r, &t, sizeof(V));
       };
       ld(b, rb, true);
@@ -110,7 +110,7 @@ __global__ void __launch_bounds__(256)
       auto st = [&](T* p, const T(&r)[W], bool nt) {
         V t;
         __builtin_memcpy(&t, r, sizeof(V));
-        if (NT && nt)
+        if (NT != 0 && nt)
           __builtin_nontemporal_store(t, reinterpret_cast<V*>(p + i));
         else
           *reinterpret_cast<V*>(p + i) = t;
@@ -157,18 +157,15 @@ inline hipError_t launch_rk4_stage(T bw, T aw, int new_step, const T* minv, T* b
   const int64_t work = aligned ? (ntotal + W - 1) / W : ntotal;
   int64_t nblocks = (work + 255) / 256;
   if (nblocks > 4096) nblocks = 4096;
-  const bool nt = vector_stream(ntotal * (int64_t)sizeof(T));
+  const int nt = vector_stream(ntotal * (int64_t)sizeof(T));
 #define FUS_RK4(W_, NT_) \
   hipLaunchKernelGGL((rk4_stage_kernel<T, W_, NT_>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, new_step, minv, b, u, v, \
                      u0, v0, ku, un, nlocal, ntotal)
-  if (aligned && nt)
-    FUS_RK4(W, true);
-  else if (aligned)
-    FUS_RK4(W, false);
-  else if (nt)
-    FUS_RK4(1, true);
-  else
-    FUS_RK4(1, false);
+  if (aligned) {
+    if (nt == 1) FUS_RK4(W, 1); else if (nt == 2) FUS_RK4(W, 2); else FUS_RK4(W, 0);
+  } else {
+    if (nt == 1) FUS_RK4(1, 1); else if (nt == 2) FUS_RK4(1, 2); else FUS_RK4(1, 0);
+  }
 #undef FUS_RK4
   return hipGetLastError();
 }

@@ -13,26 +13,32 @@ namespace fus {
 // back while the NEXT kernel runs: the headline apply takes 219-222 us after nothing / a busy wait / a 1 GiB read-only
 // stream, 287 us after a 1 GiB fill, 263 us after a 1 GiB copy, 251-272 us after the RK4 vector pass
 // (tools/interleave_probe.py, profiles/r04i_interleave_probe.log).  Non-temporal stores go to memory without lingering.
-// mode: 0 never, 1 auto (operands > kStreamBytes), 2 always  (fus_set_tuning FUS_TUNE_VECTOR_STREAM)
+// Loads too: most of these kernels update in place (u += ..., y += w x), and a non-temporal store to a line the kernel's own
+// plain load has just brought into the cache hits there and leaves it dirty all the same -- fused RK4 step on one box: cached
+// 1.621 ms, non-temporal stores only 1.569, loads and stores 1.484 (profiles/r04k_ab_vector_stream_policy.log).
+// Kernel template parameter NT: 0 cached accesses, 1 non-temporal loads AND stores, 2 non-temporal stores only.
+// mode (fus_set_tuning FUS_TUNE_VECTOR_STREAM): 0 never; 1 auto = loads and stores for operands > kStreamBytes (default);
+// 2 always loads and stores; 3 auto, stores only; 4 always, stores only
 constexpr int64_t kStreamBytes = 24ll << 20;
 inline int& vector_stream_mode() {
   static int m = 1;
   return m;
 }
-inline bool vector_stream(int64_t operand_bytes) {
+inline int vector_stream(int64_t operand_bytes) {
   const int m = vector_stream_mode();
-  return m == 2 || (m == 1 && operand_bytes > kStreamBytes);
+  const bool on = m == 2 || m == 4 || ((m == 1 || m == 3) && operand_bytes > kStreamBytes);
+  return !on ? 0 : (m >= 3 ? 2 : 1);
 }
-template <bool NT, typename V>
+template <int NT, typename V>
 __device__ __forceinline__ V ld_stream(const V* p) {
-  if constexpr (NT)
+  if constexpr (NT == 1)
     return __builtin_nontemporal_load(p);
   else
     return *p;
 }
-template <bool NT, typename V>
+template <int NT, typename V>
 __device__ __forceinline__ void st_stream(V* p, V v) {
-  if constexpr (NT)
+  if constexpr (NT != 0)
     __builtin_nontemporal_store(v, p);
   else
     *p = v;
@@ -89,7 +95,7 @@ __device__ __forceinline__ float4 apply2(const float4& a, const float4& b, const
 }
 
 // out[i] = op(a[i], b[i]);  USE_A / USE_B say which inputs are actually read.  NT: streaming (non-temporal) accesses.
-template <typename T, typename Op, bool USE_A, bool USE_B, bool VEC, bool NT>
+template <typename T, typename Op, bool USE_A, bool USE_B, bool VEC, int NT>
 __global__ void __launch_bounds__(256)
     ew_kernel(const T* __restrict__ a, const T* __restrict__ b, T* __restrict__ out, int64_t n, Op op) {
   using V = typename vec16<T>::type;
@@ -138,7 +144,7 @@ __global__ void __launch_bounds__(256)
 // numba-cpu/operators.py:19-68 is diagonal, M(c) x = (M(c) 1) (.) x, so a driver that applies the same M(c) many times
 // assembles w = M(c) 1 once (one gather-scale-scatter apply) and applies 3 vector touches per dof afterwards instead of
 // 47.6 B/dof of gather / scatter.  Opt-in (operators.diagonal_mass_operator), its own bytes contract.
-template <typename T, bool VEC, bool NT>
+template <typename T, bool VEC, int NT>
 __global__ void __launch_bounds__(256) muladd_kernel(const T* __restrict__ w, const T* __restrict__ x, T* __restrict__ y, int64_t n) {
   constexpr int W = vec16<T>::W;
   typedef T VN __attribute__((ext_vector_type(W)));
@@ -170,15 +176,14 @@ inline hipError_t launch_muladd(const T* w, const T* x, T* y, int64_t n, hipStre
   const int64_t work = aligned ? (n + W - 1) / W : n;
   int64_t nblocks = (work + 255) / 256;
   if (nblocks > 2048) nblocks = 2048;
-  const bool nt = vector_stream(n * (int64_t)sizeof(T));
-  if (aligned && nt)
-    hipLaunchKernelGGL((muladd_kernel<T, true, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
-  else if (aligned)
-    hipLaunchKernelGGL((muladd_kernel<T, true, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
-  else if (nt)
-    hipLaunchKernelGGL((muladd_kernel<T, false, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
-  else
-    hipLaunchKernelGGL((muladd_kernel<T, false, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n);
+  const int nt = vector_stream(n * (int64_t)sizeof(T));
+#define FUS_MA(VEC_, NT_) hipLaunchKernelGGL((muladd_kernel<T, VEC_, NT_>), dim3((unsigned)nblocks), dim3(256), 0, stream, w, x, y, n)
+  if (aligned) {
+    if (nt == 1) FUS_MA(true, 1); else if (nt == 2) FUS_MA(true, 2); else FUS_MA(true, 0);
+  } else {
+    if (nt == 1) FUS_MA(false, 1); else if (nt == 2) FUS_MA(false, 2); else FUS_MA(false, 0);
+  }
+#undef FUS_MA
   return hipGetLastError();
 }
 
@@ -191,17 +196,22 @@ inline hipError_t launch_ew(const T* a, const T* b, T* out, int64_t n, Op op, hi
   const int64_t work = aligned ? (n + W - 1) / W : n;
   int64_t nblocks = (work + 255) / 256;
   if (nblocks > 2048) nblocks = 2048;
-  const bool nt = vector_stream(n * (int64_t)sizeof(T));
+  const int nt = vector_stream(n * (int64_t)sizeof(T));
 #define FUS_EW(VEC_, NT_) \
   hipLaunchKernelGGL((ew_kernel<T, Op, USE_A, USE_B, VEC_, NT_>), dim3((unsigned)nblocks), dim3(256), 0, stream, a, b, out, n, op)
-  if (aligned && nt)
-    FUS_EW(true, true);
-  else if (aligned)
-    FUS_EW(true, false);
-  else if (nt)
-    FUS_EW(false, true);
-  else
-    FUS_EW(false, false);
+#define FUS_EW3(VEC_) \
+  if (nt == 1)        \
+    FUS_EW(VEC_, 1);  \
+  else if (nt == 2)   \
+    FUS_EW(VEC_, 2);  \
+  else                \
+    FUS_EW(VEC_, 0)
+  if (aligned) {
+    FUS_EW3(true);
+  } else {
+    FUS_EW3(false);
+  }
+#undef FUS_EW3
 #undef FUS_EW
   return hipGetLastError();
 }

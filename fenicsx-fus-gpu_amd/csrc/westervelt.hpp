@@ -286,7 +286,7 @@ __global__ void __launch_bounds__(256)
 // gather, one forward halo exchange less); for kind LAST it is formed from the new (u0, v0).
 // NT (vectors far larger than the caches): every access non-temporal -- see rk4.hpp: what matters is that no line this pass
 // writes stays dirty in the memory-side cache to be written back while the next cell pass runs.
-template <typename T, bool NT>
+template <typename T, int NT>
 __global__ void __launch_bounds__(256)
     rk4_stage_nl2_kernel(T bw, T aw, int kind, const T* __restrict__ m0, const T* __restrict__ w2,
                          const T* __restrict__ w5, T* __restrict__ b, T* __restrict__ u, T* __restrict__ v,
@@ -349,12 +349,12 @@ inline hipError_t launch_rk4_stage_nl2(T bw, T aw, int kind, const T* m0, const 
   if (ntotal <= 0) return hipSuccess;
   int64_t nblocks = (ntotal + 255) / 256;
   if (nblocks > 4096) nblocks = 4096;
-  if (vector_stream(ntotal * (int64_t)sizeof(T)))
-    hipLaunchKernelGGL((rk4_stage_nl2_kernel<T, true>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5,
-                       b, u, v, u0, v0, ku, un, kappa, w, nlocal, ntotal);
-  else
-    hipLaunchKernelGGL((rk4_stage_nl2_kernel<T, false>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5,
-                       b, u, v, u0, v0, ku, un, kappa, w, nlocal, ntotal);
+  const int nt = vector_stream(ntotal * (int64_t)sizeof(T));
+#define FUS_NL2(NT_) \
+  hipLaunchKernelGGL((rk4_stage_nl2_kernel<T, NT_>), dim3((unsigned)nblocks), dim3(256), 0, stream, bw, aw, kind, m0, w2, w5, b, u, v, \
+                     u0, v0, ku, un, kappa, w, nlocal, ntotal)
+  if (nt == 1) FUS_NL2(1); else if (nt == 2) FUS_NL2(2); else FUS_NL2(0);
+#undef FUS_NL2
   return hipGetLastError();
 }
 

@@ -71,7 +71,7 @@ int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_byt
 #define FUS_TUNE_MASS_VARIANT 3
 #define FUS_TUNE_PLAN_VARIANT 4      /* planned stiffness kernel build: see csrc/fus_gpu.hip */
 #define FUS_TUNE_PLAN_RUNS 5         /* which encoding of a plan's dof lists the apply kernels read: 0 the lists, 2 the run tables, 1 auto (default: fp64 run tables; fp32 run tables up to 125 dofs per entity, lists above); 0 at plan build = no run tables are built */
-#define FUS_TUNE_VECTOR_STREAM 6      /* non-temporal accesses in the streaming vector kernels (fus_axpy ... fus_rk4_stage_*): 0 never, 1 auto (default: operands > 24 MB), 2 always -- a plain store leaves its line dirty in the memory-side cache, to be written back while the NEXT kernel runs (csrc/vecops.hpp) */
+#define FUS_TUNE_VECTOR_STREAM 6      /* non-temporal accesses in the streaming vector kernels (fus_axpy ... fus_rk4_stage_*): 0 never, 1 auto (default: non-temporal loads and stores for operands > 24 MB), 2 always, 3 / 4 the same with non-temporal stores only -- a plain store leaves its line dirty in the memory-side cache, to be written back while the NEXT kernel runs (csrc/vecops.hpp) */
 int fus_set_tuning(int key, int value);
 int fus_get_tuning(int key);
 
