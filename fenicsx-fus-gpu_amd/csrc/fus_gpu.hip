@@ -967,10 +967,16 @@ FUS_HALO_GROUP(fus_halo_reverse_begin_group, 1)
 #undef FUS_HALO_GROUP
 
 int fus_halo_forward(fus_halo_t halo, void* buffer, void* stream) {
+  if (!halo || !buffer) return FUS_ERR_INVALID_ARGUMENT;
+  const int r = fus::halo_exchange_inline(&halo->h, buffer, static_cast<hipStream_t>(stream), 0);  // PEER: on the caller's stream
+  if (r <= 0) return r == 0 ? FUS_OK : FUS_ERR_COMM;
   const int rc = fus_halo_forward_begin(halo, buffer, stream);
   return rc != FUS_OK ? rc : fus_halo_forward_end(halo, buffer, stream);
 }
 int fus_halo_reverse(fus_halo_t halo, void* buffer, void* stream) {
+  if (!halo || !buffer) return FUS_ERR_INVALID_ARGUMENT;
+  const int r = fus::halo_exchange_inline(&halo->h, buffer, static_cast<hipStream_t>(stream), 1);
+  if (r <= 0) return r == 0 ? FUS_OK : FUS_ERR_COMM;
   const int rc = fus_halo_reverse_begin(halo, buffer, stream);
   return rc != FUS_OK ? rc : fus_halo_reverse_end(halo, buffer, stream);
 }

@@ -709,16 +709,18 @@ inline int halo_ipc_connect(Halo* h, int nblobs, const void* const* blobs) {
 // all the ordering there is, and no event is recorded (an event record is a marker with a cache write-back between the
 // exchange kernels).
 template <typename T>
-inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq, bool on_stream) {
+inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq, bool on_stream, bool inline_mode = false,
+                                     hipStream_t run_on = nullptr) {
   Comm* c = h->comm;
   IpcState& st = h->ipc;
+  hipStream_t rs = inline_mode ? run_on : c->stream2;  // inline: the caller's own stream (may be the null stream)
   T* vec = reinterpret_cast<T*>(vecp);
   const IpcRole& rr = dir == 0 ? st.recv_fwd : st.recv_rev;
   IpcJoin join{nullptr, 0, st.join_counter};
   if (c->join_armed && c->join_halo == h && c->join_dir == dir) {
     c->join_armed = false;
     c->join_halo = nullptr;
-    if (rr.nchunks > 0 && c->stream2 == c->stream) {  // this kernel is the last of the chain: it publishes the join flag
+    if (rr.nchunks > 0 && c->stream2 == c->stream && !inline_mode) {  // this kernel is the last of the chain: it publishes the join flag
       join.flag = c->sync_words + 1;
       join.seq = ++c->sync_seq[1];
       c->join_inflight = join.seq;
@@ -726,32 +728,33 @@ inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq,
   }
   if (rr.nchunks > 0) {
     if (dir == 1)
-      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_ADD, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->ghosts.idx_d,
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_ADD, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, rs, vec, h->ghosts.idx_d,
                          (int64_t)0, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
     else if (h->direct)
-      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, false>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->owners.idx_d,
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, false>), dim3(rr.nchunks), dim3(ipc_threads()), 0, rs, vec, h->owners.idx_d,
                          h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
     else
-      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, c->stream2, vec, h->owners.idx_d,
+      hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, rs, vec, h->owners.idx_d,
                          h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   st.done_recorded = !on_stream;
-  return on_stream ? hipSuccess : hipEventRecord(h->ev_done, c->stream2);
+  return on_stream ? hipSuccess : hipEventRecord(h->ev_done, rs);
 }
 
 template <typename T>
-inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir, bool on_stream) {
+inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir, bool on_stream, bool inline_mode = false, hipStream_t run_on = nullptr) {
   Comm* c = h->comm;
   IpcState& st = h->ipc;
+  hipStream_t ss = inline_mode ? run_on : c->stream;
   T* vec = reinterpret_cast<T*>(vecp);
   const uint64_t seq = ++st.seq[dir];
   const IpcRole& sr = dir == 0 ? st.send_fwd : st.send_rev;
   // a lazily posted fork: the first send kernel on the communicator's stream waits for the fork flag itself; where there
   // is none to carry the wait (no neighbours on this side), a wait kernel does
   IpcGate gate{nullptr, 0, nullptr};
-  if (c->gate_pending) {
+  if (c->gate_pending && !inline_mode) {
     if (sr.nchunks > 0) {
       gate = IpcGate{c->sync_words + 0, c->gate_pending, c->sync_words + 2};
       c->gate_pending = 0;
@@ -762,27 +765,27 @@ inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir, bool on_stream) {
   }
   if (sr.nchunks > 0) {
     if (dir == 0)  // owned entries listed in ghosts.idx -> the ghosting ranks
-      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->ghosts.idx_d, (int64_t)0,
+      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, ss, vec, h->ghosts.idx_d, (int64_t)0,
                          sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
     else if (h->direct)  // ghost block, already grouped by owner -> the owners
-      hipLaunchKernelGGL((ipc_send_kernel<T, false>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
+      hipLaunchKernelGGL((ipc_send_kernel<T, false>), dim3(sr.nchunks), dim3(ipc_threads()), 0, ss, vec, h->owners.idx_d, h->nlocal,
                          sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
     else
-      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, c->stream, vec, h->owners.idx_d, h->nlocal,
+      hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, ss, vec, h->owners.idx_d, h->nlocal,
                          sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
   st.sent_recorded = !on_stream;
   if (!on_stream) {
-    hipError_t e = hipEventRecord(st.ev_sent, c->stream);
+    hipError_t e = hipEventRecord(st.ev_sent, ss);
     if (e != hipSuccess) return e;
   }
   if (st.defer_recv) {  // ranks of ONE process: the receive kernel is posted by *_end (see IpcState::defer_recv)
     st.pending[dir] = seq;
     return hipSuccess;
   }
-  return halo_ipc_post_recv<T>(h, vecp, dir, seq, on_stream);
+  return halo_ipc_post_recv<T>(h, vecp, dir, seq, on_stream, inline_mode, run_on);
 }
 
 // failures seen by this halo's kernels (0 = healthy); synchronises the communicator's streams
@@ -951,6 +954,29 @@ inline int halo_begin_group(Halo* const* hs, void* const* buffers, int nh, hipSt
       hs[k]->cur_dir = dir;
       FUS_H(hipEventRecord(hs[k]->ev_packed, c->stream));
     }
+  }
+  return 0;
+}
+
+// begin + end of ONE exchange in one call (scatter_forward(buffer) / scatter_reverse(buffer) of the reference's closures called
+// stand-alone: set-up exchanges, u_sol(with_ghosts), the non-overlapped stage).  PEER: both kernels run on the CALLER's stream,
+// in stream order with what precedes and follows them -- no event edge to the communicator's stream and back (a stand-alone
+// exchange has nothing to overlap with; profiles/r04l_scatter_alone.log).  A receive that was deferred (ranks of one process)
+// is posted here too, so a host driving several ranks calls begin / end separately instead.
+inline int halo_exchange_inline(Halo* h, void* buffer, hipStream_t stream, int dir) {
+  Comm* c = h->comm;
+  if (h->owners.total == 0 && h->ghosts.total == 0) return 0;
+  if (c->kind != Comm::PEER) return 1;  // not handled here
+  if (!h->ipc.connected) {
+    c->last_error = "halo not connected: exchange the blobs of fus_halo_ipc_export and call fus_halo_ipc_connect first";
+    return -1;
+  }
+  char* vec = static_cast<char*>(buffer);
+  FUS_H(h->eb == 8 ? halo_ipc_post<double>(h, vec, dir, true, true, stream) : halo_ipc_post<float>(h, vec, dir, true, true, stream));
+  if (h->ipc.defer_recv && h->ipc.pending[dir]) {
+    const uint64_t seq = h->ipc.pending[dir];
+    h->ipc.pending[dir] = 0;
+    FUS_H(h->eb == 8 ? halo_ipc_post_recv<double>(h, vec, dir, seq, true, true, stream) : halo_ipc_post_recv<float>(h, vec, dir, seq, true, true, stream));
   }
   return 0;
 }

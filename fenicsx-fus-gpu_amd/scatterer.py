@@ -387,6 +387,7 @@ class _NativeScatter:
         self.active = True
         sfx = "reverse" if reverse else "forward"
         self._begin, self._end = getattr(lib, f"fus_halo_{sfx}_begin"), getattr(lib, f"fus_halo_{sfx}_end")
+        self._whole = getattr(lib, f"fus_halo_{sfx}")
         # PEER transport: map the neighbours' arenas (collective all-gather of the handles; in-process worlds connect
         # at the first exchange, when all ranks exist)
         self._connected = True
@@ -421,8 +422,13 @@ class _NativeScatter:
         _lib.check(self._end(self.handle, buffer.data_ptr(), _lib.stream_ptr()), "fus_halo_end", self.comm.handle)
 
     def __call__(self, buffer):
-        self.begin(buffer)
-        self.end(buffer)
+        """``scatter(buffer)`` of the reference's closures: the whole exchange, in stream order on the caller's stream
+        (``fus_halo_forward`` / ``fus_halo_reverse``: the PEER transport then runs its two kernels on that stream itself, no
+        event edge to the communicator's stream and back)."""
+        _lib.require_device_tensor(buffer, self.dtype, "buffer")
+        if not self._connected or (self._owner is not None and not self._owner._connected):
+            self._ensure_connected()
+        _lib.check(self._whole(self.handle, buffer.data_ptr(), _lib.stream_ptr()), "fus_halo_exchange", self.comm.handle)
 
     def close(self):
         # a halo must be destroyed before its communicator; if the communicator is already gone

@@ -965,3 +965,82 @@ def test_mass_exclusive_dof_marks(gpu, oracle_c, P, cells, dtype):
         y = torch.zeros(mesh.ndofs, dtype=tdt, device="cuda")
         ops.mass_operator(n * n, dtype, exclusive=True)(x_d, dev.to_device(fc.astype(dtype)), y, dev.to_device(dF.astype(dtype)), dev.to_device(fdm))
         _check(y.cpu().numpy(), y_ref, dtype, "exclusive-marks facet mass")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("mode", [0, 2, 4], ids=["cached", "nontemporal-loads-stores", "nontemporal-stores"])
+def test_vector_kernels_streaming_modes(gpu, dtype, mode):
+    """FUS_TUNE_VECTOR_STREAM: the vector kernels with cached, non-temporal load + store and non-temporal store-only accesses
+    (forced on, so that small vectors take the streaming paths too): aligned (16-byte accesses) and misaligned views, odd
+    lengths and tails, every op; the fused RK4 stage kernels of both solvers, all four stage kinds, bit for bit equal to the
+    cached mode (same arithmetic, only the access flavour differs)."""
+    import torch
+
+    dev, ops = gpu
+    lib_mod = pkg("_lib")
+    lib = lib_mod.load()
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    suf = "f64" if dtype == np.float64 else "f32"
+    rng = np.random.default_rng(3)
+    old = lib_mod.get_tuning(lib_mod.TUNE_VECTOR_STREAM)
+
+    def run_all(n, off):
+        a = torch.from_numpy(rng.standard_normal(n + off).astype(dtype)).cuda()[off:]
+        b = torch.from_numpy((2 + rng.random(n + off)).astype(dtype)).cuda()[off:]
+        res = {}
+        y = b.clone()
+        ops.axpy[1, 1](0.37, a, y)
+        res["axpy"] = y.clone()
+        out = torch.empty_like(a)
+        ops.copy(a, out)
+        res["copy"] = out.clone()
+        ops.fill(1.5, out)
+        res["fill"] = out.clone()
+        ops.pointwise_divide[1, 1](a, b, out)
+        res["divide"] = out.clone()
+        ops.square[1, 1](a, out)
+        res["square"] = out.clone()
+        ops.scale(-2.5, a, out)
+        res["scale"] = out.clone()
+        yy = b.clone()
+        lib_mod.check(getattr(lib, f"fus_muladd_{suf}")(a.data_ptr(), b.data_ptr(), yy.data_ptr(), n, lib_mod.stream_ptr()), "muladd")
+        res["muladd"] = yy.clone()
+        # fused stage kernels: 12 vectors, nlocal < ntotal (ghost block of b is zeroed, nothing else touched there)
+        nl = n - min(n // 7, 5)
+        for kind in (2, 0, 1, 3):
+            vs = [torch.from_numpy(rng.standard_normal(n + off).astype(dtype)).cuda()[off:] for _ in range(8)]
+            minv, bb, u, v, u0, v0, ku, un = vs
+            minv.abs_().add_(1.0)
+            lib_mod.check(getattr(lib, f"fus_rk4_stage_{suf}")(0.3, 0.7, kind, minv.data_ptr(), bb.data_ptr(), u.data_ptr(), v.data_ptr(), u0.data_ptr(),
+                                                            v0.data_ptr(), ku.data_ptr(), un.data_ptr(), nl, n, lib_mod.stream_ptr()), "rk4_stage")
+            res[f"rk4_{kind}"] = torch.cat([t.clone() for t in (bb, u, v, u0, v0, ku, un)])
+            vs = [torch.from_numpy(rng.standard_normal(n + off).astype(dtype)).cuda()[off:] for _ in range(11)]
+            m0, w2, w5, bb, u, v, u0, v0, ku, un, w = vs
+            m0.abs_().add_(4.0)
+            w2.mul_(0.01)
+            lib_mod.check(getattr(lib, f"fus_rk4_stage_nl2_{suf}")(0.3, 0.7, kind, m0.data_ptr(), w2.data_ptr(), w5.data_ptr(), bb.data_ptr(), u.data_ptr(),
+                                                                v.data_ptr(), u0.data_ptr(), v0.data_ptr(), ku.data_ptr(), un.data_ptr(), 0.25, w.data_ptr(), nl, n,
+                                                                lib_mod.stream_ptr()), "rk4_stage_nl2")
+            res[f"nl2_{kind}"] = torch.cat([t.clone() for t in (bb, u, v, u0, v0, ku, un, w)])
+        torch.cuda.synchronize()
+        return res
+
+    try:
+        for n in (1, 2, 3, 255, 257, 4099, 100003):
+            for off in (0, 1):
+                state = rng.bit_generator.state
+                lib_mod.set_tuning(lib_mod.TUNE_VECTOR_STREAM, 0)
+                ref = run_all(n, off)
+                rng.bit_generator.state = state  # the same random inputs
+                lib_mod.set_tuning(lib_mod.TUNE_VECTOR_STREAM, mode)
+                got = run_all(n, off)
+                for k in ref:
+                    assert torch.equal(ref[k], got[k]), f"{k}, n = {n}, offset {off}, mode {mode}"
+                # and the cached mode itself against numpy for the plain ops
+                a = ref["copy"].cpu().numpy()
+                assert np.allclose(ref["square"].cpu().numpy(), a * a, rtol=1e-6 if dtype == np.float32 else 1e-14)
+    finally:
+        lib_mod.set_tuning(lib_mod.TUNE_VECTOR_STREAM, old)
+    assert lib_mod.get_tuning(lib_mod.TUNE_VECTOR_STREAM) == old
+    with pytest.raises(lib_mod.FusGpuError):
+        lib_mod.set_tuning(lib_mod.TUNE_VECTOR_STREAM, 9)
