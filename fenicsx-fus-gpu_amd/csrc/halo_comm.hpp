@@ -794,8 +794,9 @@ inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir, bool on_stream, bo
 inline int halo_ipc_status(Halo* h, int64_t* out8) {
   Comm* c = h->comm;
   uint64_t w[ST_WORDS] = {0};
-  hipError_t e = hipStreamSynchronize(c->stream);
-  if (e == hipSuccess && c->stream2) e = hipStreamSynchronize(c->stream2);
+  // the whole device: a stand-alone exchange runs its kernels on the CALLER's stream (halo_exchange_inline), not on the
+  // communicator's
+  hipError_t e = hipDeviceSynchronize();
   if (e == hipSuccess) e = hipMemcpy(w, h->ipc.status, sizeof w, hipMemcpyDeviceToHost);
   if (e != hipSuccess) {
     c->last_error = hipGetErrorString(e);
@@ -817,8 +818,7 @@ inline int halo_ipc_status(Halo* h, int64_t* out8) {
 inline int comm_health(Comm* c, int64_t* failures, int64_t* detail3 = nullptr) {
   *failures = 0;
   int64_t d[3] = {0, 0, 0};  // time-outs of halo waits, poisoned flags read, time-outs of fork / join waits
-  hipError_t e = hipStreamSynchronize(c->stream);
-  if (e == hipSuccess && c->stream2 && c->stream2 != c->stream) e = hipStreamSynchronize(c->stream2);
+  hipError_t e = hipDeviceSynchronize();  // exchange kernels may have run on the communicator's stream(s) or on a caller's
   if (e == hipSuccess && c->sync_words) {
     uint64_t w = 0;
     e = hipMemcpy(&w, c->sync_words + 2 + ST_TIMEOUTS, sizeof w, hipMemcpyDeviceToHost);

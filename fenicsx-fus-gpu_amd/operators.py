@@ -139,6 +139,12 @@ class _PlanCache:
             self._recording.append((hit[0], hit[2]))
         return hit[0], hit[1]
 
+    def has(self, dofmap: torch.Tensor) -> bool:
+        """True if the (unmarked) plan of ``dofmap`` is cached: an apply with it does no set-up work (no allocation, no host
+        synchronisation) -- what ``HaloApply`` needs to know before it lets a launch carry a fork signal."""
+        nent, N = dofmap.shape
+        return (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index, None) in self._plans
+
     def clear(self):
         lib = _lib.load()
         for ws, _, _ in self._plans.values():

@@ -693,6 +693,14 @@ class HaloApply:
             self._hs = lib_stream if lib_stream is not None else torch.cuda.Stream(priority=-1)
         return self._hs
 
+    @staticmethod
+    def _plans_ready(views):
+        """The batch plans of the dofmaps among ``views`` (int32 [cells, dofs per cell]) are cached: the launch does no set-up."""
+        from . import operators as ops
+
+        dms = [t for t in views if t.dtype == torch.int32 and t.dim() == 2 and t.shape[1] > 8]
+        return len(dms) > 0 and all(ops._PLANS.has(t) for t in dms)
+
     def _views(self, name, percell):
         key = (name,) + tuple(t.data_ptr() for t in percell)
         v = self._views_cache.get(key)
@@ -756,7 +764,8 @@ class HaloApply:
             # range has been applied before -- its batch plan exists, no first-use set-up inside the launch call.
             a_, b_ = self.ranges["interior"]
             warm_key = ("interior",) + tuple(t.data_ptr() for t in percell)
-            attach = lib_sync and self._attach_sync and self._apply_fn is None and b_ > a_ and warm_key in self._warm
+            attach = (lib_sync and self._attach_sync and self._apply_fn is None and b_ > a_ and warm_key in self._warm
+                      and self._plans_ready(self._views("interior", percell)))
             if lib_sync:
                 self.comm.fork(lazy=fold and len(forward) > 0, attach=attach)
             else:
