@@ -40,6 +40,18 @@ from .precompute import (
 )
 
 
+def per_cell(value, mesh, name):
+    """A material parameter as a per-cell array in the MESH's cell order: a scalar (homogeneous medium, the reference's box
+    demos) or one value per cell in the caller's cell order (the DG0 arrays ``c0.x.array`` ... of the reference's production
+    drivers, cuda/demo_nonlinear_bowl.py:166-178; a mesh that re-ordered its cells -- ``ArrayMesh`` -- permutes them)."""
+    a = np.asarray(value, dtype=np.float64)
+    if a.ndim == 0:
+        return np.full(mesh.ncells, float(a))
+    if a.shape != (mesh.ncells,):
+        raise ValueError(f"{name}: a scalar or one value per cell ({mesh.ncells}), got shape {a.shape}")
+    return np.ascontiguousarray(mesh.permute_cells(a) if hasattr(mesh, "permute_cells") else a)
+
+
 def device_geometry(mesh, P, ft, dev, facet_sets):
     """G, detJ and the facet detJ of the given boundary_data sets, computed on the device
     (csrc/geometry.hpp; the reference does this with numba on the host,
@@ -93,12 +105,17 @@ class LinearSpectral3D(StepGraphMixin):
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1500.0, density=1000.0,
                  source_frequency=0.5e6, source_amplitude=60000.0, comm=None, fused=True,
                  source_time="tn", overlap=True, halo_kernels=None, affine="auto", in_kernel_geometry=False,
-                 halo_plan=None, defer_setup_exchange=False):
+                 halo_plan=None, defer_setup_exchange=False, reference_speed_of_sound=None):
+        """``speed_of_sound`` / ``density``: scalars, or one value per cell (heterogeneous medium: the DG0 material arrays of
+        the reference's drivers, in the caller's cell order).  ``reference_speed_of_sound``: the c of the source term
+        ``p0 w0 / c cos(w0 t)`` (cuda/demo_linear_box.py:515-530 uses the scalar of its homogeneous medium); default: the
+        scalar given, or the mean over the cells of the source facets."""
         self.mesh, self.P = mesh, mesh.P
         self.dt_np = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(float_type)
         self.tdt_np = self.dt_np
-        self.c0, self.rho0 = float(speed_of_sound), float(density)
+        c_cells, rho_cells = per_cell(speed_of_sound, mesh, "speed_of_sound"), per_cell(density, mesh, "density")
+        self.c0, self.rho0 = float(c_cells.mean()), float(rho_cells.mean())
         self.f0, self.p0 = float(source_frequency), float(source_amplitude)
         self.w0 = 2.0 * np.pi * self.f0
         self.fused, self.source_time = bool(fused), source_time
@@ -116,8 +133,13 @@ class LinearSpectral3D(StepGraphMixin):
         bd2 = mesh.boundary_facets([getattr(mesh, "absorbing_tag", 3)])
         D, G_d, detJ_d, (dF1_d, dF2_d) = device_geometry(mesh, P, ft, dev, (bd1, bd2))
         self.D = D
-        rho = np.full(nc, self.rho0, dtype=ft)
-        c = np.full(nc, self.c0, dtype=ft)
+        rho, c = rho_cells.astype(ft), c_cells.astype(ft)
+        if reference_speed_of_sound is not None:
+            self.c0 = float(reference_speed_of_sound)
+        elif np.ndim(speed_of_sound) == 0:
+            self.c0 = float(speed_of_sound)
+        elif bd1.shape[0]:
+            self.c0 = float(c_cells[bd1[:, 0]].mean())
         td = lambda a: torch.from_numpy(np.ascontiguousarray(a)).to(dev)  # noqa: E731
         self.cell_coeff1 = td(1.0 / rho / c / c)  # :336
         self.cell_coeff2 = td(-1.0 / rho)  # :337

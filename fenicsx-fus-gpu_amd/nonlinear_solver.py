@@ -33,16 +33,34 @@ class WesterveltSpectral3D(StepGraphMixin):
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
                  source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
                  attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False,
-                 in_kernel_geometry=False, uniform_ratio="auto", halo_plan=None, defer_setup_exchange=False):
+                 in_kernel_geometry=False, uniform_ratio="auto", halo_plan=None, defer_setup_exchange=False,
+                 reference_speed_of_sound=None, reference_density=None):
+        """``speed_of_sound``, ``density``, ``nonlinear_coefficient``, ``attenuation_coefficient_dB``: scalars, or one value per
+        cell in the caller's cell order (the DG0 material arrays of cuda/demo_nonlinear_bowl.py:166-178 -- water / skull / ...).
+        ``reference_speed_of_sound`` / ``reference_density``: the scalars of the source term and of the default source amplitude
+        (the reference uses those of the coupling medium); default: the scalars given, or the means over the source-facet cells.
+        A heterogeneous medium takes the two-gather cell pass by itself (c4 / c3 = delta / c^2 is no longer uniform)."""
+        from .linear_solver import per_cell
+
         self.mesh, self.P = mesh, mesh.P
         ft = np.dtype(float_type)
         self.tdt_np = ft
         self.tdt = _lib.torch_dtype(ft)
-        self.c0, self.rho0, self.f0 = float(speed_of_sound), float(density), float(source_frequency)
-        self.p0 = float(source_amplitude) if source_amplitude is not None else self.rho0 * self.c0 * 0.38557513826589934
+        c_cells, rho_cells = per_cell(speed_of_sound, mesh, "speed_of_sound"), per_cell(density, mesh, "density")
+        beta_cells = per_cell(nonlinear_coefficient, mesh, "nonlinear_coefficient")
+        att_cells = per_cell(attenuation_coefficient_dB, mesh, "attenuation_coefficient_dB")
+        self.f0 = float(source_frequency)
         self.w0 = 2 * np.pi * self.f0
-        self.beta = float(nonlinear_coefficient)
-        self.delta = compute_diffusivity_of_sound(self.w0, self.c0, attenuation_coefficient_dB)
+        src = mesh.boundary_facets([getattr(mesh, "source_tag", 2)])
+        pick = (lambda a: float(a[src[:, 0]].mean())) if src.shape[0] else (lambda a: float(a.mean()))
+        self.c0 = float(reference_speed_of_sound) if reference_speed_of_sound is not None else (
+            float(speed_of_sound) if np.ndim(speed_of_sound) == 0 else pick(c_cells))
+        self.rho0 = float(reference_density) if reference_density is not None else (
+            float(density) if np.ndim(density) == 0 else pick(rho_cells))
+        self.p0 = float(source_amplitude) if source_amplitude is not None else self.rho0 * self.c0 * 0.38557513826589934
+        self.beta = float(beta_cells.mean())
+        delta_cells = compute_diffusivity_of_sound(self.w0, c_cells, att_cells)
+        self.delta = float(delta_cells.mean())
         self.source_time = source_time
         self.fused = bool(fused)
         P, n = self.P, self.P + 1
@@ -52,8 +70,7 @@ class WesterveltSpectral3D(StepGraphMixin):
         # tagged facet sets: source / absorbing (a structured box: its x = 0 / x = L faces; dolfinx_adaptor.ArrayMesh: facet tags)
         bd1, bd2 = mesh.boundary_facets([getattr(mesh, "source_tag", 2)]), mesh.boundary_facets([getattr(mesh, "absorbing_tag", 3)])
         D, G_d, detJ_d, (dF1_d, dF2_d) = device_geometry(mesh, P, ft, dev, (bd1, bd2))
-        rho, c = np.full(nc, self.rho0), np.full(nc, self.c0)
-        beta, delta = np.full(nc, self.beta), np.full(nc, self.delta)
+        rho, c, beta, delta = rho_cells, c_cells, beta_cells, delta_cells
         td = lambda a: torch.from_numpy(np.ascontiguousarray(np.asarray(a, dtype=ft))).to(dev)  # noqa: E731
         # cuda/demo_nonlinear_bowl.py:357-374
         self.cc1 = td(1.0 / rho / c / c)

@@ -37,7 +37,7 @@ def step_sizes(t0, tf, dt):
 
 
 def solve(mesh, nsteps, dt, c0=1500.0, rho0=1000.0, f0=0.5e6, p0=60000.0, source_time="tn", oracle_c=None, threads=1, timing=None,
-          geometry=None):
+          geometry=None, c_ref=None):
     """``dt`` may be a sequence of per-step sizes (then ``nsteps`` is ignored).  ``oracle_c``: the C restatement of the
     operators instead of the numpy one (``threads`` > 1: its OpenMP stiffness apply).  ``timing``: a dict that receives
     ``seconds_per_step`` (the time loop alone, set-up excluded -- what the reference prints as "Solve time per step").
@@ -62,8 +62,12 @@ def solve(mesh, nsteps, dt, c0=1500.0, rho0=1000.0, f0=0.5e6, p0=60000.0, source
         pre.compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dpf, w2)
         pre.compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dpf, w2)
     fd1, fd2 = mesh.facet_dofmap(bd1), mesh.facet_dofmap(bd2)
-    cc1, cc2 = np.full(nc, 1 / rho0 / c0 / c0), np.full(nc, -1 / rho0)
-    fc1, fc2 = np.full(bd1.shape[0], 1 / rho0), np.full(bd2.shape[0], -1 / rho0 / c0)
+    # c0 / rho0: scalars or one value per cell (heterogeneous medium); the source term uses the scalar ``c_ref``
+    c_ref = float(c0) if np.ndim(c0) == 0 else (float(np.asarray(c0)[bd1[:, 0]].mean()) if c_ref is None else float(c_ref))
+    c_, rho_ = (np.broadcast_to(np.asarray(a, dtype=np.float64), (nc,)).copy() for a in (c0, rho0))
+    cc1, cc2 = 1 / rho_ / c_ / c_, -1 / rho_
+    fc1, fc2 = 1 / rho_[bd1[:, 0]], -1 / rho_[bd2[:, 0]] / c_[bd2[:, 0]]
+    c0 = c_ref
     nd = mesh.ndofs
     w0 = 2 * np.pi * f0
     m = np.zeros(nd)
@@ -109,14 +113,19 @@ def solve(mesh, nsteps, dt, c0=1500.0, rho0=1000.0, f0=0.5e6, p0=60000.0, source
 
 
 def solve_westervelt(mesh, nsteps, dt, c0=1480.0, rho0=1000.0, f0=1.1e6, p0=None, beta=3.5, att_dB=0.2,
-                     source_time="tn", oracle_c=None):
+                     source_time="tn", oracle_c=None, c_ref=None, rho_ref=None):
     """cuda/demo_nonlinear_bowl.py:357-374,458-475,540-650 restated with the oracle's operators
     (single rank; source on x = 0, absorbing on x = L)."""
     gll, pre = pkg("gll"), pkg("precompute")
     P, n = mesh.P, mesh.P + 1
+    # c0, rho0, beta, att_dB: scalars or one value per cell; the source term and the default amplitude use scalars (c_ref, rho_ref)
+    bd_src = mesh.boundary_facets([2])
+    c_ref = float(c0) if np.ndim(c0) == 0 else (float(np.asarray(c0)[bd_src[:, 0]].mean()) if c_ref is None else float(c_ref))
+    rho_ref = float(rho0) if np.ndim(rho0) == 0 else (float(np.asarray(rho0)[bd_src[:, 0]].mean()) if rho_ref is None else float(rho_ref))
     if p0 is None:
-        p0 = rho0 * c0 * 0.38557513826589934
+        p0 = rho_ref * c_ref * 0.38557513826589934
     w0 = 2 * np.pi * f0
+    c0, rho0, beta, att_dB = (np.broadcast_to(np.asarray(a, dtype=np.float64), (mesh.ncells,)).copy() for a in (c0, rho0, beta, att_dB))
     delta = 2 * (att_dB / 20 * np.log(10)) * c0**3 / w0 / w0
     pts, wts, D = gll.tabulate_1d(P)
     w3 = gll.tensor_weights_3d(wts)
@@ -131,13 +140,15 @@ def solve_westervelt(mesh, nsteps, dt, c0=1480.0, rho0=1000.0, f0=1.1e6, p0=None
     pre.compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dpf, w2)
     pre.compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dpf, w2)
     fd1, fd2 = mesh.facet_dofmap(bd1), mesh.facet_dofmap(bd2)
-    cc1 = np.full(nc, 1 / rho0 / c0**2)
-    cc2 = np.full(nc, -2 * beta / rho0**2 / c0**4)
-    cc3 = np.full(nc, -1 / rho0)
-    cc4 = np.full(nc, -delta / rho0 / c0**2)
-    cc5 = np.full(nc, 2 * beta / rho0**2 / c0**4)
-    f11, f21 = np.full(bd1.shape[0], 1 / rho0), np.full(bd1.shape[0], delta / rho0 / c0**2)
-    f12, f22 = np.full(bd2.shape[0], delta / rho0 / c0**3), np.full(bd2.shape[0], -1 / rho0 / c0)
+    cc1 = 1 / rho0 / c0**2
+    cc2 = -2 * beta / rho0**2 / c0**4
+    cc3 = -1 / rho0
+    cc4 = -delta / rho0 / c0**2
+    cc5 = 2 * beta / rho0**2 / c0**4
+    i1, i2 = bd1[:, 0], bd2[:, 0]
+    f11, f21 = 1 / rho0[i1], delta[i1] / rho0[i1] / c0[i1] ** 2
+    f12, f22 = delta[i2] / rho0[i2] / c0[i2] ** 3, -1 / rho0[i2] / c0[i2]
+    c0 = c_ref  # from here on: the scalar of the source term
     nd = mesh.ndofs
     ones = np.ones(nd)
     m0 = np.zeros(nd)

@@ -355,3 +355,32 @@ def test_linear_solver_steps_array_meshes_two_in_process_ranks(transport):
     for (am, box), s in zip(pairs, solvers):
         lex = box.global_lexicographic_ids()[: box.nlocal]
         assert rel_l2(s.u_sol(), u_ref[lex]) < 1e-11
+
+
+@pytest.mark.gpu
+def test_array_mesh_heterogeneous_materials_follow_the_cell_order():
+    """Per-cell material arrays are given in the CALLER's cell order; ``ArrayMesh`` re-orders its cells and the solver permutes
+    the arrays with them: the scrambled mesh with the scrambled arrays reproduces the structured run."""
+    import torch
+
+    torch.cuda.set_device(0)
+    ls = pkg("linear_solver")
+    P, cells, L = 3, (6, 3, 3), 0.012
+    am, box = scrambled_array_mesh(P, cells, seed=6, L=L)
+    xc = box.x_g[box.x_dofs].mean(axis=1)[:, 0]
+    bone = (xc > L / 3) & (xc < 2 * L / 3)
+    c_box, rho_box = np.where(bone, 2800.0, 1480.0), np.where(bone, 1850.0, 1000.0)
+    # the caller's (scrambled) cell order: identify each of the caller's cells by its dofs
+    key = {tuple(row): i for i, row in enumerate(box.dofmap)}
+    caller_dofmap = np.empty_like(am.dofmap)
+    caller_dofmap[am.cell_permutation] = am.dofmap  # ArrayMesh cell c is the caller's cell cell_permutation[c]
+    to_box = np.array([key[tuple(r)] for r in caller_dofmap])
+    h = ls.time_step_parameters(box, P, 2800.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 2800.0, 0.5e6, L)
+    out = []
+    for mesh, c, rho in ((box, c_box, rho_box), (am, c_box[to_box], rho_box[to_box])):
+        s = ls.LinearSpectral3D(mesh, np.float64, speed_of_sound=c, density=rho, fused=True)
+        s.init()
+        s.rk4(0.0, tf, dt, max_steps=10)
+        out.append(s.u_sol())
+    assert np.max(np.abs(out[0])) > 0 and rel_l2(out[1], out[0]) < 1e-12

@@ -543,3 +543,60 @@ def test_config5_full_degree_westervelt_fused_vs_reference_sequence():
     for name in ("fused", "fused-geom"):
         assert rel_l2(res[name][0], res["reference"][0]) < 1e-11, name
         assert rel_l2(res[name][1], res["reference"][1]) < 1e-11, name
+
+
+def _two_materials(mesh, L):
+    """Per-cell material arrays of a two-material box: a slab of 'bone' (faster, denser, more absorbing, more nonlinear) across
+    the middle third in x, 'water' around it (the DG0 arrays of the reference's production drivers, cuda/demo_nonlinear_bowl.py:166-178)."""
+    xc = mesh.x_g[mesh.x_dofs].mean(axis=1)[:, 0]
+    bone = (xc > L / 3) & (xc < 2 * L / 3)
+    assert 0 < bone.sum() < mesh.ncells
+    return dict(c=np.where(bone, 2800.0, 1480.0), rho=np.where(bone, 1850.0, 1000.0), beta=np.where(bone, 5.0, 3.5), att=np.where(bone, 2.0, 0.2))
+
+
+@pytest.mark.parametrize("fused", [False, True], ids=["reference-sequence", "fused"])
+def test_linear_solver_heterogeneous_medium(oracle_c, fused):
+    """Per-cell speed of sound and density (scalars everywhere before round 4): the GPU solver, both stage implementations,
+    against the oracle-side loop with the same arrays; the source term uses the coupling medium's scalar speed."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls = pkg("boxmesh"), pkg("linear_solver")
+    P, cells, L = 3, (6, 3, 3), 0.012
+    mesh = boxmesh.BoxMesh(P, cells, length=L, perturb=0.1, seed=2)
+    mat = _two_materials(mesh, L)
+    h = ls.time_step_parameters(mesh, P, 2800.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 2800.0, 0.5e6, L)
+    s = ls.LinearSpectral3D(mesh, np.float64, speed_of_sound=mat["c"], density=mat["rho"], fused=fused)
+    assert abs(s.c0 - 1480.0) < 1e-12  # the source facets lie in the water
+    s.init()
+    s.rk4(0.0, tf, dt, max_steps=12)
+    u_ref, v_ref = rk4_oracle.solve(mesh, 12, dt, c0=mat["c"], rho0=mat["rho"], oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 0
+    assert rel_l2(s.u_sol(), u_ref) < 1e-11 and rel_l2(s.v_sol(), v_ref) < 1e-11
+    with pytest.raises(ValueError):
+        ls.LinearSpectral3D(mesh, np.float64, speed_of_sound=mat["c"][:-1])
+
+
+@pytest.mark.parametrize("variant", ["reference-sequence", "fused", "fused-in-kernel-geometry"])
+def test_westervelt_solver_heterogeneous_medium(oracle_c, variant):
+    """Per-cell c, rho, beta and attenuation: c4 / c3 = delta / c^2 is not uniform any more, so the fused stage takes the
+    two-gather cell pass by itself; against the oracle-side Westervelt loop with the same arrays."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, nls = pkg("boxmesh"), pkg("linear_solver"), pkg("nonlinear_solver")
+    P, cells, L = 4, (6, 2, 2), 0.006
+    mesh = boxmesh.BoxMesh(P, cells, length=L, warp=_bowl_warp)
+    mat = _two_materials(mesh, L)
+    h = ls.time_step_parameters(mesh, P, 2800.0, 1.1e6, L)
+    dt, tf, _ = ls.snap_time_step(h, P, 2800.0, 1.1e6, L)
+    s = nls.WesterveltSpectral3D(mesh, np.float64, speed_of_sound=mat["c"], density=mat["rho"], nonlinear_coefficient=mat["beta"],
+                                 attenuation_coefficient_dB=mat["att"], fused=variant != "reference-sequence",
+                                 in_kernel_geometry=variant.endswith("geometry"))
+    assert s.kappa is None and abs(s.c0 - 1480.0) < 1e-12 and abs(s.rho0 - 1000.0) < 1e-12
+    s.init()
+    s.rk4(0.0, tf, dt, max_steps=10)
+    u_ref, v_ref = rk4_oracle.solve_westervelt(mesh, 10, dt, c0=mat["c"], rho0=mat["rho"], beta=mat["beta"], att_dB=mat["att"], oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 0
+    assert rel_l2(s.u_sol(), u_ref) < 1e-11 and rel_l2(s.v_sol(), v_ref) < 1e-11
