@@ -128,7 +128,7 @@ for a_ in sys.argv[3:]:
         import bench as bench_py
 
         geo = "geometry" in key
-        files = ("plan.hpp", "stiffness.hpp", "stiffness_plan.hpp") + (("stiffness_geom.hpp",) if geo else ()) + ("mass.hpp", "rk4.hpp")
+        files = ("plan.hpp", "stiffness.hpp", "stiffness_plan.hpp") + (("stiffness_geom.hpp",) if geo else ()) + ("mass.hpp", "rk4.hpp", "vecops.hpp")
         latest_path = os.path.join(out, "traffic_latest.json")
         latest = json.load(open(latest_path))
         latest.setdefault("aux", {})[key] = {
