@@ -213,3 +213,19 @@ def test_default_line_carries_the_aux_entries():
     assert aux["rk4_step"]["roofline"]["algorithmic_bytes_per_step"] > 0
     assert aux["stiffness_in_kernel_geometry"]["roofline"]["algorithmic_bytes_per_cell"] == 2100
     assert out["cpu_baseline"]["value"] > 0 and out["roofline"]["frac"] > 0
+
+
+@pytest.mark.gpu
+def test_time_scatterer_script():
+    """fenicsx-fus-gpu_amd/time_scatterer.py: the reference's numba-cpu/time_scatterer.py protocol (50 / 10 timed calls, mean +/-
+    std) -- a rank that is its own neighbour with config-4 messages, and the one-rank no-neighbour case the reference runs on a
+    single MPI rank."""
+    script = os.path.join(ROOT, "fenicsx-fus-gpu_amd", "time_scatterer.py")
+    for extra in (["--self-neighbour"], []):
+        r = subprocess.run([sys.executable, script, *extra], env=_env(), capture_output=True, text=True, timeout=600)
+        assert r.returncode == 0, (r.stdout + r.stderr)[-2000:]
+        lines = [l for l in r.stdout.splitlines() if l.startswith("Elapsed time")]
+        assert len(lines) == 2 and "scatter reverse" in lines[0] and "scatter forward" in lines[1]
+        for l in lines:
+            mean = float(l.split(":")[1].split("±")[0])
+            assert 0 < mean < 1e-3, l  # microseconds, not milliseconds
