@@ -229,3 +229,16 @@ def test_time_scatterer_script():
         for l in lines:
             mean = float(l.split(":")[1].split("±")[0])
             assert 0 < mean < 1e-3, l  # microseconds, not milliseconds
+
+
+@pytest.mark.gpu
+def test_config4_topology_rehearsal_tool():
+    """tools/rehearse_8_ranks.py at a small size: the 2x2x2 partition as 8 ranks on 4 real processes x 2 ranks over the PEER
+    transport, with bench.py's halo checks (exact ghosts, owned sums = 1^T K x = 0, no failed device-side wait)."""
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "rehearse_8_ranks.py"), "--cells", "6", "--applies", "2"], env=_env(),
+                       capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    assert out["ok"] is True and out["ranks"] == 8 and out["processes"] == 4 and out["failed_device_waits"] == 0
+    assert out["forward_max_abs_err"] == 0.0 and out["owned_sum_defect_over_sum_abs"] < 1e-9
+    assert sorted(out["rank0_ghosted_by"]) == [str(k) for k in range(1, 8)] and out["rank0_ghosted_by"]["7"] == 1
