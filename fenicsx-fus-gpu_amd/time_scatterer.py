@@ -51,10 +51,7 @@ def main():
     else:
         comm = scat.NativeComm(transport={"peer": "peer", "native": "rccl"}.get(os.environ.get("FUS_HALO", "peer"), "peer"))
         if a.self_neighbour:
-            sys.path.insert(0, ROOT)
-            import bench
-
-            owners_data, ghosts_data, nlocal = bench.config4_self_plan(a.degree * 54 + 1)
+            owners_data, ghosts_data, nlocal = utils.config4_self_plan(a.degree * 54 + 1)
             ndofs = nlocal + int(owners_data[1][0])
         else:  # one rank, no neighbours: the exchanges are no-ops (the reference on one MPI rank is, too)
             mesh = boxmesh.BoxMesh(a.degree, a.cells, dtype=ft)

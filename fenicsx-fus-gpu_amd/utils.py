@@ -150,3 +150,22 @@ def boundary_first_cell_order(dofmap, nlocal):
     touches = (dm >= nlocal).any(axis=1)
     perm = np.concatenate((np.nonzero(touches)[0], np.nonzero(~touches)[0]))
     return perm, int(touches.sum())
+
+
+def config4_self_plan(n1, permuted=False, seed=0):
+    """Halo plan of ONE rank of BASELINE config 4 (2x2x2 blocks of 54^3 P = 4 cells) that is its own neighbour: the three low
+    faces of its n1^3 lexicographic block (one contiguous plane, one plane of runs of n1, one plane of stride n1), three
+    edges and the corner -- 3 x 47 089 + 3 x 217 + 1 elements, 1.14 MB per direction.  Returns (owners_data, ghosts_data, N)."""
+    ng = 3 * n1 * n1 + 3 * n1 + 1
+    N = n1**3 - ng
+    rng = np.random.default_rng(seed)
+    ii, jj = np.meshgrid(np.arange(n1), np.arange(n1), indexing="ij")
+    lex = lambda i, j, k: ((i * n1 + j) * n1 + k).reshape(-1)  # noqa: E731
+    z0 = np.zeros_like(ii)
+    ar, zr = np.arange(n1), np.zeros(n1, dtype=np.int64)
+    g_idx = np.concatenate([lex(z0, ii, jj), lex(ii, z0, jj), lex(ii, jj, z0), lex(zr, zr, ar), lex(zr, ar, zr), lex(ar, zr, zr),
+                            np.array([0])]).astype(np.int64) % N
+    o_idx = rng.permutation(ng).astype(np.int64) if permuted else np.arange(ng, dtype=np.int64)
+    od = [o_idx, np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+    gd = [g_idx, np.array([ng]), np.array([0, ng]), np.array([0], dtype=np.int32)]
+    return od, gd, N
