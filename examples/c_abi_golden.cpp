@@ -298,7 +298,7 @@ int main(int argc, char** argv) {
     for (int64_t i = 0; i < ng; ++i) ref[g_idx[i]] += v[N + o_idx[i]];
     report((std::string("halo reverse (") + tname + ")").c_str(), rel_l2(got, ref.data()), 1e-15);
     if (transport == 1) {
-      int64_t st[4] = {-1, -1, -1, -1}, sync_to = -1;
+      int64_t st[8] = {-1, -1, -1, -1, -1, -1, -1, -1}, sync_to = -1;
       CHECK_FUS(fus_halo_ipc_status(halo, st));
       CHECK_FUS(fus_comm_sync_timeouts(comm, &sync_to));
       report("PEER transport: device-side waits that timed out", (double)(st[0] + sync_to), 0.5);
