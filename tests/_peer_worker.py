@@ -330,6 +330,41 @@ def hybrid(args, proc, nproc, dev):
         dist.barrier()
         del halos
         return
+    if what == "westervelt":
+        # the fused Westervelt solver (BASELINE config 5's loop: set-up scatter of the three assembled diagonals, per stage the
+        # grouped forward scatter of (w, v_n) and the reverse of b) on the partition == the one-rank solver
+        nls = pkg("nonlinear_solver")
+        L = 0.012
+        geom = len(args) > 10 and args[10] == "geom"
+        kw = dict(speed_of_sound=1500.0, source_frequency=0.5e6, fused=True, in_kernel_geometry=geom)
+        wmesh = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r, length=L, perturb=0.1, seed=6, ghost_order=ghost_order) for r in range(R)]
+        odw, gdw = utils.compute_scatterer_data_all([m.index_map for m in wmesh])
+        commsw = [scat.NativeComm(local=(4444, R, r), transport="peer", hosted=mine) for r in mine]
+        solvers = [nls.WesterveltSpectral3D(wmesh[r], np.float64, comm=c, halo_plan=(odw[r], gdw[r]), defer_setup_exchange=True, **kw)
+                   for r, c in zip(mine, commsw)]
+        lockstep([s_._setup for s_ in solvers])
+        one = boxmesh.BoxMesh(P, cells, length=L, perturb=0.1, seed=6)
+        h = ls.time_step_parameters(one, P, 1500.0, 0.5e6, L)
+        dts, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L)
+        for s_ in solvers:
+            s_.init()
+        lockstep([s_.rk4_schedule(0.0, tf, dts, max_steps=4) for s_ in solvers])
+        torch.cuda.synchronize()
+        for s_ in solvers:
+            s_.check_halo_health("hybrid Westervelt solver")
+        assert all(s_.halo.schedule_kind == "concurrent" for s_ in solvers)
+        ref = nls.WesterveltSpectral3D(one, np.float64, **kw)
+        ref.init()
+        ref.rk4(0.0, tf, dts, max_steps=4)
+        u_ref, v_ref = ref.u_sol(), ref.v_sol()
+        assert np.abs(u_ref).max() > 0
+        for r, s_ in zip(mine, solvers):
+            lex = wmesh[r].global_lexicographic_ids()[: wmesh[r].nlocal]
+            eu, ev = rel_l2(s_.u_sol(), u_ref[lex]), rel_l2(s_.v_sol(), v_ref[lex])
+            assert eu < 1e-11 and ev < 1e-11, f"rank {r}: partitioned Westervelt solver vs one-rank solver u {eu} v {ev}"
+        dist.barrier()
+        del solvers
+        return
     # the fused linear solver on the same partition (set-up reverse scatter, grouped forward scatters of (u_n, v_n), reverse
     # of b, concurrent schedule with the fork / join folded into the exchange kernels) == the one-rank solver
     L = (0.012, 0.012, 0.012)

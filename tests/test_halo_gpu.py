@@ -441,6 +441,20 @@ def test_peer_transport_8_ranks_2x2x2_on_4_processes(gpu, P, cells, grid, ghost_
     _run_peer_world(R // rpp, "hybrid", [P, *cells, *grid, ghost_order, rpp, what], timeout=600)
 
 
+@pytest.mark.parametrize("P,cells,grid,ghost_order,rpp,geom", [
+    (3, (4, 4, 4), (2, 2, 2), 7, 2, ""),
+    (3, (4, 4, 4), (2, 2, 2), "owner", 2, "geom"),
+    (4, (4, 3, 3), (2, 1, 1), 5, 1, ""),
+], ids=["8ranks-4procs-general-G", "8ranks-4procs-in-kernel-geometry", "2procs-general-G"])
+def test_peer_transport_westervelt_solver_real_processes(gpu, P, cells, grid, ghost_order, rpp, geom):
+    """BASELINE config 5's loop (fused Westervelt solver: set-up scatter of three assembled diagonals, grouped forward scatter
+    of (w, v_n) and reverse of b per stage, concurrent schedule) over the PEER transport with REAL processes: the 2x2x2 world
+    as 4 processes of 2 ranks, and 2 processes of one rank each; 4 steps == the one-rank solver (itself pinned to the
+    reference-driven loop, tests/test_rk4_golden.py)."""
+    R = int(np.prod(grid))
+    _run_peer_world(R // rpp, "hybrid", [P, *cells, *grid, ghost_order, rpp, "westervelt"] + ([geom] if geom else []), timeout=600)
+
+
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("direct", [True, False], ids=["direct", "permuted"])
 @pytest.mark.parametrize("transport", ["rccl", "peer"])
