@@ -3,9 +3,9 @@
 protocol -- warm-up, 10 timed reps of the cell mass, stiffness and boundary-facet mass applies,
 mean +/- std, b zeroed outside the timed region (:181-187, 227-233, 254-260) -- run with the
 ORACLE's C restatement of the reference's numba-cpu operators (numba is not installed anywhere in
-this pipeline).  Single thread, as the reference (njit without parallel=True).
+this pipeline).  Part of the oracle (test / baseline infrastructure, not product code).  Single thread, as the reference (njit without parallel=True).
 
-    python tools/time_operators_cpu.py [--degree 2 --cells 18] [--threads 1]
+    python oracle/time_operators_cpu.py [--degree 2 --cells 18] [--threads 1]
 """
 import argparse
 import os
