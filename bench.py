@@ -383,19 +383,25 @@ def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, o
         detJ, (torch.from_numpy(mesh.x_dofs).to(device), torch.from_numpy(mesh.x_g).to(device)), mesh.ncells,
         torch.from_numpy(dphi_g).to(device), torch.from_numpy(wts3).to(device))
     mop = ops.mass_operator(n**3, dt)
+    kname = ops.mass_kernel_name(dm_d, mesh.ndofs)
     K = max(1, args.steps)
-    for _ in range(3):
-        mop(x_d, cc_d, y_d, detJ, dm_d)
-    torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    t0 = time.perf_counter()
-    e0.record()
-    for _ in range(K):
-        mop(x_d, cc_d, y_d, detJ, dm_d)
-    e1.record()
-    torch.cuda.synchronize()
-    wall_ms = (time.perf_counter() - t0) / K * 1e3
-    ms = e0.elapsed_time(e1) / K
+
+    def timed(fn):
+        for _ in range(3):
+            fn(x_d, cc_d, y_d, detJ, dm_d)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        e0.record()
+        for _ in range(K):
+            fn(x_d, cc_d, y_d, detJ, dm_d)
+        e1.record()
+        torch.cuda.synchronize()
+        return (time.perf_counter() - t0) / K * 1e3, e0.elapsed_time(e1) / K
+
+    # the float-atomic batch-plan kernel beside it (what the sub-launches of a partitioned apply use)
+    _, atomic_ms = timed(mop.atomic)
+    wall_ms, ms = timed(mop)
     bpc = mass_bytes_per_cell(P, T)
     achieved = mesh.ncells * bpc / (ms * 1e-3) / 1e9
     traffic, traffic_source = None, "no PMC pass of the mass kernel in profiles/traffic_latest.json"
@@ -403,7 +409,10 @@ def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, o
         with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
             tm = json.load(f).get("aux", {}).get("mass")
         if tm and int(tm["P"]) == P and int(tm["ncell"]) == mesh.ncells and tm.get("dtype", "f64") == args.dtype:
-            if tm.get("kernel_src_sha") == kernel_src_sha(("plan.hpp", "mass.hpp")) and lib_built_from_tree():
+            files = tuple(tm.get("kernel_src_files", ("plan.hpp", "mass.hpp")))
+            if tm.get("kernel", "fus::mass_plan_kernel") != kname:
+                traffic_source = f"the profiled kernel was {tm.get('kernel', 'fus::mass_plan_kernel')}, this run launches {kname}"
+            elif tm.get("kernel_src_sha") == kernel_src_sha(files) and lib_built_from_tree():
                 traffic = float(tm["hbm_bytes_per_launch"])
                 traffic_source = f"replayed from {tm['source']} (rocprofv3 --pmc; same kernel sources and compile flags)"
             else:
@@ -412,9 +421,11 @@ def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, o
         pass
     out = {"metric": "mass_apply_dof_per_s", "value": mesh.ndofs_global / (wall_ms * 1e-3), "unit": "DOF/s", "ms_per_step": wall_ms, "steps": K,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
-                        "traffic": traffic, "traffic_source": traffic_source, "kernel": "fus::mass_plan_kernel", "kernel_ms": ms,
+                        "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "kernel_ms": ms,
                         "kernel_ms_how": "one HIP-event pair around K back-to-back launches / K",
-                        "algorithmic_bytes_per_cell": bpc, "cells_per_launch": mesh.ncells},
+                        "algorithmic_bytes_per_cell": bpc, "cells_per_launch": mesh.ncells,
+                        "atomic_kernel": "fus::mass_plan_kernel", "atomic_kernel_ms": atomic_ms,
+                        "atomic_kernel_frac": mesh.ncells * bpc / (atomic_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "cpu_baseline": None}
     if x_host is not None:
         out["cpu_baseline"] = cpu_baseline_mass(P, mesh, x_host.astype(np.float64), cc_host.astype(np.float64), detJ.cpu().numpy().astype(np.float64))
@@ -940,6 +951,9 @@ def main():
                          "libfusgpu.so (default); native = grouped ncclSend/ncclRecv issued by libfusgpu.so; torch = "
                          "torch.distributed all_to_all_single.  A transport that does not come up on every rank or "
                          "fails the run's halo check is replaced by the next one (peer -> native -> torch)")
+    ap.add_argument("--mass-atomic", action="store_true",
+                    help="--mode mass: the float-atomic batch-plan kernel instead of the atomic-free transposed-dofmap kernel (what a "
+                         "partitioned apply uses anyway: its sub-launches and the reverse exchange add into one y concurrently)")
     ap.add_argument("--exclusive", action="store_true",
                     help="--mode mass: the batch plan carries exclusive-dof marks (plain load + store instead of an atomic for dofs "
                          "one batch touches alone; opt-in, measured slower from P = 4 up: profiles/r04d_ab_mass_exclusive_marks.log)")
@@ -1075,7 +1089,7 @@ def main():
         def op(x_, cc_, y_, detJ_, dm_):
             dmo(x_, y_)
     elif mass:
-        op = ops.mass_operator(n**3, dt, exclusive=args.exclusive)
+        op = ops.mass_operator(n**3, dt, exclusive=args.exclusive, atomic=args.mass_atomic or args.exclusive)
     else:
         op = ops.stiffness_operator(P, D.flatten(), dt)
 
@@ -1265,7 +1279,7 @@ def main():
     elif mass_diag:
         kname = "fus::muladd_kernel"
     elif mass:
-        kname = "fus::mass_plan_kernel" if ops._USE_PLAN else "fus::mass_kernel"
+        kname = ops.mass_kernel_name(dm_d, mesh.ndofs, atomic=args.mass_atomic or args.exclusive or halo is not None)
     else:
         kname = "fus::stiffness_plan_kernel" if ops._USE_PLAN else "fus::stiffness_col_kernel"
 

@@ -227,6 +227,13 @@ int main(int argc, char** argv) {
         mass(d_x, d_cc, d_y);
         CHECK_HIP(fetch_y());
         report("MassSpectral3D<double,4>::operator()", rel_l2(y, g["ref_y_mass"].f64()), tol);
+        // the same functor on the atomic-free kernel (transposed dofmap, fus_mass_apply_gather_*)
+        mass.enable_gather(d_dm, ndofs);
+        if (!mass.gather_enabled()) throw std::runtime_error("the gather plan was declined for a hexahedral dofmap");
+        CHECK_HIP(reset_y());
+        mass(d_x, d_cc, d_y);
+        CHECK_HIP(fetch_y());
+        report("MassSpectral3D<double,4>::operator(), atomic-free kernel", rel_l2(y, g["ref_y_mass"].f64()), tol);
       } catch (const std::exception& e) {
         std::fprintf(stderr, "functor twins: %s\n", e.what());
         ok = false;

@@ -36,6 +36,9 @@ def _signatures():
         "fus_plan_build_ordered": [_vp, _vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_plan_release": [_vp],
         "fus_plan_mark_exclusive": [_vp, _int, _int, _i64, _vp, _i64, _vp],
+        "fus_mass_gather_plan_bytes": [_int, _i64, _i64],
+        "fus_mass_gather_plan_build": [_vp, _int, _i64, _i64, _vp, _i64, _vp],
+        "fus_mass_gather_plan_info": [_vp, _vp],
         "fus_stiffness_plan_build": [_vp, _int, _i64, _vp, _i64, _vp],
         # communicator + halo exchange (csrc/halo_comm.hpp)
         "fus_comm_unique_id": [_vp],
@@ -79,6 +82,7 @@ def _signatures():
         sig[f"fus_stiffness_apply_planned_geom_{suf}"] = [_vp] * 9 + [_int, _i64, _vp]
         sig[f"fus_mass_apply_planned_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _int, _i64, _vp]
         sig[f"fus_mass_apply_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
+        sig[f"fus_mass_apply_gather_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp]
         sig[f"fus_facet_terms_{suf}"] = [_vp, _vp, ct, _vp, ct, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _vp]
         sig[f"fus_facet_terms_dev_{suf}"] = [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _vp, _vp, _vp, _vp, _i64, _int, _vp]
         sig[f"fus_axpy_{suf}"] = [ct, _vp, _vp, _i64, _vp]
@@ -136,6 +140,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = {"fus_stiffness_plan_bytes": _i64, "fus_plan_bytes": _i64, "fus_comm_stream": _vp,
+                      "fus_mass_gather_plan_bytes": _i64,
                       "fus_halo_ipc_blob_bytes": _i64, "fus_comm_last_error": C.c_char_p}.get(name, _int)
     lib.fus_error_string.argtypes = [_int]
     lib.fus_error_string.restype = C.c_char_p
@@ -149,6 +154,7 @@ def load():
 
 
 ERR_COMM = -5
+ERR_UNSUPPORTED_ENTITY = -3
 
 
 def tree_source_hash():

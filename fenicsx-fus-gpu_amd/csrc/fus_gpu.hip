@@ -14,6 +14,7 @@
 #include "halo.hpp"
 #include "halo_comm.hpp"
 #include "mass.hpp"
+#include "mass_gather.hpp"
 #include "plan.hpp"
 #include "rk4.hpp"
 #include "stiffness.hpp"
@@ -75,6 +76,9 @@ bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, boo
   if (exclusive) *exclusive = p.exclusive;
   return true;
 }
+
+// transposed-dofmap plans of the atomic-free mass apply (csrc/mass_gather.hpp), keyed by workspace address
+std::unordered_map<const void*, fus::GatherHeader> g_gather_plans;
 
 inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
 
@@ -339,6 +343,22 @@ int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const v
   return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>(N), excl));
 }
 
+template <typename T>
+int mass_apply_gather(const T* x, const T* c, T* y, const T* detJ, const void* ws, int N, int64_t nent, void* stream) {
+  if (nent < 0 || N < 1) return FUS_ERR_INVALID_ARGUMENT;
+  fus::GatherHeader h{};
+  {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    auto it = g_gather_plans.find(ws);
+    if (it == g_gather_plans.end() || it->second.N != N || it->second.nent != nent) return FUS_ERR_PLAN_MISMATCH;
+    h = it->second;
+  }
+  if (nent == 0) return FUS_OK;
+  if (!x || !c || !y || !detJ) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::launch_mass_gather<T>(x, c, y, detJ, ws, h, static_cast<hipStream_t>(stream),
+                                           g_mass_variant.load(std::memory_order_relaxed)));
+}
+
 }  // namespace
 
 extern "C" {
@@ -462,7 +482,53 @@ int fus_plan_build(const int32_t* dofmap, int N, int entities_per_batch, int64_t
 int fus_plan_release(const void* workspace) {
   std::lock_guard<std::mutex> lk(g_plans_mu);
   g_plans.erase(workspace);
+  g_gather_plans.erase(workspace);
   return FUS_OK;
+}
+
+int64_t fus_mass_gather_plan_bytes(int N, int64_t nent, int64_t ndofs) {
+  if (N < 1 || N > 2048 || nent < 0 || ndofs < 0 || nent * (int64_t)N > (int64_t)INT32_MAX) return FUS_ERR_INVALID_ARGUMENT;
+  fus::GatherHeader h{};
+  fus::gather_layout(nent, N, ndofs, &h);
+  return h.bytes;
+}
+
+int fus_mass_gather_plan_build(const int32_t* dofmap, int N, int64_t nent, int64_t ndofs, void* workspace,
+                               int64_t workspace_bytes, void* stream) {
+  const int64_t need = fus_mass_gather_plan_bytes(N, nent, ndofs);
+  if (need < 0) return (int)need;
+  if (!workspace || misaligned(workspace, 256) || workspace_bytes < need) return FUS_ERR_INVALID_ARGUMENT;
+  if (nent > 0 && !dofmap) return FUS_ERR_INVALID_ARGUMENT;
+  fus::GatherHeader h{};
+  int bad = 0;
+  const hipError_t e = fus::gather_plan_build(dofmap, N, nent, ndofs, workspace, static_cast<hipStream_t>(stream), &h, &bad);
+  if (e != hipSuccess) return hip_rc(e);
+  if (bad) return FUS_ERR_UNSUPPORTED_ENTITY;
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  g_gather_plans[workspace] = h;
+  return FUS_OK;
+}
+
+int fus_mass_gather_plan_info(const void* workspace, int64_t* out4) {
+  if (!workspace || !out4) return FUS_ERR_INVALID_ARGUMENT;
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  auto it = g_gather_plans.find(workspace);
+  if (it == g_gather_plans.end()) return FUS_ERR_PLAN_MISMATCH;
+  out4[0] = it->second.nrows;
+  out4[1] = it->second.dense;
+  out4[2] = it->second.max_len;
+  out4[3] = it->second.bytes;
+  return FUS_OK;
+}
+
+
+int fus_mass_apply_gather_f64(const double* x, const double* c, double* y, const double* detJ, const void* ws, int N,
+                              int64_t nent, void* stream) {
+  return mass_apply_gather<double>(x, c, y, detJ, ws, N, nent, stream);
+}
+int fus_mass_apply_gather_f32(const float* x, const float* c, float* y, const float* detJ, const void* ws, int N,
+                              int64_t nent, void* stream) {
+  return mass_apply_gather<float>(x, c, y, detJ, ws, N, nent, stream);
 }
 
 int fus_plan_build_ordered(const int32_t* dofmap, const int32_t* entity_order, int N, int entities_per_batch,

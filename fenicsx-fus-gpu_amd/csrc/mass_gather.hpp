@@ -1,0 +1,325 @@
+// Mass apply without atomics: the TRANSPOSED dofmap ("which (entity, local index) entries touch dof d"), one thread per
+// touched dof.  Same sum as numba-cpu/operators.py:19-68 / cuda/operators.py:18-70,
+//     y[d] += sum over the entries e = (entity c, local i) with dofmap[c, i] == d of  x[d] * detJ[c, i] * constants[c],
+// and the same bytes (detJ once, one 4-byte index per entry, x once, y read-modify-write once), but every dof is
+// finished by ONE thread: plain coalesced loads / stores of x and y instead of a scattered float atomic per shared
+// dof -- the request rate of those atomics is what bounds mass_plan_kernel at 0.44-0.45 of the HBM roofline (DESIGN
+// 3.4).  The entries of a dof are visited in ascending (entity, local index) order, the order of the reference's serial
+// loop: the result does not depend on scheduling (bitwise reproducible run to run, unlike the atomic kernels).
+//
+// Plan (built once per dofmap on the device, fus_mass_gather_plan_build; lives in a caller-owned workspace):
+//   header | rows[nrows] (touched dofs, ascending; omitted when they are 0..nrows-1) | len[nrows] (uint8: entries of the
+//   row) | block_base[nblocks + 1] (first entry of each 256-row block) | entries[nent * N] (entry ids c * N + i, sorted
+//   by dof, ties ascending)
+// The row pointer of a thread is block_base[block] + the exclusive prefix sum of len[] inside the block (wave scan +
+// one LDS hand-off): 1 byte per dof instead of a 4-byte row pointer.
+#pragma once
+
+#include <hip/hip_runtime.h>
+#include <hipcub/hipcub.hpp>
+#include <stdint.h>
+
+#include <type_traits>
+
+#include "vecops.hpp"
+
+namespace fus {
+
+constexpr int kGatherThreads = 256;
+constexpr int64_t kGatherMagic = 0x4655534d47415431LL;  // "FUSMGAT1"
+constexpr int kGatherHeaderBytes = 256;
+
+struct GatherHeader {
+  int64_t magic, nent, N, nrows, dense, nblocks, bytes, max_len;
+  int64_t off_rows, off_len, off_base, off_entries;
+};
+
+struct GatherView {
+  int64_t nrows, nblocks;
+  const int32_t* rows;  // nullptr: dense (row r is dof r)
+  const uint8_t* len;
+  const int32_t* base;
+  const int32_t* entries;
+};
+
+inline int64_t gather_align(int64_t v) { return (v + 255) / 256 * 256; }
+
+// workspace layout: sizes depend on (nent, N) and on the length of the dof vector (rows <= min(entries, ndofs))
+inline void gather_layout(int64_t nent, int N, int64_t ndofs, GatherHeader* h) {
+  const int64_t total = nent * N;
+  const int64_t maxrows = total < ndofs ? total : ndofs;
+  const int64_t maxblocks = (maxrows + kGatherThreads - 1) / kGatherThreads;
+  h->off_rows = kGatherHeaderBytes;
+  h->off_len = h->off_rows + gather_align(maxrows * 4);
+  h->off_base = h->off_len + gather_align(maxrows);
+  h->off_entries = h->off_base + gather_align((maxblocks + 1) * 4);
+  h->bytes = h->off_entries + gather_align(total * 4);
+}
+
+// R rows per thread (row r0 + k * 256, k < R: every access of a wave stays contiguous).  One row per thread leaves the
+// kernel latency-bound: three dependent loads (len -> entry -> detJ) with ~40 bytes in flight per thread is 3.5 TB/s at
+// full occupancy (0.117 ms at config 3); R rows per thread issue R independent chains (two rows: 0.100-0.104 ms, 56 VGPRs).
+// What was measured and not kept (profiles/r04t_ab_mass_gather.log): a workgroup walking over several blocks and issuing
+// the first-level loads of its next block before chasing the entries of the current one -- slower (0.110-0.117 ms: 74
+// VGPRs, six waves per SIMD); non-temporal loads of the index streams -- slower (0.120: the per-lane strided entry reads
+// live on L1 re-use).  HBM traffic is 1.06 x the algorithmic bytes already (r04t_mass_gather_counters.json); an ablation
+// prices the parts: without the gather of the entity constant 0.097, without the entry indirection (detJ read in row
+// order, 79 MB fewer) 0.084, without both 0.076 -- the kernel pays for its vector-memory instructions, not for bytes.
+template <typename T, int NT, bool DENSE, int R>
+__global__ void __launch_bounds__(kGatherThreads)
+    mass_gather_kernel(const T* __restrict__ x, const T* __restrict__ cc, T* __restrict__ y, const T* __restrict__ detJ,
+                       GatherView v, double inv_n, int chunk, int64_t nkb) {
+  // consecutive blocks of rows stay on one XCD (workgroups are dealt round-robin to the 8 XCDs): neighbouring rows gather
+  // from the same detJ lines, which then hit in that XCD's L2 (natural block order: 0.1065 against 0.1004 ms)
+  const int64_t b = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
+  if (b >= nkb) return;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t r0 = b * (kGatherThreads * R) + threadIdx.x;
+  int len[R], incl[R];
+  int64_t d[R];
+  bool live[R];
+  T xv[R], acc[R];
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    const int64_t r = r0 + k * kGatherThreads;
+    live[k] = r < v.nrows;
+    len[k] = live[k] ? (int)v.len[r] : 0;
+    d[k] = DENSE ? r : (live[k] ? (int64_t)v.rows[r] : 0);
+  }
+#pragma unroll
+  for (int k = 0; k < R; ++k) {
+    xv[k] = live[k] ? ld_stream<NT>(x + d[k]) : T(0);
+    acc[k] = live[k] ? ld_stream<NT>(y + d[k]) : T(0);
+  }
+  // exclusive prefix of len over the workgroup's R * 256 rows (row order: k, wave, lane)
+#pragma unroll
+  for (int k = 0; k < R; ++k) incl[k] = len[k];
+#pragma unroll
+  for (int o = 1; o < 64; o <<= 1) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+      const int up = __shfl_up(incl[k], o, 64);
+      if (lane >= o) incl[k] += up;
+    }
+  }
+  constexpr int NW = kGatherThreads / 64;
+  __shared__ int wsum[R * NW];
+  if (lane == 63) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) wsum[k * NW + wave] = incl[k];
+  }
+  __syncthreads();
+  int64_t beg[R];
+  {
+    int run = 0;
+    const int64_t base = (int64_t)v.base[b * R];
+#pragma unroll
+    for (int k = 0; k < R; ++k) {
+#pragma unroll
+      for (int w = 0; w < NW; ++w) {
+        if (w == wave) beg[k] = base + run + incl[k] - len[k];
+        run += wsum[k * NW + w];
+      }
+    }
+  }
+  // Entries in batches whose loads are all independent (entry ids, then detJ and the constants), predicated per lane; the
+  // sums stay in ascending entry order.  84 % of the dofs of a hexahedral mesh have at most two entries, edge dofs four,
+  // vertex dofs eight: a wave goes on to the next batch only if one of its lanes needs it.
+  int maxlen = len[0];
+#pragma unroll
+  for (int k = 1; k < R; ++k) maxlen = len[k] > maxlen ? len[k] : maxlen;
+  auto batch = [&](auto bc, int j0) {
+    constexpr int B = decltype(bc)::value;
+    uint32_t e[R][B];
+    T dv[R][B], cv[R][B];
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int q = 0; q < B; ++q) e[k][q] = j0 + q < len[k] ? (uint32_t)v.entries[beg[k] + j0 + q] : 0u;
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int q = 0; q < B; ++q) {
+        const bool on = j0 + q < len[k];
+        dv[k][q] = on ? detJ[e[k][q]] : T(0);
+        cv[k][q] = on ? cc[(int)(((double)e[k][q] + 0.5) * inv_n)] : T(0);  // e / N, exact for e < 2^31, N <= 2^11
+      }
+#pragma unroll
+    for (int k = 0; k < R; ++k)
+#pragma unroll
+      for (int q = 0; q < B; ++q)
+        if (j0 + q < len[k]) acc[k] += xv[k] * dv[k][q] * cv[k][q];
+  };
+  batch(std::integral_constant<int, 2>{}, 0);
+  if (__any(maxlen > 2)) batch(std::integral_constant<int, 2>{}, 2);
+  for (int j0 = 4; __any(j0 < maxlen); j0 += 4) batch(std::integral_constant<int, 4>{}, j0);
+#pragma unroll
+  for (int k = 0; k < R; ++k)
+    if (live[k]) st_stream<NT>(y + d[k], acc[k]);
+}
+
+// ---- plan build (device): stable sort of the entries by dof, run lengths, per-block bases
+__global__ void gather_iota_kernel(int32_t* out, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) out[i] = (int32_t)i;
+}
+// sorted keys -> row starts: flag[i] = 1 where a new dof begins
+__global__ void gather_flag_kernel(const int32_t* keys, int32_t* flag, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n) flag[i] = (i == 0 || keys[i] != keys[i - 1]) ? 1 : 0;
+}
+// rowid[i] = inclusive scan of flag - 1; at a row start: rows[rowid] = key, start[rowid] = i
+__global__ void gather_rows_kernel(const int32_t* keys, const int32_t* flag, const int32_t* rowid_incl, int32_t* rows,
+                                   int32_t* start, int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i < n && flag[i]) {
+    const int32_t r = rowid_incl[i] - 1;
+    rows[r] = keys[i];
+    start[r] = (int32_t)i;
+  }
+}
+// len[r] = start[r + 1] - start[r]; base[b] = start[b * 256]; stats: [0] max len, [1] 1 if rows != 0..nrows-1
+__global__ void gather_len_kernel(const int32_t* start, const int32_t* rows, uint8_t* len, int32_t* base, int64_t nrows,
+                                  int64_t total, int64_t nblocks, int32_t* stats) {
+  const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (r < nrows) {
+    const int64_t nxt = r + 1 < nrows ? start[r + 1] : total;
+    const int64_t l = nxt - start[r];
+    len[r] = (uint8_t)(l > 255 ? 255 : l);
+    if (l > 255) atomicMax(stats + 0, 1 << 30);
+    atomicMax(stats + 0, (int32_t)(l > 255 ? 255 : l));
+    if (rows[r] != (int32_t)r) atomicMax(stats + 1, 1);
+    if (r % kGatherThreads == 0) base[r / kGatherThreads] = start[r];
+  }
+  if (r == 0) base[nblocks] = (int32_t)total;
+}
+
+// Builds the plan in ``ws`` (>= gather_layout(...).bytes).  Scratch: hipMallocAsync-free -- three int32 arrays of nent * N
+// and the cub temporaries are carved from a scratch allocation made and released here (set-up path, not the hot path).
+// *bad = 1: a dofmap value outside [0, ndofs) or a dof with more than 255 entries (nothing usable was built)
+inline hipError_t gather_plan_build(const int32_t* dofmap, int N, int64_t nent, int64_t ndofs, void* ws, hipStream_t stream,
+                                    GatherHeader* out, int* bad) {
+  GatherHeader h{};
+  *bad = 0;
+  gather_layout(nent, N, ndofs, &h);
+  const int64_t total = nent * N;
+  char* w = static_cast<char*>(ws);
+  int32_t* rows = reinterpret_cast<int32_t*>(w + h.off_rows);
+  uint8_t* len = reinterpret_cast<uint8_t*>(w + h.off_len);
+  int32_t* base = reinterpret_cast<int32_t*>(w + h.off_base);
+  int32_t* entries = reinterpret_cast<int32_t*>(w + h.off_entries);
+  h.magic = kGatherMagic;
+  h.nent = nent;
+  h.N = N;
+  if (total == 0) {
+    h.nrows = h.nblocks = h.max_len = 0;
+    h.dense = 1;
+    *out = h;
+    const hipError_t e0 = hipMemcpyAsync(ws, &h, sizeof h, hipMemcpyHostToDevice, stream);
+    return e0 != hipSuccess ? e0 : hipStreamSynchronize(stream);
+  }
+  size_t sort_bytes = 0, scan_bytes = 0;
+  hipError_t e = hipcub::DeviceRadixSort::SortPairs(nullptr, sort_bytes, (const int32_t*)nullptr, (int32_t*)nullptr,
+                                                    (const int32_t*)nullptr, (int32_t*)nullptr, (int)total, 0, 32, stream);
+  if (e != hipSuccess) return e;
+  e = hipcub::DeviceScan::InclusiveSum(nullptr, scan_bytes, (const int32_t*)nullptr, (int32_t*)nullptr, (int)total, stream);
+  if (e != hipSuccess) return e;
+  const int64_t arr = gather_align(total * 4);
+  const int64_t tmp_bytes = gather_align((int64_t)(sort_bytes > scan_bytes ? sort_bytes : scan_bytes));
+  char* scratch = nullptr;
+  e = hipMalloc(&scratch, 4 * arr + tmp_bytes + 256);
+  if (e != hipSuccess) return e;
+  int32_t* iota = reinterpret_cast<int32_t*>(scratch);
+  int32_t* keys = reinterpret_cast<int32_t*>(scratch + arr);
+  int32_t* flag = reinterpret_cast<int32_t*>(scratch + 2 * arr);  // later: start[]
+  int32_t* rowid = reinterpret_cast<int32_t*>(scratch + 3 * arr);
+  void* tmp = scratch + 4 * arr;
+  int32_t* stats = reinterpret_cast<int32_t*>(scratch + 4 * arr + tmp_bytes);
+  const int T = 256;
+  const unsigned gb = (unsigned)((total + T - 1) / T);
+  hipLaunchKernelGGL(gather_iota_kernel, dim3(gb), dim3(T), 0, stream, iota, total);
+  size_t sb = sort_bytes;
+  e = hipcub::DeviceRadixSort::SortPairs(tmp, sb, dofmap, keys, (const int32_t*)iota, entries, (int)total, 0, 32, stream);
+  if (e == hipSuccess) {
+    hipLaunchKernelGGL(gather_flag_kernel, dim3(gb), dim3(T), 0, stream, keys, flag, total);
+    size_t cb = scan_bytes;
+    e = hipcub::DeviceScan::InclusiveSum(tmp, cb, (const int32_t*)flag, rowid, (int)total, stream);
+  }
+  int32_t nrows32 = 0, kmin = 0, kmax = 0;
+  if (e == hipSuccess) e = hipMemcpyAsync(&nrows32, rowid + (total - 1), 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&kmin, keys, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipMemcpyAsync(&kmax, keys + (total - 1), 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e == hipSuccess && (kmin < 0 || (int64_t)kmax >= ndofs)) *bad = 1;
+  int32_t st[2] = {0, 0};
+  if (e == hipSuccess && !*bad) {
+    const int64_t nrows = nrows32;
+    const int64_t nblocks = (nrows + kGatherThreads - 1) / kGatherThreads;
+    int32_t* start = iota;  // iota is no longer needed
+    hipLaunchKernelGGL(gather_rows_kernel, dim3(gb), dim3(T), 0, stream, keys, flag, rowid, rows, start, total);
+    e = hipMemsetAsync(stats, 0, 8, stream);
+    if (e == hipSuccess) {
+      hipLaunchKernelGGL(gather_len_kernel, dim3((unsigned)((nrows + T - 1) / T)), dim3(T), 0, stream, start, rows, len, base,
+                         nrows, total, nblocks, stats);
+      e = hipMemcpyAsync(st, stats, 8, hipMemcpyDeviceToHost, stream);
+    }
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    h.nrows = nrows;
+    h.nblocks = nblocks;
+    h.max_len = st[0];
+    h.dense = st[1] ? 0 : 1;
+    if (st[0] > 255) *bad = 1;
+    if (e == hipSuccess) e = hipMemcpyAsync(ws, &h, sizeof h, hipMemcpyHostToDevice, stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(stream);
+    *out = h;
+  }
+  (void)hipFree(scratch);
+  if (e == hipSuccess) e = hipGetLastError();
+  return e;
+}
+
+template <typename T, int R>
+inline hipError_t launch_mass_gather_r(const T* x, const T* cc, T* y, const T* detJ, const GatherView& v, const GatherHeader& h,
+                                       hipStream_t stream) {
+  const int64_t nkb = (h.nrows + (int64_t)kGatherThreads * R - 1) / ((int64_t)kGatherThreads * R);
+  const int chunk = (int)((nkb + 7) / 8);  // blocks of one XCD
+  const dim3 grid((unsigned)(chunk * 8)), block(kGatherThreads);
+  const double inv_n = 1.0 / (double)h.N;
+  const int nt = vector_stream(h.nrows * (int64_t)sizeof(T)) == 1 ? 1 : 0;
+  if (h.dense) {
+    if (nt)
+      hipLaunchKernelGGL((mass_gather_kernel<T, 1, true, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+    else
+      hipLaunchKernelGGL((mass_gather_kernel<T, 0, true, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+  } else {
+    if (nt)
+      hipLaunchKernelGGL((mass_gather_kernel<T, 1, false, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+    else
+      hipLaunchKernelGGL((mass_gather_kernel<T, 0, false, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+  }
+  return hipGetLastError();
+}
+
+// ``variant`` (FUS_TUNE_MASS_VARIANT): rows per thread (1, 2, 4; anything else: chosen by size and type)
+template <typename T>
+inline hipError_t launch_mass_gather(const T* x, const T* cc, T* y, const T* detJ, const void* ws, const GatherHeader& h,
+                                     hipStream_t stream, int variant = 0) {
+  if (h.nrows == 0) return hipSuccess;
+  const char* w = static_cast<const char*>(ws);
+  const GatherView v{h.nrows, h.nblocks, h.dense ? nullptr : reinterpret_cast<const int32_t*>(w + h.off_rows),
+                     reinterpret_cast<const uint8_t*>(w + h.off_len), reinterpret_cast<const int32_t*>(w + h.off_base),
+                     reinterpret_cast<const int32_t*>(w + h.off_entries)};
+  int rows_per_thread = variant;
+  if (rows_per_thread != 1 && rows_per_thread != 2 && rows_per_thread != 4) {
+    // measured (profiles/r04t_ab_mass_gather.log): below ~0.5 M dofs one row per thread fills the chip best; fp64 two rows
+    // (0.100 ms at config 3, four rows the same, one row 0.117); fp32 four rows from a few M dofs (0.070 against 0.075)
+    rows_per_thread = h.nrows < (1 << 19) ? 1 : ((sizeof(T) == 4 && h.nrows >= (1 << 22)) ? 4 : 2);
+  }
+  switch (rows_per_thread) {
+    case 1: return launch_mass_gather_r<T, 1>(x, cc, y, detJ, v, h, stream);
+    case 4: return launch_mass_gather_r<T, 4>(x, cc, y, detJ, v, h, stream);
+    default: return launch_mass_gather_r<T, 2>(x, cc, y, detJ, v, h, stream);
+  }
+}
+
+}  // namespace fus

@@ -155,6 +155,70 @@ class _PlanCache:
 _PLANS = _PlanCache()
 _MASS_PLAN_MIN_ENTRIES = 1 << 15  # below this the plan-free kernel is already launch-bound
 
+# The mass apply WITHOUT atomics (csrc/mass_gather.hpp): one thread per touched dof sums its (entity, local index) entries
+# from the transposed dofmap.  FUS_MASS_GATHER=0 / use_mass_gather(False) keeps the atomic kernels everywhere.
+_USE_GATHER = os.environ.get("FUS_MASS_GATHER", "1") != "0"
+# mean entries per touched dof above which the gather loses to the atomic batch plan: at P = 2 (27 / 8 = 3.4 entries per dof,
+# one-element detJ segments) 0.262 against 0.200 ms, at P = 3 (2.4) 0.142 against 0.158 (profiles/r04t_ab_mass_gather.log)
+_GATHER_MAX_MEAN_ENTRIES = 2.6
+
+
+def use_mass_gather(flag: bool):
+    global _USE_GATHER
+    _USE_GATHER = bool(flag)
+
+
+class _GatherPlanCache:
+    """Transposed-dofmap plans of the atomic-free mass apply, keyed like the batch plans (identity of the dofmap array) plus
+    the length of the dof vectors.  An entry is ``None`` when the library refused the dofmap (a dof with more than 255
+    entries) or the gather would lose (``_GATHER_MAX_MEAN_ENTRIES``): the caller then takes the atomic path."""
+
+    def __init__(self, capacity: int = 16):
+        self._plans = {}
+        self.capacity = capacity
+
+    def get(self, dofmap: torch.Tensor, ndofs: int):
+        lib = _lib.load()
+        nent, N = dofmap.shape
+        key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index, int(ndofs))
+        if key in self._plans:
+            hit = self._plans[key]
+        else:
+            import ctypes as C
+
+            hit = None
+            nbytes = lib.fus_mass_gather_plan_bytes(N, nent, int(ndofs))
+            if nbytes > 0:
+                ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dofmap.device)
+                rc = lib.fus_mass_gather_plan_build(dofmap.data_ptr(), N, nent, int(ndofs), ws.data_ptr(), int(nbytes), _lib.stream_ptr())
+                if rc == 0:
+                    info = (C.c_int64 * 4)()
+                    _lib.check(lib.fus_mass_gather_plan_info(ws.data_ptr(), info), "fus_mass_gather_plan_info")
+                    if info[0] > 0 and nent * N <= _GATHER_MAX_MEAN_ENTRIES * info[0]:
+                        hit = (ws, dofmap, tuple(int(v) for v in info))
+                    else:
+                        lib.fus_plan_release(ws.data_ptr())
+                elif rc != _lib.ERR_UNSUPPORTED_ENTITY:
+                    _lib.check(rc, "fus_mass_gather_plan_build")
+            if len(self._plans) >= self.capacity:
+                old = self._plans.pop(next(iter(self._plans)))
+                if old is not None:
+                    lib.fus_plan_release(old[0].data_ptr())
+            self._plans[key] = hit
+        if hit is not None and _PLANS._recording is not None:
+            _PLANS._recording.append((hit[0], hit[1]))  # a captured graph keeps the workspace alive
+        return hit
+
+    def clear(self):
+        lib = _lib.load()
+        for hit in self._plans.values():
+            if hit is not None:
+                lib.fus_plan_release(hit[0].data_ptr())
+        self._plans.clear()
+
+
+_GATHER_PLANS = _GatherPlanCache()
+
 
 class _Launchable:
     """``obj[grid, block](...)`` == ``obj.launch(...)`` (launch config ignored)."""
@@ -164,7 +228,7 @@ class _Launchable:
 
 
 # --------------------------------------------------------------------------- mass
-def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, exclusive=False):
+def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, exclusive=False, atomic=False):
     lib = _lib.load()
     dt = x.dtype if isinstance(x, torch.Tensor) else None
     _req(x, dt, "x")
@@ -181,6 +245,16 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, excl
         raise ValueError("entity_constants must have one value per entity")
     if nent == 0:
         return
+    if _USE_GATHER and not atomic and nent * n_per >= _MASS_PLAN_MIN_ENTRIES and n_per <= 2048 and nent * n_per < 2**31:
+        hit = _GATHER_PLANS.get(entity_dofmap, min(x.numel(), y.numel()))  # every dofmap value is checked against both vectors
+        if hit is not None:
+            fn = getattr(lib, f"fus_mass_apply_gather_{_lib.suffix(dt)}")
+            _lib.check(
+                fn(x.data_ptr(), entity_constants.data_ptr(), y.data_ptr(), entity_detJ.data_ptr(), hit[0].data_ptr(),
+                   int(n_per), int(nent), _lib.stream_ptr()),
+                "fus_mass_apply_gather",
+            )
+            return
     if _USE_PLAN and 2 <= n_per <= 4096 and nent * n_per >= _MASS_PLAN_MIN_ENTRIES:  # plan batches hold <= 4096 entries
         ws, epb = _PLANS.get(entity_dofmap, exclusive_ndofs=y.numel() if exclusive else None)
         fn = getattr(lib, f"fus_mass_apply_planned_{_lib.suffix(dt)}")
@@ -198,24 +272,46 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, excl
     )
 
 
+def mass_kernel_name(entity_dofmap, ndofs, atomic=False):
+    """Which kernel ``mass_operator``'s apply launches for this dofmap and vector length (bench.py reports it)."""
+    nent, n_per = entity_dofmap.shape
+    big = nent * n_per >= _MASS_PLAN_MIN_ENTRIES
+    if _USE_GATHER and not atomic and big and n_per <= 2048 and nent * n_per < 2**31 and _GATHER_PLANS.get(entity_dofmap, int(ndofs)) is not None:
+        return "fus::mass_gather_kernel"
+    return "fus::mass_plan_kernel" if (_USE_PLAN and 2 <= n_per <= 4096 and big) else "fus::mass_kernel"
+
+
+class _MassApply:
+    """``operator(x, entity_constants, y, entity_detJ, entity_dofmap)`` returned by ``mass_operator(N, float_type)``;
+    ``.atomic``: the same operator on the float-atomic kernels (safe next to concurrent writers of ``y``)."""
+
+    def __init__(self, N, tdt, exclusive, atomic):
+        self.N, self.dtype, self._exclusive, self._atomic = N, tdt, exclusive, atomic
+        self.atomic = self if atomic else _MassApply(N, tdt, exclusive, True)
+
+    def __call__(self, x, entity_constants, y, entity_detJ, entity_dofmap):
+        if isinstance(x, torch.Tensor) and x.dtype != self.dtype:
+            raise TypeError(f"x: expected dtype {self.dtype}, got {x.dtype}")
+        _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, self.N, exclusive=self._exclusive, atomic=self._atomic)
+
+
 class _MassOperator(_Launchable):
-    def __call__(self, N: int, float_type, exclusive=False):
+    def __call__(self, N: int, float_type, exclusive=False, atomic=False):
         """``mass_operator(N, float_type)`` -> ``operator(x, entity_constants, y, entity_detJ, entity_dofmap)``
-        (numba-cpu/operators.py:19-68).  ``exclusive=True`` (keyword, no reference counterpart): the batch plan carries
-        exclusive-dof marks -- a dof that exactly one batch of entities touches is finished with a plain load + store
-        instead of a float atomic (the apply is bound by the chip's float-atomic request rate).  The caller
-        guarantees that NOTHING ELSE adds into ``y`` while the launch runs (launches on the same stream are fine; another
-        stream's launch or a halo receive adding into the same ``y`` concurrently is not): the drivers use it for the
-        stand-alone applies of set-up (lumped mass, diagonals), not inside the overlapped stage."""
-        tdt = _lib.torch_dtype(float_type)
-        N = int(N)
+        (numba-cpu/operators.py:19-68).
 
-        def operator(x, entity_constants, y, entity_detJ, entity_dofmap):
-            if isinstance(x, torch.Tensor) and x.dtype != tdt:
-                raise TypeError(f"x: expected dtype {tdt}, got {x.dtype}")
-            _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N, exclusive=exclusive)
-
-        return operator
+        Default kernel (csrc/mass_gather.hpp): ONE thread per touched dof sums the dof's (entity, local index) entries from
+        the transposed dofmap in the order of the reference's serial loop and finishes ``y[dof]`` with a plain load +
+        store -- no float atomics (their request rate bounds the atomic kernels at 0.44-0.45 of the HBM roofline), bitwise
+        reproducible.  Like the reference's CPU operator (a plain ``+=``), such a launch assumes NOTHING ELSE adds into ``y``
+        while it runs (earlier and later launches of the same stream are fine).  ``atomic=True`` (keyword, or the ``.atomic``
+        attribute of the returned operator): the float-atomic kernels of cuda/operators.py:66-70's behaviour, safe next to
+        another stream's launch or a halo receive adding into the same ``y`` -- what ``HaloApply`` uses for its overlapped
+        sub-launches.  Dofmaps the gather does not pay for (P = 2: 3.4 entries per dof) or cannot hold (a dof in more than 255
+        entities) take the atomic batch plan by themselves.
+        ``exclusive=True`` (atomic batch plan with exclusive-dof marks, round 4's first attempt): kept for the atomic path,
+        measured slower than the unmarked plan."""
+        return _MassApply(int(N), _lib.torch_dtype(float_type), exclusive, atomic)
 
     @staticmethod
     def launch(x, entity_constants, y, detJ_entity, entity_dofmap):

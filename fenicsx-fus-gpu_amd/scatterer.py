@@ -610,7 +610,9 @@ class HaloApply:
         from .utils import compute_scatterer_data_flat
 
         self.mesh = mesh
-        self.op = op
+        # the sub-launches of one apply run next to each other and next to the reverse exchange's receive kernel, all adding
+        # into the same y: an operator with an atomic-free default (mass_operator) hands over its atomic twin
+        self.op = getattr(op, "atomic", op)
         self.comm = comm
         # plan = (owners_data, ghosts_data) already computed (e.g. by the reference-style
         # compute_scatterer_data of a driver); default: exchange the indices over ``comm`` now

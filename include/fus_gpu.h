@@ -52,6 +52,7 @@ extern "C" {
  *      flags it publishes, so its neighbours fail too instead of consuming stale data; fus_comm_fork / fus_comm_join
  *      enforce their one-caller-stream contract (FUS_ERR_INVALID_ARGUMENT); new: fus_comm_fork_lazy, fus_comm_arm_join,
  *      fus_comm_health; the PEER blob identifies the exporting process by a random token and its device by PCI bus id.
+ *      Added since without a bump (new symbols only): fus_mass_gather_plan_bytes / _build / _info, fus_mass_apply_gather_*.
  * There are deliberately NO fus_cpu_* twins of the entry points (SURVEY.md 8b proposed them): a CPU path inside the
  * product would be a silent fallback; the CPU restatement of the reference is test infrastructure and lives outside the product tree.
  */
@@ -68,7 +69,7 @@ int fus_device_info(int device, char* name, int* compute_units, int64_t* hbm_byt
 /* Tuning knobs (process-global, not part of the numerical contract).  Keys: */
 #define FUS_TUNE_STIFFNESS_VARIANT 1 /* 0 = default; see DESIGN.md for the variants */
 #define FUS_TUNE_XCD_REMAP 2         /* 1 = give each XCD a contiguous range of cell batches */
-#define FUS_TUNE_MASS_VARIANT 3
+#define FUS_TUNE_MASS_VARIANT 3       /* rows per thread of the atomic-free mass apply (fus_mass_apply_gather_*): 1, 2, 4; 0 (default) = by size and type */
 #define FUS_TUNE_PLAN_VARIANT 4      /* planned stiffness kernel build: see csrc/fus_gpu.hip */
 #define FUS_TUNE_PLAN_RUNS 5         /* which encoding of a plan's dof lists the apply kernels read: 0 the lists, 2 the run tables, 1 auto (default: fp64 run tables; fp32 run tables up to 125 dofs per entity, lists above); 0 at plan build = no run tables are built */
 #define FUS_TUNE_VECTOR_STREAM 6      /* non-temporal accesses in the streaming vector kernels (fus_axpy ... fus_rk4_stage_*): 0 never, 1 auto (default: non-temporal loads and stores for operands > 24 MB), 2 always, 3 / 4 the same with non-temporal stores only -- a plain store leaves its line dirty in the memory-side cache, to be written back while the NEXT kernel runs (csrc/vecops.hpp) */
@@ -222,6 +223,28 @@ int fus_mass_apply_planned_f64(const double* x, const double* entity_constants, 
 int fus_mass_apply_planned_f32(const float* x, const float* entity_constants, float* y, const float* entity_detJ,
                                const void* workspace, int ndof_per_entity, int entities_per_batch, int64_t nent,
                                void* stream);
+
+/*
+ * Atomic-free mass apply over the TRANSPOSED dofmap (csrc/mass_gather.hpp): one thread per touched dof sums its entries
+ * (entity, local index) in ascending order -- the order of the reference's serial loop (numba-cpu/operators.py:60-68) -- and
+ * finishes y[dof] with one plain load + store.  Same result as fus_mass_apply_* up to the summation order of the atomics
+ * there; bitwise reproducible from run to run; same algorithmic bytes (detJ once, 4 index bytes per entry, x once, y
+ * read-modify-write once) + 1 byte per dof.  The plan is built on the device (radix sort of the entries by dof):
+ *   ndofs   length of the dof vectors x / y; every dofmap value must lie in [0, ndofs)
+ *   returns FUS_ERR_UNSUPPORTED_ENTITY for a dofmap value out of range or a dof with more than 255 entries (use
+ *   fus_mass_apply_planned_* / fus_mass_apply_* then), FUS_ERR_INVALID_ARGUMENT for nent * ndof_per_entity >= 2^31.
+ * fus_mass_gather_plan_info: out4 = {touched dofs, 1 if they are exactly 0 .. touched - 1, largest number of entries of a dof,
+ * workspace bytes}.  fus_plan_release forgets the workspace.  No reference counterpart (its kernels issue one atomic per
+ * (entity, dof), cuda/operators.py:66-70).
+ */
+int64_t fus_mass_gather_plan_bytes(int ndof_per_entity, int64_t nent, int64_t ndofs);
+int fus_mass_gather_plan_build(const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, int64_t ndofs,
+                               void* workspace, int64_t workspace_bytes, void* stream);
+int fus_mass_gather_plan_info(const void* workspace, int64_t* out4);
+int fus_mass_apply_gather_f64(const double* x, const double* entity_constants, double* y, const double* entity_detJ,
+                              const void* workspace, int ndof_per_entity, int64_t nent, void* stream);
+int fus_mass_apply_gather_f32(const float* x, const float* entity_constants, float* y, const float* entity_detJ,
+                              const void* workspace, int ndof_per_entity, int64_t nent, void* stream);
 
 /*
  * Streaming vector kernels of the RK4 stage.

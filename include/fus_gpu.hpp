@@ -67,6 +67,9 @@ struct Abi<double> {
                   void* s) {
     return fus_mass_apply_planned_f64(x, c, y, dJ, ws, N, epb, ne, s);
   }
+  static int mass_gather(const double* x, const double* c, double* y, const double* dJ, const void* ws, int N, int64_t ne, void* s) {
+    return fus_mass_apply_gather_f64(x, c, y, dJ, ws, N, ne, s);
+  }
 };
 template <>
 struct Abi<float> {
@@ -80,6 +83,9 @@ struct Abi<float> {
   }
   static int mass(const float* x, const float* c, float* y, const float* dJ, const void* ws, int N, int epb, int64_t ne, void* s) {
     return fus_mass_apply_planned_f32(x, c, y, dJ, ws, N, epb, ne, s);
+  }
+  static int mass_gather(const float* x, const float* c, float* y, const float* dJ, const void* ws, int N, int64_t ne, void* s) {
+    return fus_mass_apply_gather_f32(x, c, y, dJ, ws, N, ne, s);
   }
 };
 
@@ -130,6 +136,30 @@ struct Plan {
     }
   }
 };
+// the transposed dofmap of the atomic-free mass apply (fus_mass_gather_plan_build); ``ok`` stays false when the library
+// declines the dofmap (a dof in more than 255 entities): the functor then keeps to the atomic kernel
+struct GatherPlan {
+  void* ws = nullptr;
+  bool ok = false;
+  GatherPlan() = default;
+  GatherPlan(const GatherPlan&) = delete;
+  GatherPlan& operator=(const GatherPlan&) = delete;
+  void build(const int32_t* dofmap, int ndof_per_entity, int64_t n_entities, int64_t ndofs, hipStream_t stream) {
+    const int64_t bytes = fus_mass_gather_plan_bytes(ndof_per_entity, n_entities, ndofs);
+    if (bytes < 0) return;  // 2^31 entries or more: atomic kernel
+    check_hip(hipMalloc(&ws, (size_t)bytes), "hipMalloc(gather plan workspace)");
+    const int rc = fus_mass_gather_plan_build(dofmap, ndof_per_entity, n_entities, ndofs, ws, bytes, stream);
+    if (rc == FUS_ERR_UNSUPPORTED_ENTITY) return;
+    check(rc, "fus_mass_gather_plan_build");
+    ok = true;
+  }
+  ~GatherPlan() {
+    if (ws) {
+      (void)fus_plan_release(ws);
+      (void)hipFree(ws);
+    }
+  }
+};
 }  // namespace detail
 
 /// y += M(coeffs) x, M the collocated (diagonal) GLL mass operator; cpp/common/spectral_op.hpp:29-107
@@ -156,8 +186,20 @@ public:
   }
   MassSpectral3D(const MassSpectral3D&) = delete;
   MassSpectral3D& operator=(const MassSpectral3D&) = delete;
+  /// Opt in to the atomic-free kernel (one thread per dof over the transposed dofmap: no float atomics, bitwise
+  /// reproducible, 0.100 against 0.133 ms at P = 4 / 10 M dofs): ``ndofs`` = length of the vectors the operator is applied to
+  /// (every dofmap value < ndofs).  A launch then assumes that nothing else adds into y while it runs (other launches of the
+  /// same stream are fine); ``apply_atomic`` stays safe next to concurrent writers (a halo receive, another stream).
+  void enable_gather(const int32_t* dofmap, int64_t ndofs, hipStream_t stream = nullptr) { gather_.build(dofmap, Nd, Nc, ndofs, stream); }
+  bool gather_enabled() const { return gather_.ok; }
   /// y += M x   (x, y: device vectors of nlocal + nghost entries; coeffs: device T[ncells])
   void operator()(const T* x, const T* coeffs, T* y, hipStream_t stream = nullptr) const {
+    if (gather_.ok)
+      check(detail::Abi<T>::mass_gather(x, coeffs, y, detJ_, gather_.ws, Nd, Nc, stream), "fus_mass_apply_gather");
+    else
+      apply_atomic(x, coeffs, y, stream);
+  }
+  void apply_atomic(const T* x, const T* coeffs, T* y, hipStream_t stream = nullptr) const {
     check(detail::Abi<T>::mass(x, coeffs, y, detJ_, plan_.ws, Nd, plan_.epb, Nc, stream), "fus_mass_apply_planned");
   }
   const T* detJ() const { return detJ_; }
@@ -167,6 +209,7 @@ private:
   const T* detJ_ = nullptr;
   detail::DeviceBuffer<T> detJ_own_;  // members are released in reverse order, also when the constructor throws
   detail::Plan plan_;
+  detail::GatherPlan gather_;
 };
 
 /// y += K(coeffs) x, the sum-factorised stiffness operator; cpp/common/spectral_op.hpp:132-284

@@ -72,7 +72,8 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
     res["fetch_bytes_corrected"] = 2 * f * 1024
     res["write_bytes"] = w * 1024
     bytes_model = {"stiffness_plan_kernel": lambda nc, P: nc * (6 * (P + 1) ** 3 * 8 + 4 * (P + 1) ** 3 + 3 * 8 * P ** 3 + 8),
-                   "mass_plan_kernel": lambda nc, P: nc * ((P + 1) ** 3 * 8 + 4 * (P + 1) ** 3 + 3 * 8 * P ** 3 + 8)}
+                   "mass_plan_kernel": lambda nc, P: nc * ((P + 1) ** 3 * 8 + 4 * (P + 1) ** 3 + 3 * 8 * P ** 3 + 8),
+                   "mass_gather_kernel": lambda nc, P: nc * ((P + 1) ** 3 * 8 + 4 * (P + 1) ** 3 + 3 * 8 * P ** 3 + 8)}
     ncell = bench["config"].get("cells_per_gpu") or bench.get("roofline", {}).get("cells_per_launch")
     P = bench["config"].get("degree")
     if "algorithmic_bytes_per_cell" in (bench.get("roofline") or {}) and ncell:
@@ -102,7 +103,9 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
         latest.setdefault("aux", {})["mass"] = {
             "P": bench["config"]["degree"], "ncell": ncell, "dtype": bench.get("dtype", "f64"), "hbm_bytes_per_launch": res["hbm_bytes_per_launch"],
             "source": f"profiles/{_tag_for_files}_counters.json", "lib_sha": res["lib_sha"],
-            "kernel_src_sha": bench_py.kernel_src_sha(("plan.hpp", "mass.hpp")),
+            "kernel": "fus::mass_gather_kernel" if "gather" in kernel_key else "fus::mass_plan_kernel",
+            "kernel_src_files": ["mass_gather.hpp", "vecops.hpp"] if "gather" in kernel_key else ["plan.hpp", "mass.hpp"],
+            "kernel_src_sha": bench_py.kernel_src_sha(("mass_gather.hpp", "vecops.hpp") if "gather" in kernel_key else ("plan.hpp", "mass.hpp")),
             "atomic_requests_per_launch": counters.get("TCC_EA0_ATOMIC_sum", {}).get("mean_per_launch")}
         json.dump(latest, open(latest_path, "w"), indent=1)
 for a_ in sys.argv[3:]:

@@ -915,7 +915,7 @@ def test_maximum_size_beyond_32bit_offsets(gpu, oracle_c):
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
 @pytest.mark.parametrize("P,cells", [(4, 12), (2, 20), (6, (6, 5, 4))], ids=["P4", "P2", "P6"])
 def test_mass_exclusive_dof_marks(gpu, oracle_c, P, cells, dtype):
-    """``mass_operator(N, T, exclusive=True)``: dofs that exactly one batch of the plan touches are finished with a plain load +
+    """``mass_operator(N, T, exclusive=True, atomic=True)`` (the float-atomic batch plan with exclusive-dof marks): dofs that exactly one batch of the plan touches are finished with a plain load +
     store instead of an atomic.  Same result as the oracle; accumulates into y like the unmarked apply (two launches back to
     back on one stream); cell and facet entities; with every dof declared as used elsewhere nothing is marked."""
     import torch
@@ -929,7 +929,7 @@ def test_mass_exclusive_dof_marks(gpu, oracle_c, P, cells, dtype):
     oracle_c.mass_apply(x64, cc64, y_ref, dj64, mesh.dofmap)
     x_d, cc_d, dj_d, dm = (dev.to_device(a) for a in (pb["x"], pb["cc"], pb["detJ"], mesh.dofmap))
     tdt = torch.float64 if dtype == np.float64 else torch.float32
-    op = ops.mass_operator(n**3, dtype, exclusive=True)
+    op = ops.mass_operator(n**3, dtype, exclusive=True, atomic=True)
     y = torch.zeros(mesh.ndofs, dtype=tdt, device="cuda")
     op(x_d, cc_d, y, dj_d, dm)
     _check(y.cpu().numpy(), y_ref, dtype, "exclusive-marks cell mass")
@@ -963,8 +963,165 @@ def test_mass_exclusive_dof_marks(gpu, oracle_c, P, cells, dtype):
         y_ref = np.zeros(mesh.ndofs)
         oracle_c.mass_apply(x64, fc, y_ref, dF, fdm)
         y = torch.zeros(mesh.ndofs, dtype=tdt, device="cuda")
-        ops.mass_operator(n * n, dtype, exclusive=True)(x_d, dev.to_device(fc.astype(dtype)), y, dev.to_device(dF.astype(dtype)), dev.to_device(fdm))
+        ops.mass_operator(n * n, dtype, exclusive=True, atomic=True)(x_d, dev.to_device(fc.astype(dtype)), y, dev.to_device(dF.astype(dtype)), dev.to_device(fdm))
         _check(y.cpu().numpy(), y_ref, dtype, "exclusive-marks facet mass")
+
+
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+@pytest.mark.parametrize("P,cells,order", [(4, 12, "lex"), (3, (9, 9, 7), "random"), (6, (6, 5, 4), "lex"), (5, 7, "random"), (8, 4, "lex")],
+                         ids=["P4", "P3-random-cell-order", "P6", "P5-random-cell-order", "P8"])
+def test_mass_gather_kernel(gpu, oracle_c, P, cells, order, dtype):
+    """The default cell mass apply: the atomic-free transposed-dofmap kernel (csrc/mass_gather.hpp).  Same result as the
+    oracle (numba-cpu/operators.py:19-68 restated) and as the float-atomic kernel; accumulates into y (two launches back to
+    back); bitwise reproducible from run to run; any cell order; boundary facets (touched dofs are a sparse subset: the plan
+    carries its row list); the operator's ``.atomic`` twin launches the batch-plan kernel."""
+    import torch
+
+    dev, ops = gpu
+    pb = build_problem(P, cells, dtype=dtype, perturb=0.16)
+    mesh = pb["mesh"]
+    n = P + 1
+    perm = np.arange(mesh.ncells) if order == "lex" else np.random.default_rng(11).permutation(mesh.ncells)
+    dofmap = np.ascontiguousarray(mesh.dofmap[perm])
+    x64, cc64, dj64 = pb["x"].astype(np.float64), pb["cc"].astype(np.float64)[perm], pb["detJ"].astype(np.float64)[perm]
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.mass_apply(x64, cc64, y_ref, dj64, dofmap)
+    x_d, cc_d, dj_d, dm = (dev.to_device(a) for a in (pb["x"], pb["cc"][perm], pb["detJ"][perm], dofmap))
+    tdt = torch.float64 if dtype == np.float64 else torch.float32
+    assert mesh.ncells * n**3 >= ops._MASS_PLAN_MIN_ENTRIES
+    assert ops.mass_kernel_name(dm, mesh.ndofs) == "fus::mass_gather_kernel"
+    assert ops.mass_kernel_name(dm, mesh.ndofs, atomic=True) == "fus::mass_plan_kernel"
+    op = ops.mass_operator(n**3, dtype)
+    y = torch.zeros(mesh.ndofs, dtype=tdt, device="cuda")
+    op(x_d, cc_d, y, dj_d, dm)
+    _check(y.cpu().numpy(), y_ref, dtype, "gather cell mass")
+    y1 = y.clone()
+    op(x_d, cc_d, y, dj_d, dm)
+    _check(y.cpu().numpy(), 2 * y_ref, dtype, "gather cell mass, second launch")
+    y2 = torch.zeros_like(y)
+    op(x_d, cc_d, y2, dj_d, dm)
+    assert torch.equal(y1, y2), "the gather kernel must be bitwise reproducible"
+    ya = torch.zeros_like(y)
+    op.atomic(x_d, cc_d, ya, dj_d, dm)
+    _check(ya.cpu().numpy(), y_ref, dtype, "atomic twin")
+    info = ops._GATHER_PLANS.get(dm, mesh.ndofs)[2]
+    assert info[0] == mesh.ndofs and info[1] == 1 and info[2] == 8  # every dof touched, rows 0..ndofs-1, vertex dofs in 8 cells
+    # every build of the kernel (rows per thread)
+    lib = pkg("_lib")
+    for variant in (1, 2, 4):
+        lib.set_tuning(lib.TUNE_MASS_VARIANT, variant)
+        try:
+            yv = torch.zeros_like(y)
+            op(x_d, cc_d, yv, dj_d, dm)
+            assert torch.equal(yv, y1), f"variant {variant}"
+        finally:
+            lib.set_tuning(lib.TUNE_MASS_VARIANT, 0)
+    # boundary facets (N = n^2): only the boundary dofs are touched
+    gll, pre = pkg("gll"), pkg("precompute")
+    bd = mesh.boundary_facets()
+    dF = np.zeros((bd.shape[0], n * n))
+    pre.compute_boundary_facets_scaled_jacobian_determinant(dF, (mesh.x_dofs.astype(np.int32), mesh.x_g.astype(np.float64)), bd,
+                                                            pre.tabulate_facet_gradients(gll.gll_points_weights(P)[0]),
+                                                            gll.tensor_weights_2d(gll.gll_points_weights(P)[1]))
+    fdm = mesh.facet_dofmap(bd)
+    fc = 1.0 + 0.25 * np.random.default_rng(5).standard_normal(bd.shape[0])
+    old = ops._MASS_PLAN_MIN_ENTRIES
+    ops._MASS_PLAN_MIN_ENTRIES = 0  # small facet sets take the plan-free kernel by default: force the gather here
+    try:
+        fdm_d = dev.to_device(fdm)
+        assert ops.mass_kernel_name(fdm_d, mesh.ndofs) == "fus::mass_gather_kernel"
+        y_ref = np.full(mesh.ndofs, 0.5)
+        oracle_c.mass_apply(x64, fc, y_ref, dF, fdm)
+        y = torch.full((mesh.ndofs,), 0.5, dtype=tdt, device="cuda")  # untouched dofs keep their values
+        ops.mass_operator(n * n, dtype)(x_d, dev.to_device(fc.astype(dtype)), y, dev.to_device(dF.astype(dtype)), fdm_d)
+        _check(y.cpu().numpy(), y_ref, dtype, "gather facet mass")
+        finfo = ops._GATHER_PLANS.get(fdm_d, mesh.ndofs)[2]
+        assert finfo[0] == np.unique(fdm).size and finfo[1] == 0
+    finally:
+        ops._MASS_PLAN_MIN_ENTRIES = old
+    ops._GATHER_PLANS.clear()
+
+
+def test_mass_gather_policy_and_errors(gpu, oracle_c):
+    """P = 2 (27 / 8 = 3.4 entries per dof: the gather loses there) keeps the atomic batch plan by itself; the C ABI refuses
+    what the plan cannot hold (a dofmap value outside the vector, a dof in more than 255 entities, 2^31 entries) and an apply
+    with a workspace it did not build; FUS_MASS_GATHER's switch."""
+    import ctypes as C
+
+    import torch
+
+    dev, ops = gpu
+    lib = pkg("_lib")
+    L = lib.load()
+    pb = build_problem(2, 12, perturb=0.1)
+    mesh = pb["mesh"]
+    dm = dev.to_device(mesh.dofmap)
+    assert mesh.ncells * 27 >= ops._MASS_PLAN_MIN_ENTRIES
+    assert ops.mass_kernel_name(dm, mesh.ndofs) == "fus::mass_plan_kernel"
+    x_d, cc_d, dj_d = (dev.to_device(a) for a in (pb["x"], pb["cc"], pb["detJ"]))
+    y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+    ops.mass_operator(27, np.float64)(x_d, cc_d, y, dj_d, dm)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.mass_apply(pb["x"], pb["cc"], y_ref, pb["detJ"], mesh.dofmap)
+    _check(y.cpu().numpy(), y_ref, np.float64, "P = 2 cell mass (atomic plan by policy)")
+    # ... but the kernel itself is right there too (policy threshold lifted)
+    old = ops._GATHER_MAX_MEAN_ENTRIES
+    ops._GATHER_MAX_MEAN_ENTRIES = 100.0
+    ops._GATHER_PLANS.clear()
+    try:
+        assert ops.mass_kernel_name(dm, mesh.ndofs) == "fus::mass_gather_kernel"
+        y.zero_()
+        ops.mass_operator(27, np.float64)(x_d, cc_d, y, dj_d, dm)
+        _check(y.cpu().numpy(), y_ref, np.float64, "P = 2 cell mass (gather)")
+    finally:
+        ops._GATHER_MAX_MEAN_ENTRIES = old
+        ops._GATHER_PLANS.clear()
+    # switch
+    pb4 = build_problem(4, 7, perturb=0.1)
+    dm4 = dev.to_device(pb4["mesh"].dofmap)
+    ops.use_mass_gather(False)
+    try:
+        assert ops.mass_kernel_name(dm4, pb4["mesh"].ndofs) == "fus::mass_plan_kernel"
+    finally:
+        ops.use_mass_gather(True)
+    assert ops.mass_kernel_name(dm4, pb4["mesh"].ndofs) == "fus::mass_gather_kernel"
+    # C ABI
+    assert L.fus_mass_gather_plan_bytes(0, 10, 10) == -1 and L.fus_mass_gather_plan_bytes(8, -1, 10) == -1
+    assert L.fus_mass_gather_plan_bytes(125, 2**31 // 125 + 1, 1000) < 0  # 2^31 entries
+    nent, N, nd = 300, 8, 50
+    nbytes = int(L.fus_mass_gather_plan_bytes(N, nent, nd))
+    assert nbytes > 0
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    bad = torch.zeros((nent, N), dtype=torch.int32, device="cuda")  # dof 0 in 2400 entries
+    assert L.fus_mass_gather_plan_build(bad.data_ptr(), N, nent, nd, ws.data_ptr(), nbytes, None) == lib.ERR_UNSUPPORTED_ENTITY
+    oob = torch.arange(nent * N, dtype=torch.int32, device="cuda").reshape(nent, N) % nd
+    oob[5, 3] = nd  # one past the vector
+    assert L.fus_mass_gather_plan_build(oob.data_ptr(), N, nent, nd, ws.data_ptr(), nbytes, None) == lib.ERR_UNSUPPORTED_ENTITY
+    oob[5, 3] = -1
+    assert L.fus_mass_gather_plan_build(oob.data_ptr(), N, nent, nd, ws.data_ptr(), nbytes, None) == lib.ERR_UNSUPPORTED_ENTITY
+    v = torch.zeros(nd, dtype=torch.float64, device="cuda")
+    c = torch.ones(nent, dtype=torch.float64, device="cuda")
+    dj = torch.ones((nent, N), dtype=torch.float64, device="cuda")
+    rc = L.fus_mass_apply_gather_f64(v.data_ptr(), c.data_ptr(), v.data_ptr(), dj.data_ptr(), ws.data_ptr(), N, nent, None)
+    assert rc == -6  # FUS_ERR_PLAN_MISMATCH: nothing was registered at this address
+    info = (C.c_int64 * 4)()
+    assert L.fus_mass_gather_plan_info(ws.data_ptr(), info) == -6
+    oob[5, 3] = 7
+    assert L.fus_mass_gather_plan_build(oob.data_ptr(), N, nent, nd, ws.data_ptr(), nbytes, None) == 0
+    assert L.fus_mass_apply_gather_f64(v.data_ptr(), c.data_ptr(), v.data_ptr(), dj.data_ptr(), ws.data_ptr(), N + 1, nent, None) == -6
+    xx = torch.arange(1, nd + 1, dtype=torch.float64, device="cuda")
+    assert L.fus_mass_apply_gather_f64(xx.data_ptr(), c.data_ptr(), v.data_ptr(), dj.data_ptr(), ws.data_ptr(), N, nent, None) == 0
+    torch.cuda.synchronize()
+    cnt = np.bincount(oob.cpu().numpy().reshape(-1), minlength=nd)
+    assert np.allclose(v.cpu().numpy(), cnt * np.arange(1, nd + 1))
+    assert L.fus_plan_release(ws.data_ptr()) == 0
+    assert L.fus_mass_gather_plan_info(ws.data_ptr(), info) == -6
+    # empty entity set
+    e0 = int(L.fus_mass_gather_plan_bytes(N, 0, nd))
+    ws0 = torch.empty(max(e0, 256), dtype=torch.uint8, device="cuda")
+    assert L.fus_mass_gather_plan_build(None, N, 0, nd, ws0.data_ptr(), ws0.numel(), None) == 0
+    assert L.fus_mass_apply_gather_f64(None, None, None, None, ws0.data_ptr(), N, 0, None) == 0
+    L.fus_plan_release(ws0.data_ptr())
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])

@@ -56,6 +56,9 @@ SHIPPED = [
     (r"westervelt_cell_kernel<double, 6, 5, 1, 4, false>", 168, 3),   # BASELINE config 5: what the solver runs
     (r"westervelt_cell_kernel<double, 4, 10, 1, 5, false>", 128, 4),
     (r"westervelt_cell_kernel<float, 4, 10, 1, 3, true>", 96, 4),
+    # atomic-free mass apply (transposed dofmap): latency-bound unless eight waves per SIMD are resident
+    (r"mass_gather_kernel<double, 1, true, 2>", 64, 8),
+    (r"mass_gather_kernel<float, 1, true, 4>", 64, 8),
     # plan-free column kernel
     (r"stiffness_col_kernel<double, 4, 10>", 128, 4),
     # PEER halo transport: the whole design rests on these fitting NEXT TO an operator launch that holds every
@@ -83,6 +86,8 @@ def test_no_scratch(table):
     allowed = {r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>": 32}
     bad = []
     for name, d in table.items():
+        if "rocprim::" in name:  # the radix sort / scan of the gather plan's one-off build (hipCUB, set-up path): not ours to tune
+            continue
         lim = next((v for k, v in allowed.items() if re.search(k, name)), 0)
         if d["scratch"] > lim:
             bad.append((name, d["scratch"]))
