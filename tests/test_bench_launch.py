@@ -173,6 +173,8 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
         # the run checks its own exchanges before timing anything (forward: exact copy; reverse: owned sums)
         assert cfg["halo_check"]["ok"] is True and cfg["halo_check"]["owned_sum_defect_over_sum_abs"] < 1e-9
         assert "PEER" in cfg["halo_transport"] and cfg["halo_check"]["device_wait_timeouts"] == 0
+        if mode == "mass":  # overlapped sub-launches + the reverse receive add into one y: the float-atomic twin, not the gather kernel
+            assert out["roofline"]["kernel"] in ("fus::mass_plan_kernel", "fus::mass_kernel")
     else:  # the solver lines check the exchange they are about to use, too
         hc = out["config"]["halo_check"]
         assert hc["ok"] is True and hc["forward_wrong_ghosts"] == 0 and hc["reverse_sum"] == hc["global_ghosts"] > 0
