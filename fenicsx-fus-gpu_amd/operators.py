@@ -150,6 +150,9 @@ class _PlanCache:
         for ws, _, _ in self._plans.values():
             lib.fus_plan_release(ws.data_ptr())
         self._plans.clear()
+        gather = globals().get("_GATHER_PLANS")  # the transposed-dofmap plans of the mass apply go with them
+        if gather is not None:
+            gather.clear()
 
 
 _PLANS = _PlanCache()

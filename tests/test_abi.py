@@ -194,5 +194,7 @@ def test_committed_pmc_passes_belong_to_the_kernels_in_this_tree():
 
     t = json.load(open(os.path.join(ROOT, "profiles", "traffic_latest.json")))
     assert t["kernel_src_sha"] == bench.kernel_src_sha(), "stiffness kernel sources changed since profiles/" + t["source"]
-    assert t["aux"]["mass"]["kernel_src_sha"] == bench.kernel_src_sha(("plan.hpp", "mass.hpp")), "mass kernel sources changed"
+    tm = t["aux"]["mass"]
+    assert tm["kernel_src_sha"] == bench.kernel_src_sha(tuple(tm.get("kernel_src_files", ("plan.hpp", "mass.hpp")))), "mass kernel sources changed"
+    assert tm.get("kernel") == "fus::mass_gather_kernel"  # what aux.mass of the default line launches at config 3
     assert os.path.exists(os.path.join(ROOT, t["source"])) and os.path.exists(os.path.join(ROOT, t["aux"]["mass"]["source"]))
