@@ -1042,6 +1042,72 @@ def test_mass_gather_kernel(gpu, oracle_c, P, cells, order, dtype):
     ops._GATHER_PLANS.clear()
 
 
+@pytest.mark.parametrize("seed", range(6))
+def test_mass_gather_random_dofmaps(gpu, seed):
+    """The transposed-dofmap mass apply on dofmaps no mesh produces: any entity size (1 ... 64), dofs repeated inside an
+    entity, hot dofs with up to 250 entries next to untouched ones (row list, run lengths 1 ... 250, multi-batch rows),
+    fp64 and fp32, every build of the kernel -- against numpy's add.at in float64."""
+    import ctypes as C
+
+    import torch
+
+    lib = pkg("_lib")
+    L = lib.load()
+    rng = np.random.default_rng(100 + seed)
+    N = int(rng.choice([1, 3, 8, 27, 64]))
+    nent = int(rng.integers(1, 4000))
+    nd = int(rng.integers(5, 20000))
+    dm = rng.integers(0, nd, size=(nent, N))
+    # a few hot dofs (at most 250 entries each, the plan's limit is 255) and a dead zone nobody touches
+    hot = rng.choice(nd, size=min(3, nd), replace=False)
+    flat = dm.reshape(-1)
+    for h in hot:
+        idx = rng.choice(flat.size, size=min(80, flat.size), replace=False)
+        flat[idx] = h
+    lo = nd // 3
+    flat[(flat >= lo) & (flat < lo + nd // 10)] = 0 if seed % 2 else lo  # empties a range of dofs
+    counts = np.bincount(flat, minlength=nd)
+    if counts.max() > 255:  # keep inside the plan's limit: spread the excess
+        for d in np.nonzero(counts > 250)[0]:
+            where = np.nonzero(flat == d)[0][250:]
+            flat[where] = rng.integers(lo + nd // 10, nd, size=where.size) if lo + nd // 10 < nd else d
+        counts = np.bincount(flat, minlength=nd)
+    assume_ok = counts.max() <= 255
+    dm = flat.reshape(nent, N).astype(np.int32)
+    x = rng.standard_normal(nd)
+    c = rng.standard_normal(nent)
+    dj = rng.uniform(0.5, 1.5, size=(nent, N))
+    y0 = rng.standard_normal(nd)
+    ref = y0.copy()
+    np.add.at(ref, dm.reshape(-1), (x[dm] * dj * c[:, None]).reshape(-1))
+    dm_d = torch.from_numpy(dm).cuda()
+    nbytes = int(L.fus_mass_gather_plan_bytes(N, nent, nd))
+    ws = torch.empty(nbytes, dtype=torch.uint8, device="cuda")
+    rc = L.fus_mass_gather_plan_build(dm_d.data_ptr(), N, nent, nd, ws.data_ptr(), nbytes, None)
+    if not assume_ok:
+        assert rc == lib.ERR_UNSUPPORTED_ENTITY
+        return
+    assert rc == 0
+    info = (C.c_int64 * 4)()
+    assert L.fus_mass_gather_plan_info(ws.data_ptr(), info) == 0
+    assert info[0] == int((counts > 0).sum()) and info[2] == int(counts.max())
+    assert info[1] == int(bool((counts[: info[0]] > 0).all()))  # dense iff the touched dofs are 0 .. touched - 1
+    try:
+        for dt, tol in ((np.float64, 1e-13), (np.float32, 2e-5)):
+            fn = getattr(L, f"fus_mass_apply_gather_{'f64' if dt == np.float64 else 'f32'}")
+            xd, cd, djd = (torch.from_numpy(a.astype(dt)).cuda() for a in (x, c, dj))
+            for variant in (0, 1, 2, 4):
+                lib.set_tuning(lib.TUNE_MASS_VARIANT, variant)
+                y = torch.from_numpy(y0.astype(dt)).cuda()
+                assert fn(xd.data_ptr(), cd.data_ptr(), y.data_ptr(), djd.data_ptr(), ws.data_ptr(), N, nent, None) == 0
+                torch.cuda.synchronize()
+                err = np.abs(y.cpu().numpy().astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1.0)
+                assert err < tol * max(1, int(counts.max())), f"N={N} nent={nent} nd={nd} {dt.__name__} variant {variant}: {err}"
+    finally:
+        lib.set_tuning(lib.TUNE_MASS_VARIANT, 0)
+        L.fus_plan_release(ws.data_ptr())
+
+
 def test_mass_gather_policy_and_errors(gpu, oracle_c):
     """P = 2 (27 / 8 = 3.4 entries per dof: the gather loses there) keeps the atomic batch plan by itself; the C ABI refuses
     what the plan cannot hold (a dofmap value outside the vector, a dof in more than 255 entities, 2^31 entries) and an apply
