@@ -39,7 +39,7 @@ def main():
         y = torch.zeros_like(x)
         cc = torch.randn(mesh.ncells, dtype=torch.float64, device=dev)
         dm = torch.from_numpy(mesh.dofmap).to(dev)
-        opsd = {"atomics only": ops.mass_operator(n**3, np.float64), "exclusive marks": ops.mass_operator(n**3, np.float64, exclusive=True)}
+        opsd = {"atomics only": ops.mass_operator(n**3, np.float64, atomic=True), "exclusive marks": ops.mass_operator(n**3, np.float64, exclusive=True, atomic=True)}
         ref = None
         res = {k: [] for k in opsd}
         for k, op in opsd.items():

@@ -73,9 +73,10 @@ def main():
                     t = timeit(lambda: opa(x, cc, y, G, dm))
                     res.append(f"K[affine build {av}] {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s")
                 lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
-            t = timeit(lambda: mop(x, cc, y, detJ, dm))
-            gbs = mesh.ncells * mass_bytes_per_cell(P, T) / (t * 1e-3) / 1e9
-            res.append(f"M {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s {100 * gbs / 8000:5.1f}%")
+            for name, fn in (("M", mop), ("M[atomic]", mop.atomic)):  # default (atomic-free from P = 3 up) and the float-atomic twin
+                t = timeit(lambda: fn(x, cc, y, detJ, dm))
+                gbs = mesh.ncells * mass_bytes_per_cell(P, T) / (t * 1e-3) / 1e9
+                res.append(f"{name} {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s {100 * gbs / 8000:5.1f}%")
             print(f"P={P} N={N} {dname} cells={mesh.ncells} dofs={mesh.ndofs}: " + " | ".join(res), flush=True)
             del x, cc, G, detJ, dm, y, pb
             torch.cuda.empty_cache()
