@@ -62,7 +62,7 @@ inline void gather_layout(int64_t nent, int N, int64_t ndofs, GatherHeader* h) {
 // What was measured and not kept (profiles/r04t_ab_mass_gather.log): a workgroup walking over several blocks and issuing
 // the first-level loads of its next block before chasing the entries of the current one -- slower (0.110-0.117 ms: 74
 // VGPRs, six waves per SIMD); non-temporal loads of the index streams -- slower (0.120: the per-lane strided entry reads
-// live on L1 re-use).  HBM traffic is 1.06 x the algorithmic bytes already (r04t_mass_gather_counters.json); an ablation
+// live on L1 re-use); the ids of a batch in one 8 / 16-byte load per row -- no change (0.1056; fp32 -3 %).  HBM traffic is 1.06 x the algorithmic bytes already (r04t_mass_gather_counters.json); an ablation
 // prices the parts: without the gather of the entity constant 0.097, without the entry indirection (detJ read in row
 // order, 79 MB fewer) 0.084, without both 0.076 -- the kernel pays for its vector-memory instructions, not for bytes.
 template <typename T, int NT, bool DENSE, int R>
@@ -194,8 +194,8 @@ __global__ void gather_len_kernel(const int32_t* start, const int32_t* rows, uin
   if (r == 0) base[nblocks] = (int32_t)total;
 }
 
-// Builds the plan in ``ws`` (>= gather_layout(...).bytes).  Scratch: hipMallocAsync-free -- three int32 arrays of nent * N
-// and the cub temporaries are carved from a scratch allocation made and released here (set-up path, not the hot path).
+// Builds the plan in ``ws`` (>= gather_layout(...).bytes).  Scratch: four int32 arrays of nent * N entries and hipCUB's
+// temporaries, carved from ONE allocation made and released here (set-up path, once per dofmap: 25 ms at config 3).
 // *bad = 1: a dofmap value outside [0, ndofs) or a dof with more than 255 entries (nothing usable was built)
 inline hipError_t gather_plan_build(const int32_t* dofmap, int N, int64_t nent, int64_t ndofs, void* ws, hipStream_t stream,
                                     GatherHeader* out, int* bad) {
