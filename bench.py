@@ -1406,6 +1406,13 @@ def main():
             except Exception as e:  # noqa: BLE001
                 log(f"aux {name} line failed: {e!r}")
                 out["aux"][name] = None
+        try:  # BASELINE config 5's step on one GPU: Westervelt, P = 6, 36^3 bowl-warped cells (10.2 M dofs), fused stage
+            wargs = argparse.Namespace(**{**vars(args), "degree": 6, "cells": max(4, round(args.cells * 2 / 3))})  # 54 -> 36: the same dof count
+            r = measure_rk4(wargs, rank, world, device, "westervelt", True, False, max(1, min(args.steps, 20)), 2, cpu_leg=False)
+            out["aux"]["westervelt_step"] = {k: r[k] for k in keys}
+        except Exception as e:  # noqa: BLE001
+            log(f"aux westervelt_step line failed: {e!r}")
+            out["aux"]["westervelt_step"] = None
         try:  # the reference's third timing script (numba-cpu/time_scatterer.py), self-neighbour with config-4 messages
             out["aux"]["scatter"] = measure_scatter(device, dt, reps=100, P=P, cells=args.cells)
         except Exception as e:  # noqa: BLE001

@@ -203,13 +203,16 @@ def test_scatter_mode_line():
 def test_default_line_carries_the_aux_entries():
     """The driver's default command at a small size: the headline line with every ``aux`` entry of DESIGN.md section 6 (mass, its
     cached-diagonal form, sustained applies, in-kernel geometry, the RK4 step with and without in-kernel geometry -- with its
-    CPU oracle leg --, scatter)."""
+    CPU oracle leg --, the Westervelt step of config 5's shape, scatter)."""
     r = subprocess.run([sys.executable, BENCH, "--steps", "5", "--warmup", "2", "--cells", "12"], env=_env(), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     out = _one_json_line(r.stdout)
     aux = out["aux"]
-    for k in ("mass", "mass_cached_diagonal", "sustained", "stiffness_in_kernel_geometry", "rk4_step", "rk4_step_in_kernel_geometry", "scatter"):
+    for k in ("mass", "mass_cached_diagonal", "sustained", "stiffness_in_kernel_geometry", "rk4_step", "rk4_step_in_kernel_geometry",
+              "westervelt_step", "scatter"):
         assert aux.get(k) is not None, k
+    assert aux["westervelt_step"]["config"]["degree"] == 6 and aux["westervelt_step"]["value"] > 0
+    assert aux["mass"]["roofline"]["kernel"] == "fus::mass_gather_kernel" and aux["mass"]["roofline"]["atomic_kernel_ms"] > 0
     assert aux["sustained"]["applies"] >= 2000 and len(aux["sustained"]["window_ms_per_apply"]) == 10
     assert aux["rk4_step"]["cpu_baseline"]["value"] > 0 and aux["rk4_step"]["cpu_baseline"]["single_thread_value"] > 0
     assert aux["rk4_step"]["roofline"]["algorithmic_bytes_per_step"] > 0
