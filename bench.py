@@ -475,6 +475,29 @@ def cpu_baseline_rk4(P, mesh, solver, dts, steps=2):
                     "'Solve time per step' (numba-cpu/demo_linear_box.py:472-473)"}
 
 
+def aux_traffic(key, P, ncell, dtype):
+    """(HBM bytes per launch / per step of the ``aux.<key>`` entry of profiles/traffic_latest.json, source) or (None, reason):
+    a REPLAYED figure of separate rocprofv3 --pmc passes, reported only when the workload is the profiled one and every
+    kernel source it names (and the compile flags) are the profiled ones -- the rule of the headline's ``roofline.traffic``."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "traffic_latest.json")) as f:
+            t = json.load(f).get("aux", {}).get(key)
+    except Exception:
+        return None, "no profiles/traffic_latest.json"
+    if not t:
+        return None, f"no PMC passes in profiles/traffic_latest.json (aux.{key})"
+    if int(t.get("P", -1)) != P or int(t.get("ncell", -1)) != ncell or t.get("dtype", "f64") != dtype:
+        return None, "profiled workload differs from this run"
+    files = tuple(t.get("kernel_src_files", ()))
+    if not files or t.get("kernel_src_sha") != kernel_src_sha(files) or not lib_built_from_tree():
+        return None, "the kernel sources differ from the profiled ones"
+    val = t.get("hbm_bytes_per_step", t.get("hbm_bytes_per_launch"))
+    src = f"(2 FETCH_SIZE + WRITE_SIZE) x 1024 of separate rocprofv3 --pmc passes ({t.get('source')}"
+    if t.get("breakdown"):
+        src += f"; per launch: {t['breakdown']}, 4 launches of each per step"
+    return float(val), src + "); same kernel sources and compile flags"
+
+
 def rk4_step_traffic(P, ncell, dtype, in_kernel_geometry):
     """(HBM bytes per fused RK4 step from the committed per-kernel PMC passes, source) or (None, reason): the sum over the
     step's launches of each kernel's per-launch bytes, replayed only when every kernel's sources and the compile flags are
@@ -596,19 +619,30 @@ def measure_scatter(device, dtype_np, kinds=("peer", "native", "torch"), reps=10
 
 def measure_sustained(step_fn, alg_bytes, total=2500, windows=10):
     """>= 0.5 s of back-to-back headline applies: ms per apply overall and per sub-window (one HIP event between two
-    windows), device clocks before / after where rocm-smi answers."""
-    import subprocess
+    windows), device clocks before / after where sysfs shows them."""
+    import glob
 
     import torch
 
     def clocks():
+        # sysfs, read in-process: rocm-smi is a '#!/usr/bin/env python3' script, and starting it from a process that has
+        # initialised the GPU (or under a profiler's preloaded library) is the exec hop this pool forbids (ADVICE r4, medium)
+        out = {}
         try:
-            r = subprocess.run(["rocm-smi", "--showclocks", "--json"], capture_output=True, text=True, timeout=20)
-            d = json.loads(r.stdout)
-            card = d[sorted(d)[0]]
-            return {k: v for k, v in card.items() if "sclk" in k.lower() or "mclk" in k.lower() or "fclk" in k.lower()}
+            for card in sorted(glob.glob("/sys/class/drm/card*/device")):
+                for name in ("pp_dpm_sclk", "pp_dpm_mclk", "pp_dpm_fclk"):
+                    try:
+                        with open(os.path.join(card, name)) as f:
+                            cur = [ln.split(":", 1)[1].strip().rstrip("*").strip() for ln in f.read().splitlines() if ln.rstrip().endswith("*")]
+                    except OSError:
+                        continue
+                    if cur:
+                        out[name[7:]] = cur[0]
+                if out:
+                    break
         except Exception:  # noqa: BLE001
             return None
+        return out or None
 
     per = max(1, total // windows)
     ev = [torch.cuda.Event(enable_timing=True) for _ in range(windows + 1)]
@@ -672,6 +706,8 @@ def cpu_baseline(P, pb, reps_omp=60, reps_serial=10):
             t0 = time.perf_counter()
             O.stiffness_apply(P, pb["D"], pb["x"], pb["cc"][:ncell], y, pb["G"][:ncell], mesh.dofmap[:ncell], threads=threads)
             ts.append(time.perf_counter() - t0)
+        if name == "omp":
+            pb["y_oracle"] = y.copy()  # K x of the whole mesh (y is zeroed before every rep): what result_check compares with
         dofs = ncell * P**3  # asymptotic dofs per cell, so slabs compare with the full box
         res[name] = dict(t=float(np.median(ts)), tmin=float(np.min(ts)), mean=float(np.mean(ts)), std=float(np.std(ts)),
                          dof_per_s=dofs / float(np.median(ts)), ncell=int(ncell), threads=int(threads), dofs=dofs)
@@ -723,6 +759,160 @@ def cpu_baseline_mass(P, mesh, x, cc, detJ, reps=5):
     return {"value": mesh.ndofs / t, "unit": "DOF/s", "cores": 1, "kind": "port",
             "sample": f"full workload ({mesh.ncells} cells), {reps} reps, one thread (the reference's njit loop is serial)",
             "ms_per_apply": t * 1e3, "impl": "oracle/fus_oracle.c oracle_mass_apply_f64"}
+
+
+def oracle_apply(P, mesh, D, x, cc, geo, mass, ncells=None):
+    """One apply of the oracle (oracle/fus_oracle.c: numba-cpu/operators.py:71-227 / :19-68 restated) on this rank's cells,
+    all host cores: the checker of ``result_check``, never the thing measured."""
+    from oracle import oracle_c
+
+    try:
+        oracle_c.build(native=True)
+        O = oracle_c.OracleLib(native=True)
+    except Exception as e:  # noqa: BLE001
+        log(f"native oracle build failed ({e}); using the portable build")
+        O = oracle_c.OracleLib()
+    threads = max(1, min(O.max_threads(), host_cores()))
+    y = np.zeros(mesh.ndofs)
+    if mass:
+        O.mass_apply(x, cc, y, geo, mesh.dofmap)
+    else:
+        O.stiffness_apply(P, D, x, cc, y, geo, mesh.dofmap, threads=threads)
+    return y
+
+
+def compare_with_oracle(y_gpu, y_ref, dtype, what):
+    """{rel_l2, rel_max, sum_y, ...}: the GPU result of the timed run against the oracle's on the same inputs.  Tolerance:
+    SURVEY 8d (fp64 rel l2 <= 1e-12, max-abs / max <= 1e-11; fp32 1e-5 / 1e-4)."""
+    y_gpu = np.asarray(y_gpu, dtype=np.float64)
+    d = y_gpu - y_ref
+    nrm, mx = float(np.linalg.norm(y_ref)), float(np.max(np.abs(y_ref))) if y_ref.size else 0.0
+    rel_l2 = float(np.linalg.norm(d)) / max(nrm, 1e-300)
+    rel_max = (float(np.max(np.abs(d))) if d.size else 0.0) / max(mx, 1e-300)
+    tol_l2, tol_max = (1e-12, 1e-11) if dtype == "f64" else (1e-5, 1e-4)
+    return {"rel_l2": rel_l2, "rel_max": rel_max, "sum_y": float(y_gpu.sum()), "sum_y_oracle": float(y_ref.sum()), "norm_y_oracle": nrm,
+            "tol_rel_l2": tol_l2, "tol_rel_max": tol_max, "ok": bool(np.isfinite(rel_l2) and rel_l2 <= tol_l2 and rel_max <= tol_max and nrm > 0.0),
+            "what": what, "oracle": "oracle/fus_oracle.c (C restatement of numba-cpu/operators.py), same x, constants, geometry factors, dofmap"}
+
+
+def measure_halo_proxy(op, mesh, cc_d, G_d, dm_d, y_d, device, dt_np, P, cells, kinds=("peer", "native"), rounds=5, reps=40):
+    """north_star's "< 5 % halo-exchange overhead" on the only proxy a one-GPU box has (tools/overlap_probe.py --paired, the
+    measurement DESIGN 4.3 quotes): ONE rank that is its own neighbour with the messages of a config-4 rank (3 faces + 3 edges
+    + 1 corner of a 54^3-cell P = 4 block: 1.14 MB per direction; it sends AND receives every message -- the upper bound of what
+    a rank of a 2x2x2 partition does), 8 590 boundary cells first.  ``rounds`` alternating rounds of ``reps`` applies each of
+    (single launch over all cells | HaloApply's own launch schedule without exchange | the same with both exchanges);
+    medians, and medians of the per-round differences.  Per transport: PEER (the default) and RCCL grouped send / recv."""
+    import torch
+
+    import fusgpu_loader
+
+    scat = fusgpu_loader.submodule("scatterer")
+    n1 = P * cells + 1
+    od, gd, N = config4_self_plan(n1)
+    ng = int(od[1][0])
+    if N + ng != mesh.ndofs:
+        raise ValueError("halo proxy: the self-neighbour plan is sized for the serial box")
+
+    class _RankView:  # the attributes HaloApply reads from a mesh
+        pass
+
+    m = _RankView()
+    nb = cells * cells + cells * (cells - 1) + (cells - 1) * (cells - 1)  # the cells on three faces of a cells^3 block ...
+    nb = (nb + 9) // 10 * 10  # ... in whole batches of the plan (8 590 at config 4, as tools/overlap_probe.py)
+    m.num_boundary_cells, m.ncells, m.nlocal, m.dofmap, m.index_map = nb, mesh.ncells, N, mesh.dofmap, None
+    tdt = torch.float64 if np.dtype(dt_np) == np.float64 else torch.float32
+    xg = torch.randn(mesh.ndofs, dtype=tdt, device=device)
+    out = {"workload": f"one rank, its own neighbour, config-4 messages ({ng} elements per direction), {nb} boundary cells of {mesh.ncells}; "
+                       f"{rounds} alternating rounds x {reps} applies, medians of per-round differences",
+           "rounds": rounds, "reps": reps, "transports": {}}
+
+    def timed(fn):
+        fn()
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for _ in range(reps):
+            fn()
+        e1.record()
+        torch.cuda.synchronize()
+        return e0.elapsed_time(e1) / reps * 1e3
+
+    for kind in kinds:
+        comm = halo = None
+        try:
+            comm = scat.NativeComm(transport="peer" if kind == "peer" else "rccl")
+            halo = scat.HaloApply(m, op, comm, dt_np, plan=(od, gd))
+            halo.prepare(xg, cc_d, G_d, dm_d)
+            fns = (("single", lambda: op(xg, cc_d, y_d, G_d, dm_d)),
+                   ("schedule", lambda: halo.apply_no_exchange(xg, cc_d, y_d, G_d, dm_d)),
+                   ("halo", lambda: halo.apply(xg, cc_d, y_d, G_d, dm_d)))
+            res = {k: [] for k, _ in fns}
+            for _ in range(rounds):
+                for k, fn in fns:
+                    res[k].append(timed(fn))
+            a = {k: np.array(v) for k, v in res.items()}
+            single = float(np.median(a["single"]))
+            d_halo, d_split = float(np.median(a["halo"] - a["single"])), float(np.median(a["schedule"] - a["single"]))
+            out["transports"][kind] = {
+                "transport": TRANSPORT_TEXT[kind], "schedule": halo.schedule_kind, "lead_cells": halo.lead_cells,
+                "single_launch_us": single, "schedule_without_exchange_us": float(np.median(a["schedule"])),
+                "with_both_exchanges_us": float(np.median(a["halo"])), "exposed_us": d_halo, "exposed_pct": 100.0 * d_halo / single,
+                "split_us": d_split, "exchanges_us": float(np.median(a["halo"] - a["schedule"])),
+                "exposed_us_per_round": [float(v) for v in (a["halo"] - a["single"])], "failed_waits": int(halo.health())}
+        except Exception as e:  # noqa: BLE001
+            out["transports"][kind] = {"error": repr(e)}
+            log(f"halo proxy, transport {kind!r}: {e!r}")
+        finally:
+            try:
+                torch.cuda.synchronize()
+                if halo is not None:
+                    halo.fwd.close(), halo.rev.close()
+                if comm is not None:
+                    comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+    return out
+
+
+def secondary_summary(out):
+    """The scalars of ``aux`` that matter, mirrored into ``roofline.secondary`` (<= 1 kB): the driver's record keeps
+    ``config``, ``roofline`` and ``cpu_baseline`` verbatim and only the NAME of ``aux``."""
+    aux = out.get("aux") or {}
+    r3, r1 = (lambda v: None if v is None else round(float(v), 3)), (lambda v: None if v is None else round(float(v), 1))
+    sec = {}
+
+    def line(key, name):
+        a = aux.get(name)
+        if not a:
+            return
+        rf = a.get("roofline") or {}
+        alg = rf.get("algorithmic_bytes_per_step") or ((rf.get("algorithmic_bytes_per_cell") or 0) * (rf.get("cells_per_launch") or 0)) or rf.get("algorithmic_bytes_per_launch")
+        tr = rf.get("traffic")
+        sec[key] = {"ms": None if rf.get("kernel_ms") is None else round(float(rf["kernel_ms"]), 4), "frac": r3(rf.get("frac")),
+                    "tr": r3(tr / alg) if (tr and alg) else None}
+
+    line("mass", "mass")
+    line("mass_diag", "mass_cached_diagonal")
+    line("geom", "stiffness_in_kernel_geometry")
+    line("rk4", "rk4_step")
+    line("rk4_geom", "rk4_step_in_kernel_geometry")
+    line("westervelt", "westervelt_step")
+    line("westervelt_geom", "westervelt_step_in_kernel_geometry")
+    line("westervelt_het", "westervelt_step_heterogeneous")
+    su = aux.get("sustained")
+    if su:
+        sec["sustained"] = {"ms": round(float(su["ms_per_apply"]), 4), "frac": r3(su["frac_of_hbm_roofline"])}
+    hp = (aux.get("halo_proxy") or {}).get("transports") or {}
+    if hp:
+        sec["halo_proxy"] = {k: ({"us": r1(v.get("exposed_us")), "pct": r1(v.get("exposed_pct"))} if "exposed_us" in v else {"error": True})
+                             for k, v in hp.items()}
+    sc = (aux.get("scatter") or {}).get("transports") or {}
+    if "peer" in sc and "scatter_forward" in sc["peer"]:
+        sec["scatter_peer_us"] = [r1(sc["peer"]["scatter_forward"]["us_per_call_sync_mean"]), r1(sc["peer"]["scatter_reverse"]["us_per_call_sync_mean"])]
+    ck = out.get("check")
+    if ck:
+        sec["check"] = {"rel_l2": float(f"{ck['rel_l2']:.2e}"), "ok": ck["ok"]}
+    return sec
 
 
 def load_traffic(P, ncell, sha, dtype="f64"):
@@ -871,8 +1061,13 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
     model = rk4_step_bytes(P, T, mesh.ncells, mesh.ndofs, int(solver.fdm1.shape[0]), int(solver.fdm2.shape[0]), mode,
                            bool(solver.affine), geo_kernel, single_gather)
     achieved = model["bytes_per_step"] / (dev_ms * 1e-3) / 1e9
-    traffic, traffic_source = (rk4_step_traffic(P, mesh.ncells, args.dtype, geo_kernel) if (mode == "rk4" and perturbed and world == 1)
-                               else (None, "no PMC passes replayed for this configuration of the step"))
+    if mode == "rk4" and perturbed and world == 1:
+        traffic, traffic_source = rk4_step_traffic(P, mesh.ncells, args.dtype, geo_kernel)
+    elif mode == "westervelt" and world == 1:
+        traffic, traffic_source = aux_traffic("westervelt_step" + ("" if single_gather else "_two_gather") + ("_in_kernel_geometry" if geo_kernel else ""),
+                                              P, mesh.ncells, args.dtype)
+    else:
+        traffic, traffic_source = None, "no PMC passes replayed for this configuration of the step"
     cpu = None
     if cpu_leg and mode == "rk4" and world == 1 and not geo_kernel and dt_np == np.float64:
         try:
@@ -890,7 +1085,7 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
                    "degree": P, "cells_per_gpu": mesh.ncells, "global_dofs": mesh.ndofs_global,
                    "steps_to_final_time": nstep, "dt": dts,
                    "geometry": "affine box: constant-G fast path (opt-in, checked at set-up)" if solver.affine
-                   else ("G and detJ formed in the cell kernel from the vertices (opt-in)" if geo_kernel else "general per-quadrature-point G"),
+                   else ("G (and detJ) formed in the cell kernel from the vertices (the solvers' default on non-affine cells of degree >= 3)" if geo_kernel else "general per-quadrature-point G"),
                    "halo_check": halo_check, "halo_schedule": getattr(getattr(solver, "halo", None), "schedule_kind", None),
                    "lib_sha": lib_sha(), "lib_built_from_tree": lib_built_from_tree()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
@@ -957,6 +1152,9 @@ def main():
     ap.add_argument("--exclusive", action="store_true",
                     help="--mode mass: the batch plan carries exclusive-dof marks (plain load + store instead of an atomic for dofs "
                          "one batch touches alone; opt-in, measured slower from P = 4 up: profiles/r04d_ab_mass_exclusive_marks.log)")
+    ap.add_argument("--no-check", action="store_true",
+                    help="skip the comparison of the timed run's y with the oracle's K x (stiffness / mass modes; done by default, the "
+                         "run exits non-zero when it fails)")
     ap.add_argument("--no-aux", action="store_true", help="default mode at N = 1: skip the mass and RK4-step lines of 'aux'")
     args = ap.parse_args()
 
@@ -1199,6 +1397,8 @@ def main():
         elapsed = float(tt.item())
     ms_per_step = elapsed / args.steps * 1e3
     region_ms = r0.elapsed_time(r1) / args.steps
+    # what the timed region left in y: K accumulated applies (y was zeroed right before it) -- kept for result_check below
+    y_region = y_d.clone() if (not use_dist and not args.no_check) else None
     if halo is not None:
         # a device-side wait that gave up inside the timed region means an exchange did not deliver: no line then
         late = torch.tensor([float(halo.health())], dtype=torch.float64, device=coll_device(device))
@@ -1372,6 +1572,12 @@ def main():
         except Exception as e:  # noqa: BLE001
             log(f"aux sustained line failed: {e!r}")
             out["aux"]["sustained"] = None
+        try:  # north_star's "< 5 % halo overhead" on the one-GPU proxy: paired single launch | schedule | schedule + exchanges
+            if mesh.ncells == args.cells**3:
+                out["aux"]["halo_proxy"] = measure_halo_proxy(op, mesh, cc_d, G_d, dm_d, y_d, device, dt, P, args.cells)
+        except Exception as e:  # noqa: BLE001
+            log(f"aux halo_proxy line failed: {e!r}")
+            out["aux"]["halo_proxy"] = None
         keys = ("metric", "value", "unit", "ms_per_step", "steps", "warmup", "config", "roofline", "cpu_baseline")
         try:  # the same apply with G formed in the kernel -- own bytes contract, own line
             gop = ops.stiffness_operator(P, D.flatten(), dt, geometry=(mesh.x_dofs, mesh.x_g, pts, wts))
@@ -1388,9 +1594,10 @@ def main():
             gms = g0.elapsed_time(g1) / K
             gb = geom_bytes_per_cell(P, T)
             gach = mesh.ncells * gb / (gms * 1e-3) / 1e9
+            gtr, gtr_src = aux_traffic("stiffness_in_kernel_geometry", P, mesh.ncells, args.dtype)
             out["aux"]["stiffness_in_kernel_geometry"] = {
                 "metric": "stiffness_apply_in_kernel_geometry_dof_per_s", "value": mesh.ndofs_global / (gms * 1e-3), "unit": "DOF/s", "ms_per_step": gms, "steps": K,
-                "roofline": {"bound": "hbm", "achieved": gach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gach / HBM_PEAK_GBS, "traffic": None,
+                "roofline": {"bound": "hbm", "achieved": gach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gach / HBM_PEAK_GBS, "traffic": gtr, "traffic_source": gtr_src,
                              "kernel": "fus::stiffness_plan_geom_kernel", "kernel_ms": gms, "algorithmic_bytes_per_cell": gb, "cells_per_launch": mesh.ncells,
                              "bytes_contract": "no G array: dofmap + x once + y RMW + constant + 8 vertex ids + one vertex per cell (DESIGN 3.3); NOT the headline contract",
                              "bound_note": "float-atomic request rate of the flush, not HBM bytes (DESIGN 3.3 / 3.4)"},
@@ -1408,39 +1615,112 @@ def main():
                 out["aux"][name] = None
         try:  # BASELINE config 5's step on one GPU: Westervelt, P = 6, 36^3 bowl-warped cells (10.2 M dofs), fused stage
             wargs = argparse.Namespace(**{**vars(args), "degree": 6, "cells": max(4, round(args.cells * 2 / 3))})  # 54 -> 36: the same dof count
-            r = measure_rk4(wargs, rank, world, device, "westervelt", True, False, max(1, min(args.steps, 20)), 2, cpu_leg=False)
-            out["aux"]["westervelt_step"] = {k: r[k] for k in keys}
+            for name, geo_k in (("westervelt_step", False), ("westervelt_step_in_kernel_geometry", True)):  # the reference's G stream | the solver's default
+                try:
+                    r = measure_rk4(wargs, rank, world, device, "westervelt", True, geo_k, max(1, min(args.steps, 20)), 2, cpu_leg=False)
+                    out["aux"][name] = {k: r[k] for k in keys}
+                except Exception as e:  # noqa: BLE001
+                    log(f"aux {name} line failed: {e!r}")
+                    out["aux"][name] = None
         except Exception as e:  # noqa: BLE001
-            log(f"aux westervelt_step line failed: {e!r}")
+            log(f"aux westervelt_step lines failed: {e!r}")
             out["aux"]["westervelt_step"] = None
         try:  # the reference's third timing script (numba-cpu/time_scatterer.py), self-neighbour with config-4 messages
             out["aux"]["scatter"] = measure_scatter(device, dt, reps=100, P=P, cells=args.cells)
         except Exception as e:  # noqa: BLE001
             log(f"aux scatter line failed: {e!r}")
             out["aux"]["scatter"] = None
-    if rank == 0:
-        if world == 1 and not args.no_cpu_baseline and mass:
+    out["cpu_baseline"] = None
+    pb = None
+    if rank == 0 and world == 1 and not use_dist:
+        if not args.no_cpu_baseline and mass:
             try:
                 out["cpu_baseline"] = cpu_baseline_mass(P, mesh, x.astype(np.float64), cc.astype(np.float64), G_d.cpu().numpy().astype(np.float64))
-            except Exception as e:
+            except Exception as e:  # noqa: BLE001
                 log(f"cpu_baseline failed: {e!r}")
-                out["cpu_baseline"] = None
-        elif world == 1 and not args.no_cpu_baseline and not geom:
+        elif not args.no_cpu_baseline and not geom:
             G = G_d.cpu().numpy()  # the CPU baseline streams the same G the GPU did
-            pb = dict(mesh=mesh, D=D, x=x.astype(np.float64), cc=cc.astype(np.float64), G=G.astype(np.float64))
-            if dt != np.float64:
-                D = D.astype(np.float64)
-                pb["D"] = D
+            pb = dict(mesh=mesh, D=D.astype(np.float64), x=x.astype(np.float64), cc=cc.astype(np.float64), G=np.asarray(G, dtype=np.float64))
             try:
                 out["cpu_baseline"] = cpu_baseline(P, pb)
-            except Exception as e:
+            except Exception as e:  # noqa: BLE001
                 log(f"cpu_baseline failed: {e!r}")
-                out["cpu_baseline"] = None
-        else:
-            out["cpu_baseline"] = None
+    # ---- result check bound to the timed run (the reference keeps cuda/test_operators.py:213-312 next to cuda/time_operators.py:204-290
+    # on the same operators): what the timed region left in y, against the oracle's apply on the same inputs
+    check = None
+    if not args.no_check:
+        try:
+            x64, cc64, D64 = x.astype(np.float64), cc.astype(np.float64), D.astype(np.float64)
+            if mass:
+                geo_h = G_d.cpu().numpy().astype(np.float64)
+            elif pb is not None:
+                geo_h = pb["G"]
+            else:
+                Gt = G_d
+                if Gt is None:  # in-kernel geometry: the oracle still takes the reference's G array (numba-cpu/precompute.py:115-163)
+                    Gt = torch.empty((mesh.ncells, n**3, 6), dtype=x_d.dtype, device=device)
+                    pre.compute_scaled_geometrical_factor_device(
+                        Gt, (torch.from_numpy(mesh.x_dofs).to(device), torch.from_numpy(mesh.x_g).to(device)), mesh.ncells,
+                        torch.from_numpy(dphi_g).to(device), torch.from_numpy(wts3).to(device))
+                geo_h = Gt.cpu().numpy().astype(np.float64)
+                del Gt
+            if os.environ.get("FUS_BENCH_TEST_BREAK_CHECK") == "1":  # test hook: the checker sees other constants than the GPU did
+                cc64 = cc64 * (1.0 + 1e-3)
+                if pb is not None:
+                    pb.pop("y_oracle", None)
+            if not use_dist:
+                y_ref = pb.get("y_oracle") if pb is not None else None
+                if y_ref is None:
+                    y_ref = oracle_apply(P, mesh, D64, x64, cc64, geo_h, mass)
+                check = compare_with_oracle(y_region.cpu().numpy() / args.steps, y_ref, args.dtype,
+                                            f"y of the timed region (zeroed before it, {args.steps} accumulated applies) / {args.steps}  vs  one oracle apply, all {mesh.ndofs} dofs")
+                y_region = None
+            else:
+                # N > 1: the ghost block of y keeps its partial sums from step to step, so the region's y is not K steps of one
+                # operator; one more apply into a zeroed y (same halo objects, same kernels), owned dofs of every rank against the
+                # oracle's apply over this rank's cells reverse-scattered through the transport the halo check passed
+                y_loc = oracle_apply(P, mesh, D64, x64, cc64, geo_h, mass)
+                y_ref_d = torch.from_numpy(y_loc.astype(dt)).to(device)
+                halo.rev(y_ref_d)
+                ops.fill(0.0, y_d)
+                step()
+                torch.cuda.synchronize()
+                nl = mesh.nlocal
+                dd = (y_d[:nl].double() - y_ref_d[:nl].double())
+                sums = torch.stack([(dd * dd).sum(), (y_ref_d[:nl].double() ** 2).sum(), y_d[:nl].double().sum(), y_ref_d[:nl].double().sum()]).to(coll_device(device))
+                dist.all_reduce(sums)
+                mx = torch.stack([dd.abs().max() if nl else dd.new_zeros(()), y_ref_d[:nl].double().abs().max() if nl else dd.new_zeros(()),
+                                  torch.tensor(float(halo.health()), dtype=torch.float64, device=device)]).to(coll_device(device))
+                dist.all_reduce(mx, op=dist.ReduceOp.MAX)
+                rel_l2 = float(sums[0].sqrt().item()) / max(float(sums[1].sqrt().item()), 1e-300)
+                rel_max = float(mx[0].item()) / max(float(mx[1].item()), 1e-300)
+                tol_l2, tol_max = (1e-12, 1e-11) if args.dtype == "f64" else (1e-5, 1e-4)
+                check = {"rel_l2": rel_l2, "rel_max": rel_max, "sum_y": float(sums[2].item()), "sum_y_oracle": float(sums[3].item()),
+                         "norm_y_oracle": float(sums[1].sqrt().item()), "tol_rel_l2": tol_l2, "tol_rel_max": tol_max,
+                         "ok": bool(np.isfinite(rel_l2) and rel_l2 <= tol_l2 and rel_max <= tol_max and float(sums[1].item()) > 0 and float(mx[2].item()) == 0.0),
+                         "what": "one apply after the timed region (same halo objects and kernels) into a zeroed y, owned dofs of all ranks  vs  the oracle's "
+                                 "apply over each rank's cells, reverse-scattered", "oracle": "oracle/fus_oracle.c"}
+        except Exception as e:  # noqa: BLE001
+            log(f"result check could not run: {e!r}")
+            check = {"ok": False, "error": repr(e), "rel_l2": float("nan"), "rel_max": float("nan"), "sum_y": float("nan")}
+        out["check"] = check
+        out["config"]["check"] = check  # the driver's record keeps ``config`` verbatim
+        if not check["ok"]:
+            out["valid"] = False
+    if out.get("aux") is not None or check is not None:
+        try:
+            out["roofline"]["secondary"] = secondary_summary(out)
+        except Exception as e:  # noqa: BLE001
+            log(f"roofline.secondary failed: {e!r}")
+    if rank == 0:
         emit(out)
+    failed = check is not None and not check["ok"]
+    if failed and rank == 0:
+        log(f"RESULT CHECK FAILED: {check}")
     if use_dist:
         dist.destroy_process_group()
+    if failed:
+        raise SystemExit(3)
 
 
 if __name__ == "__main__":

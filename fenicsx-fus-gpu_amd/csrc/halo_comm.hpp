@@ -455,15 +455,40 @@ struct IpcOpened {
   hipIpcMemHandle_t handle;
   void* ptr;
   int refs;
+  std::vector<int> importers;  // devices of this process that may dereference ``ptr``
 };
 inline std::vector<IpcOpened>& ipc_opened_table() {  // guarded by local_worlds_mutex()
   static std::vector<IpcOpened> t;
   return t;
 }
-inline hipError_t ipc_open_shared(const hipIpcMemHandle_t& handle, void** out) {
+// ``importer``: the device whose kernels will use the mapping (the communicator's); ``exporter``: the device the arena lives on,
+// as an ordinal of THIS process (-1: not visible here).  hipIpcMemLazyEnablePeerAccess enables peer access for the device that
+// is current at the first open only: a second rank of this process on ANOTHER device that borders the same neighbour gets
+// the cached pointer and must have peer access to the exporter enabled for itself, or its send / receive kernel faults
+// (ADVICE r4).
+inline hipError_t ipc_open_shared(const hipIpcMemHandle_t& handle, int importer, int exporter, void** out) {
   std::lock_guard<std::mutex> lock(local_worlds_mutex());
   for (IpcOpened& o : ipc_opened_table())
     if (!std::memcmp(&o.handle, &handle, sizeof handle)) {
+      bool known = false;
+      for (int d : o.importers) known = known || d == importer;
+      if (!known) {
+        if (exporter >= 0 && exporter != importer) {
+          int cur = -1;
+          hipError_t e = hipGetDevice(&cur);
+          if (e == hipSuccess && cur != importer) e = hipSetDevice(importer);
+          if (e == hipSuccess) {
+            e = hipDeviceEnablePeerAccess(exporter, 0);
+            if (e == hipErrorPeerAccessAlreadyEnabled) {
+              (void)hipGetLastError();
+              e = hipSuccess;
+            }
+          }
+          if (cur >= 0 && cur != importer) (void)hipSetDevice(cur);
+          if (e != hipSuccess) return e;
+        }
+        o.importers.push_back(importer);
+      }
       ++o.refs;
       *out = o.ptr;
       return hipSuccess;
@@ -471,7 +496,7 @@ inline hipError_t ipc_open_shared(const hipIpcMemHandle_t& handle, void** out) {
   void* p = nullptr;
   const hipError_t e = hipIpcOpenMemHandle(&p, handle, hipIpcMemLazyEnablePeerAccess);
   if (e != hipSuccess) return e;
-  ipc_opened_table().push_back(IpcOpened{handle, p, 1});
+  ipc_opened_table().push_back(IpcOpened{handle, p, 1, {importer}});
   *out = p;
   return hipSuccess;
 }
@@ -638,7 +663,7 @@ inline int halo_ipc_connect(Halo* h, int nblobs, const void* const* blobs) {
         }
         (void)hipGetLastError();
         void* p = nullptr;
-        const hipError_t e = ipc_open_shared(v.hd->handle, &p);
+        const hipError_t e = ipc_open_shared(v.hd->handle, c->device, peer_dev, &p);
         if (e != hipSuccess) {
           c->last_error = "hipIpcOpenMemHandle (rank " + std::to_string(rank) + "): " + hipGetErrorString(e);
           return false;

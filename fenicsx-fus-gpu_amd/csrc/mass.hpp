@@ -217,7 +217,7 @@ inline hipError_t launch_mass_plan(const T* x, const T* consts, T* y, const T* d
   else if (ept <= 11) FUS_MASS_LAUNCH(11);
   else FUS_MASS_LAUNCH(16);
 #undef FUS_MASS_LAUNCH
-  return hipGetLastError();
+  return settle_launch_signal(stream, sig, hipGetLastError());
 }
 
 }  // namespace fus

@@ -99,6 +99,13 @@ inline LaunchSignal post_launch_signal(hipStream_t stream, uint64_t* flag, uint6
   v.push_back(PendingLaunchSignal{stream, LaunchSignal{flag, seq}});
   return old;
 }
+// A launch that took a signal and then failed (hipGetLastError() != hipSuccess) has not published it: put it back, so that
+// the next planned launch of the stream -- or fus_comm_fork_flush / the next fork / join -- does.  Without this the
+// communicator's wait kernel (or gated send kernel) would spin for FUS_IPC_SPIN_SECONDS and poison the halo.
+inline hipError_t settle_launch_signal(hipStream_t stream, const LaunchSignal& sig, hipError_t e) {
+  if (e != hipSuccess && sig.flag != nullptr) (void)post_launch_signal(stream, sig.flag, sig.seq);
+  return e;
+}
 // the signal still waiting to be carried for ``flag`` (no planned launch has come), with its stream; {nullptr} if none
 inline LaunchSignal take_launch_signal_of(const uint64_t* flag, hipStream_t* stream) {
   std::lock_guard<std::mutex> lock(pending_launch_signals_mutex());

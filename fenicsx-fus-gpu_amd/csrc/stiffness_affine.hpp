@@ -104,10 +104,11 @@ inline hipError_t launch_stiffness_plan_affine(const T* x, const T* cc, T* y, co
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
+  const LaunchSignal sig = take_launch_signal(stream);
   hipLaunchKernelGGL((stiffness_plan_affine_kernel<T, P, CPB, ALIAS, PADLDS, MINW>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, wratio,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, take_launch_signal(stream));
-  return hipGetLastError();
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig);
+  return settle_launch_signal(stream, sig, hipGetLastError());
 }
 
 }  // namespace fus

@@ -259,18 +259,19 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   plan_flush<T, SPT, BLOCK>(y, mydof, nu_b, tid, sy);
 }
 
-template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, bool PREG>
+// CPB: cells per batch = the plan's entities per batch (default: the plan builder's own choice, ~256 threads per workgroup).
+template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, bool PREG, int CPB = plan_cells_per_batch<P>()>
 inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs,
                                              const T* pts, const T* wts, const void* workspace, const T* dphi,
                                              int64_t ncell, hipStream_t stream, bool ordered = false, bool use_runs = false) {
-  constexpr int CPB = plan_cells_per_batch<P>();
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
+  const LaunchSignal sig = take_launch_signal(stream);
   hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, take_launch_signal(stream));
-  return hipGetLastError();
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig);
+  return settle_launch_signal(stream, sig, hipGetLastError());
 }
 
 }  // namespace fus

@@ -258,10 +258,11 @@ inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* 
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
+  const LaunchSignal sig = take_launch_signal(stream);
   hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GPRE>), dim3((unsigned)v.nbatch),
                      dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, take_launch_signal(stream));
-  return hipGetLastError();
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig);
+  return settle_launch_signal(stream, sig, hipGetLastError());
 }
 
 }  // namespace fus

@@ -222,10 +222,11 @@ inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, co
   constexpr int MINW = 1;
   // stiffness-only: the ring sizes of the stiffness kernel (its register profile + one more gather)
   constexpr int RING = MASS ? westervelt_g_ring<P>() : (P >= 6 ? plan_g_ring<P>() : P + 1);
+  const LaunchSignal sig = take_launch_signal(stream);
   hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, RING, MASS>), dim3((unsigned)pv.nbatch),
                      dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell,
-                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr, take_launch_signal(stream));
-  return hipGetLastError();
+                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr, sig);
+  return settle_launch_signal(stream, sig, hipGetLastError());
 }
 
 // Fused RK4 stage vector kernel of the Westervelt solver: as rk4_stage_kernel (rk4.hpp) but the

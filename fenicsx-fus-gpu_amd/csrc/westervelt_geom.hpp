@@ -197,10 +197,11 @@ inline hipError_t launch_westervelt_cell_geom(const T* u, const T* v, const T* c
   if (ncell <= 0) return hipSuccess;
   PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
+  const LaunchSignal sig = take_launch_signal(stream);
   hipLaunchKernelGGL((westervelt_cell_geom_kernel<T, P, CPB, 1, MASS>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u,
                      v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, pv.nu, pv.udofs, pv.slot, dphi, ncell,
-                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr, take_launch_signal(stream));
-  return hipGetLastError();
+                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr, sig);
+  return settle_launch_signal(stream, sig, hipGetLastError());
 }
 
 }  // namespace fus

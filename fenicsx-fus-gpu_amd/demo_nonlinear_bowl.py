@@ -34,7 +34,10 @@ def main():
     ap.add_argument("--cells", type=int, default=None, help="cells per direction of the whole box (default: 2 per wavelength at P = 6 scale)")
     ap.add_argument("--length", type=float, default=None, help="domain length in m (reference: 0.08; default here 0.012 so the default run takes seconds)")
     ap.add_argument("--reference-sequence", action="store_true", help="the reference's unfused launch sequence (four cell kernels per stage)")
-    ap.add_argument("--in-kernel-geometry", action="store_true")
+    ap.add_argument("--geometry", default="auto", choices=["auto", "kernel", "array"],
+                    help="auto: G formed in the cell kernel from the vertices for the fused stage of degree >= 3 (the solver's default); "
+                         "array: the reference's precomputed G array; kernel: force the kernel form")
+    ap.add_argument("--in-kernel-geometry", action="store_true", help="same as --geometry kernel")
     ap.add_argument("--max-steps", type=int, default=None)
     ap.add_argument("--out-dir", default=None, help="write the last-period pressure fields there")
     a = ap.parse_args()
@@ -92,7 +95,7 @@ def main():
         print(f"Number of degrees-of-freedom: {mesh.ndofs_global}", flush=True)
     solver = nls.WesterveltSpectral3D(mesh, float_type, speed_of_sound, density, source_frequency, source_amplitude,
                                       nonlinear_coefficient, attenuation_coefficient_dB, comm=comm, fused=not a.reference_sequence,
-                                      in_kernel_geometry=a.in_kernel_geometry)
+                                      in_kernel_geometry=True if (a.in_kernel_geometry or a.geometry == "kernel") else ("auto" if a.geometry == "auto" else False))
     solver.init()
 
     # sampling set: the owned dofs on the mid-z plane of the global dof grid

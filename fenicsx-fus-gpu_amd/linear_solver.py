@@ -104,12 +104,17 @@ def snap_time_step(mesh_size, P, speed_of_sound, source_frequency, domain_length
 class LinearSpectral3D(StepGraphMixin):
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1500.0, density=1000.0,
                  source_frequency=0.5e6, source_amplitude=60000.0, comm=None, fused=True,
-                 source_time="tn", overlap=True, halo_kernels=None, affine="auto", in_kernel_geometry=False,
-                 halo_plan=None, defer_setup_exchange=False, reference_speed_of_sound=None):
+                 source_time="tn", overlap=True, halo_kernels=None, affine="auto", in_kernel_geometry="auto",
+                 halo_plan=None, defer_setup_exchange=False, reference_speed_of_sound=None, keep_G=False):
         """``speed_of_sound`` / ``density``: scalars, or one value per cell (heterogeneous medium: the DG0 material arrays of
         the reference's drivers, in the caller's cell order).  ``reference_speed_of_sound``: the c of the source term
         ``p0 w0 / c cos(w0 t)`` (cuda/demo_linear_box.py:515-530 uses the scalar of its homogeneous medium); default: the
-        scalar given, or the mean over the cells of the source facets."""
+        scalar given, or the mean over the cells of the source facets.
+        ``in_kernel_geometry``: ``"auto"`` (default) -- on non-affine cells of degree >= 3 the stiffness apply forms G in the kernel
+        from the 8 vertices of each cell (the reference's geometry is P1 everywhere, cuda/demo_nonlinear_bowl.py:317): -18 % per
+        step and no 6 n^3-value-per-cell G array at config 3; ``False`` keeps the reference's G stream
+        (numba-cpu/precompute.py:115-163), ``True`` forces the kernel form for any degree.  ``keep_G``: keep the G array on the
+        device although the apply does not read it (``solver.G_array``)."""
         self.mesh, self.P = mesh, mesh.P
         self.dt_np = np.dtype(float_type)
         self.tdt = _lib.torch_dtype(float_type)
@@ -119,6 +124,10 @@ class LinearSpectral3D(StepGraphMixin):
         self.f0, self.p0 = float(source_frequency), float(source_amplitude)
         self.w0 = 2.0 * np.pi * self.f0
         self.fused, self.source_time = bool(fused), source_time
+        if comm is not None:  # an MPI.Comm (the reference's comm = MPI.COMM_WORLD) becomes the bootstrap of a NativeComm
+            from .scatterer import as_comm
+
+            comm = as_comm(comm)
         self.comm = comm
         P, n = self.P, self.P + 1
         dev = torch.device("cuda", torch.cuda.current_device())
@@ -159,12 +168,18 @@ class LinearSpectral3D(StepGraphMixin):
         self.stiff = ops.stiffness_operator(P, D.flatten(), ft, affine_weights=w3 if self.affine else None)
         # opt-in for non-affine (trilinear) cells: G formed in the kernel from the cell vertices; the
         # per-cell argument of the stiffness apply is then the cell's vertex ids instead of G
+        if in_kernel_geometry == "auto":
+            in_kernel_geometry = P >= 3  # below that G is not the dominant stream and the kernel form loses
         self.in_kernel_geometry = bool(in_kernel_geometry) and not self.affine
+        self.G_array = self.G  # the reference's geometric-factor array (None once dropped)
         if self.in_kernel_geometry:
             pts1, wts1 = gll_points_weights(P)
             self.x_dofs = td(mesh.x_dofs)
             self.stiff = ops.stiffness_operator(P, D.flatten(), ft, geometry=(self.x_dofs, mesh.x_g, pts1, wts1))
             self.G = self.x_dofs  # x_dofs rows travel in the G position (cell sub-ranges slice them)
+            if not keep_G:
+                self.G_array = None  # 6 n^3 values per cell nobody reads any more (config 3: 945 MB)
+                del G_d
         self.mass_cell = ops.mass_operator(n**3, ft)
         self.mass_facet = ops.mass_operator(n * n, ft)
         self.axpy = ops.axpy(self.ndofs)
@@ -178,6 +193,11 @@ class LinearSpectral3D(StepGraphMixin):
             # one process has no index exchange to run); default: exchanged over ``comm`` now
             self.halo = HaloApply(mesh, self.stiff, comm, ft, overlap=overlap, kernels=halo_kernels, plan=halo_plan)
             self.fwd_v = scatter_forward(comm, self.halo.owners_data, self.halo.ghosts_data, mesh.nlocal, ft, halo_kernels)
+        # the facet mass applies of a stage are ``boundary_terms`` of HaloApply: in its concurrent schedule they run on the
+        # communicator's stream WHILE the interior stiffness launch adds into the same b with float atomics (interior cells
+        # on the x = 0 / x = L faces touch exactly the facet dofs).  The atomic-free gather kernel's plain load + store would
+        # lose those adds: next to a halo the facet operator is the float-atomic twin.
+        self._mass_facet_stage = self.mass_facet if self.halo is None else self.halo.concurrent_safe(self.mass_facet)
 
         z = lambda: torch.zeros(self.ndofs, dtype=self.tdt, device=dev)  # noqa: E731
         self.u, self.v, self.u0, self.v0 = z(), z(), z(), z()
@@ -236,8 +256,8 @@ class LinearSpectral3D(StepGraphMixin):
         fill(0.0, self.b)
 
         def facets():
-            self.mass_facet(self.g, self.facet_coeff1, self.b, self.detJ_f1, self.fdm1)
-            self.mass_facet(self.v_n, self.facet_coeff2, self.b, self.detJ_f2, self.fdm2)
+            self._mass_facet_stage(self.g, self.facet_coeff1, self.b, self.detJ_f1, self.fdm1)
+            self._mass_facet_stage(self.v_n, self.facet_coeff2, self.b, self.detJ_f2, self.fdm2)
 
         if self.halo is None:
             self.stiff(self.u_n, self.cell_coeff2, self.b, self.G, self.dofmap)

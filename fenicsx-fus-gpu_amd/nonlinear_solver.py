@@ -33,15 +33,22 @@ class WesterveltSpectral3D(StepGraphMixin):
     def __init__(self, mesh, float_type=np.float64, speed_of_sound=1480.0, density=1000.0,
                  source_frequency=1.1e6, source_amplitude=None, nonlinear_coefficient=3.5,
                  attenuation_coefficient_dB=0.2, comm=None, source_time="tn", overlap=True, fused=False,
-                 in_kernel_geometry=False, uniform_ratio="auto", halo_plan=None, defer_setup_exchange=False,
-                 reference_speed_of_sound=None, reference_density=None):
+                 in_kernel_geometry="auto", uniform_ratio="auto", halo_plan=None, defer_setup_exchange=False,
+                 reference_speed_of_sound=None, reference_density=None, keep_G=False):
         """``speed_of_sound``, ``density``, ``nonlinear_coefficient``, ``attenuation_coefficient_dB``: scalars, or one value per
         cell in the caller's cell order (the DG0 material arrays of cuda/demo_nonlinear_bowl.py:166-178 -- water / skull / ...).
         ``reference_speed_of_sound`` / ``reference_density``: the scalars of the source term and of the default source amplitude
         (the reference uses those of the coupling medium); default: the scalars given, or the means over the source-facet cells.
-        A heterogeneous medium takes the two-gather cell pass by itself (c4 / c3 = delta / c^2 is no longer uniform)."""
+        A heterogeneous medium takes the two-gather cell pass by itself (c4 / c3 = delta / c^2 is no longer uniform).
+        ``in_kernel_geometry``: ``"auto"`` (default) -- the fused stage of degree >= 3 forms G in the cell kernel from the 8
+        vertices of each (trilinear) cell and the G array is dropped unless ``keep_G``; ``False``: the reference's G stream;
+        the reference launch sequence (``fused=False``) always reads G."""
         from .linear_solver import per_cell
 
+        if comm is not None:  # an MPI.Comm (the reference's comm = MPI.COMM_WORLD) becomes the bootstrap of a NativeComm
+            from .scatterer import as_comm
+
+            comm = as_comm(comm)
         self.mesh, self.P = mesh, mesh.P
         ft = np.dtype(float_type)
         self.tdt_np = ft
@@ -145,7 +152,10 @@ class WesterveltSpectral3D(StepGraphMixin):
         if comm is not None and getattr(comm, "size", 1) > 1 and getattr(comm, "_world_id", None) is None:
             import torch.distributed as dist
 
-            if dist.is_available() and dist.is_initialized():
+            if hasattr(comm, "allgather_floats"):  # NativeComm: over its bootstrap (torch.distributed or MPI)
+                every = comm.allgather_floats([kmin, kmax])
+                kmin, kmax = float(every[:, 0].min()), float(every[:, 1].max())
+            elif dist.is_available() and dist.is_initialized():
                 on_gpu = dist.get_backend() == "nccl"
                 t = torch.tensor([-kmin, kmax], dtype=torch.float64, device=self.dev if on_gpu else "cpu")
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -156,7 +166,11 @@ class WesterveltSpectral3D(StepGraphMixin):
         self.w = z() if self.kappa is not None else None
         # opt-in (fused mode): G and detJ formed in the cell kernel from the vertices -- the cells of
         # the reference's meshes are trilinear (P1 geometry, cuda/demo_nonlinear_bowl.py:317)
+        if in_kernel_geometry == "auto":
+            in_kernel_geometry = self.fused and P >= 3
         self.in_kernel_geometry = bool(in_kernel_geometry)
+        if self.in_kernel_geometry and self.fused and not keep_G:
+            self.G = None  # the fused stage does not read it (P = 6, 36^3 cells: 768 MB)
         if self.in_kernel_geometry:
             from .gll import tabulate_1d
 

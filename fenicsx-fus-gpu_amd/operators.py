@@ -51,6 +51,15 @@ def use_plan(flag: bool):
 # consecutive cells adjacent (BoxMesh, a bandwidth-reordered dolfinx mesh) is left alone; a random cell
 # order goes from 0.365 back to 0.243 ms per apply at P = 4, 10 M dofs (profiles/r02c_numbering.log).
 _LOCALITY_ORDER = os.environ.get("FUS_PLAN_LOCALITY_ORDER", "1") != "0"
+# Two-row strip order for the plans of the scatter-bound kernels (plan_tiles.py; FUS_PLAN_STRIP_ORDER=0 / use_strip_order(False)
+# turns it off)
+_STRIP_ORDER = os.environ.get("FUS_PLAN_STRIP_ORDER", "1") != "0"
+
+
+def use_strip_order(flag: bool):
+    global _STRIP_ORDER
+    _STRIP_ORDER = bool(flag)
+
 
 
 def use_locality_order(flag: bool):
@@ -78,16 +87,22 @@ class _PlanCache:
         held, self._recording = self._recording or [], None
         return held
 
-    def get(self, dofmap: torch.Tensor, exclusive_ndofs=None, external_use=None):
-        """-> (workspace tensor, entities_per_batch).  ``exclusive_ndofs`` (length of the vectors the plan is applied to):
+    def get(self, dofmap: torch.Tensor, exclusive_ndofs=None, external_use=None, strips=False):
+        """-> (workspace tensor, entities_per_batch).  ``strips``: the plan of a kernel bound by its scatter side (in-kernel
+        geometry, affine cells): its cell order interleaves adjacent rows of cells (``plan_tiles.two_row_strip_order``: 2 x 5
+        pieces instead of 10 cells in a row at P = 4, -8 % distinct dofs per batch) when that lowers the number of distinct dofs
+        the batches touch -- a separate cache entry from the row-ordered plan of the same dofmap, which the general-G kernels keep.  ``exclusive_ndofs`` (length of the vectors the plan is applied to):
         the plan also carries EXCLUSIVE-DOF MARKS (``fus_plan_mark_exclusive``: a dof touched by exactly one batch is finished
         with a plain load + store instead of a float atomic), a separate cache entry from the unmarked plan of the same
         dofmap.  ``external_use``: device int32[ndofs], what else adds into each dof while a launch with this plan runs
         (default: nothing -- the launch runs alone or only next to launches of the same stream)."""
         lib = _lib.load()
         nent, N = dofmap.shape
+        strips = bool(strips) and _STRIP_ORDER and exclusive_ndofs is None
         key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index,
                None if exclusive_ndofs is None else (int(exclusive_ndofs), None if external_use is None else (external_use.data_ptr(), external_use._version)))
+        if strips:
+            key = key + ("strips",)
         hit = self._plans.get(key)
         if hit is None:
             epb = lib.fus_plan_entities_per_batch(N)
@@ -120,6 +135,20 @@ class _PlanCache:
                     if distinct_dofs(ws2) < 0.97 * distinct_dofs(ws):
                         ws, ws2, self.last_order = ws2, ws, order
                     lib.fus_plan_release(ws2.data_ptr())  # the plan that was not kept
+            if strips and nent > 4 * epb:
+                n = int(round(N ** (1.0 / 3.0)))
+                if n >= 3 and n**3 == N:  # cells of degree >= 2 in tensor-product local order
+                    from . import plan_tiles
+
+                    faces = torch.from_numpy(plan_tiles.face_interior_local_dofs(n)).to(dofmap.device)
+                    cand = plan_tiles.two_row_strip_order(dofmap[:, faces].cpu().numpy(),
+                                                          None if self.last_order is None else self.last_order.cpu().numpy())
+                    if cand is not None:
+                        order = torch.from_numpy(cand.astype("int32")).to(dofmap.device)
+                        ws2 = build(order)
+                        if distinct_dofs(ws2) < 0.97 * distinct_dofs(ws):
+                            ws, ws2, self.last_order = ws2, ws, order
+                        lib.fus_plan_release(ws2.data_ptr())
             if exclusive_ndofs is not None:
                 use = (external_use.to(torch.int32).clone() if external_use is not None
                        else torch.zeros(int(exclusive_ndofs), dtype=torch.int32, device=dofmap.device))
@@ -140,10 +169,13 @@ class _PlanCache:
         return hit[0], hit[1]
 
     def has(self, dofmap: torch.Tensor) -> bool:
-        """True if the (unmarked) plan of ``dofmap`` is cached: an apply with it does no set-up work (no allocation, no host
-        synchronisation) -- what ``HaloApply`` needs to know before it lets a launch carry a fork signal."""
+        """True if an (unmarked) plan of ``dofmap`` is cached -- row-ordered or strip-ordered: an operator uses one of the two
+        consistently, and ``HaloApply`` asks only for a cell range the operator has been applied to before -- so an apply with
+        it does no set-up work (no allocation, no host synchronisation): what ``HaloApply`` needs to know before it lets a
+        launch carry a fork signal."""
         nent, N = dofmap.shape
-        return (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index, None) in self._plans
+        key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index, None)
+        return key in self._plans or key + ("strips",) in self._plans
 
     def clear(self):
         lib = _lib.load()
@@ -503,7 +535,7 @@ class _StiffnessOperator(_Launchable):
                 xd = G
             if xd.shape[0] != ncell:
                 raise ValueError(f"geometry: x_dofs has {xd.shape[0]} cells, dofmap has {ncell}")
-            ws, _ = _PLANS.get(dofmap)
+            ws, _ = _PLANS.get(dofmap, strips=True)
             _lib.check(
                 self._fn_geom(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), xg.data_ptr(), xd.data_ptr(),
                               pt.data_ptr(), wt.data_ptr(), ws.data_ptr(), dphi_t.data_ptr(), self.P, int(ncell),
@@ -511,7 +543,7 @@ class _StiffnessOperator(_Launchable):
                 "fus_stiffness_apply_planned_geom",
             )
         elif self._wratio is not None:
-            ws, _ = _PLANS.get(dofmap)
+            ws, _ = _PLANS.get(dofmap, strips=True)
             _lib.check(
                 self._fn_affine(x.data_ptr(), cell_constants.data_ptr(), y.data_ptr(), G.data_ptr(),
                                 self._wratio.data_ptr(), ws.data_ptr(), dphi_t.data_ptr(), self.P, int(ncell),
@@ -537,7 +569,7 @@ class _StiffnessOperator(_Launchable):
         lazily inside the first apply."""
         _req(dofmap, torch.int32, "dofmap")
         if _USE_PLAN and dofmap.shape[0] > 0:
-            _PLANS.get(dofmap)
+            _PLANS.get(dofmap, strips=self._geom is not None or self._wratio is not None)
 
     # numba-cpu flavour: op(x, cell_constants, y, G, dofmap)
     def __call__(self, x, cell_constants, y, G, dofmap):
@@ -639,7 +671,7 @@ class _WesterveltCellGeomOperator:
                 raise ValueError(f"{name} must have one value per cell")
         if ncell == 0:
             return
-        ws, _ = _PLANS.get(dofmap)
+        ws, _ = _PLANS.get(dofmap, strips=True)
         _lib.check(
             self._fn(u.data_ptr(), v.data_ptr(), c2.data_ptr(), c3.data_ptr(), c4.data_ptr(), c5.data_ptr(),
                      b.data_ptr(), m.data_ptr(), self.x_g.data_ptr(), x_dofs.data_ptr(), self.pts.data_ptr(),
@@ -667,7 +699,7 @@ def _westervelt_stiffness_only(self, u, v, c3, c4, b, G_or_xdofs, dofmap, geom):
         raise ValueError(f"dofmap [ncell, {nd}] and one c3 / c4 value per cell expected")
     if ncell == 0:
         return
-    ws, _ = _PLANS.get(dofmap)
+    ws, _ = _PLANS.get(dofmap, strips=geom)
     if geom:
         _req(G_or_xdofs, torch.int32, "x_dofs")
         if tuple(G_or_xdofs.shape) != (ncell, 8):

@@ -22,6 +22,8 @@ MI355X-first differences from the reference:
     overlaps the exchange (``HaloApply`` below).
 
 ``comm`` selects the transport:
+  * an ``mpi4py.MPI.Comm`` -- what the reference's drivers pass (cuda/demo_linear_box.py:41, 206-207) -- is accepted as it
+    is: it becomes the bootstrap of a ``NativeComm`` (``as_comm``; ``mpi_bootstrap.py``), no ``torch.distributed`` needed;
   * ``NativeComm`` (default of the drivers): the exchange lives in libfusgpu.so
     (csrc/halo_comm.hpp, C ABI ``fus_halo_*``): pack, ``ncclGroupStart ...
     ncclSend/ncclRecv ... ncclGroupEnd`` and unpack are issued from C++ on a
@@ -81,6 +83,13 @@ class TorchComm:
         dist.all_reduce(t, op=dist.ReduceOp.MIN, group=self.group)
         return bool(t.item() == 1.0)
 
+    def bcast_bytes(self, payload: bytes, root: int = 0) -> bytes:
+        """``payload`` of group rank ``root`` on every rank (same length everywhere: the 128-byte RCCL unique id)."""
+        dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
+        t = torch.frombuffer(bytearray(payload), dtype=torch.uint8).clone().to(dev)
+        dist.broadcast(t, src=dist.get_global_rank(self.group, root) if self.group is not None else root, group=self.group)
+        return bytes(t.cpu().numpy().tobytes())
+
     def allgather_bytes(self, payload: bytes):
         """Every rank's ``payload`` (host bytes of any length), as a list indexed by rank."""
         dev = torch.device("cuda", torch.cuda.current_device()) if self.backend == "nccl" else torch.device("cpu")
@@ -122,7 +131,11 @@ class NativeComm:
     _peer_local = {}  # (world_id, halo index) -> {rank: blob}: in-process PEER worlds
     _peer_gathered = {}  # (world_id, halo index) -> {rank: blob} of ALL processes (hybrid worlds: gathered once per process)
 
-    def __init__(self, group=None, local=None, transport="rccl", hosted=None):
+    def __init__(self, group=None, local=None, transport="rccl", hosted=None, bootstrap=None):
+        """``bootstrap``: the object that carries the one-off set-up collectives (rank / size, the votes, the all-gather of
+        the arena handles or the broadcast of the RCCL id, the index exchange) instead of the default ``torch.distributed``
+        group -- ``mpi_bootstrap.MpiBootstrap(MPI.COMM_WORLD)`` in an ``mpirun`` world (``as_comm`` builds it from a raw
+        MPI communicator)."""
         import ctypes as C
 
         if transport not in ("rccl", "peer"):
@@ -156,7 +169,10 @@ class NativeComm:
                 self.backend = "local"
                 _lib.check(lib.fus_comm_create_local(world_id, self.size, self.rank, C.byref(self.handle)), "fus_comm_create_local")
             return
-        if dist.is_available() and dist.is_initialized():
+        if bootstrap is not None:
+            self._torch = bootstrap  # same methods as TorchComm (all_ok, allgather_bytes, bcast_bytes, barrier, alltoallv_int64)
+            self.rank, self.size = int(bootstrap.rank), int(bootstrap.size)
+        elif dist.is_available() and dist.is_initialized():
             self._torch = TorchComm(group)
             self.rank, self.size = self._torch.rank, self._torch.size
         else:
@@ -176,13 +192,9 @@ class NativeComm:
             raise _lib.FusGpuError(f"RCCL is not usable on every rank (this rank: {err or 'ok'}): no native communicator")
         if err is not None:
             raise _lib.FusGpuError(err)
-        uid = torch.frombuffer(bytearray(buf.raw), dtype=torch.uint8).clone()
+        raw = bytes(buf.raw)
         if self.size > 1:
-            dev = torch.device("cuda", torch.cuda.current_device()) if self._torch.backend == "nccl" else torch.device("cpu")
-            t = uid.to(dev)
-            dist.broadcast(t, src=dist.get_global_rank(group, 0) if group is not None else 0, group=group)
-            uid = t.cpu()
-        raw = bytes(uid.numpy().tobytes())
+            raw = self._torch.bcast_bytes(raw, 0)
         rc = lib.fus_comm_create(raw, self.size, self.rank, C.byref(self.handle))
         err = None if rc == 0 else f"fus_comm_create: {lib.fus_error_string(rc).decode()}: {(lib.fus_comm_last_error(None) or b'?').decode()}"
         if self.size > 1 and not self._torch.all_ok(err is None):
@@ -195,12 +207,24 @@ class NativeComm:
     def alltoallv_int64(self, send_np, send_counts, recv_counts):
         """Set-up path (index exchange of compute_scatterer_data): through torch.distributed."""
         if self._torch is None:
-            raise _lib.FusGpuError("NativeComm: the index exchange of a multi-rank world needs torch.distributed")
+            raise _lib.FusGpuError("NativeComm: the index exchange of a multi-rank world needs a bootstrap (torch.distributed or an MPI communicator)")
         return self._torch.alltoallv_int64(send_np, send_counts, recv_counts)
 
     def barrier(self):
         if self._torch is not None:
             self._torch.barrier()
+
+    def allgather_floats(self, values):
+        """Every rank's ``values`` (a few host floats) as an array [size, len(values)] -- set-up agreements of the drivers
+        (a min / max over the ranks) through whatever carries this communicator's bootstrap.  One-rank world or all ranks in
+        this process without a bootstrap: the local values alone."""
+        import struct
+
+        v = [float(x) for x in values]
+        if self._torch is None or self.size == 1:
+            return np.asarray([v])
+        blobs = self._torch.allgather_bytes(struct.pack(f"<{len(v)}d", *v))
+        return np.asarray([struct.unpack(f"<{len(v)}d", b) for b in blobs])
 
     def close(self):
         if self.handle:
@@ -333,15 +357,58 @@ class NativeComm:
 
 
 def default_comm(group=None):
-    """The communicator a driver should use at N > 1 (one process per GPU, ``torch.distributed`` initialised): the PEER
-    transport of libfusgpu.so unless ``FUS_HALO=native`` (grouped RCCL send / recv) or ``FUS_HALO=torch``
-    (``all_to_all_single``).  Creation fails on all ranks or on none."""
+    """The communicator a driver should use at N > 1 (one process per GPU): the PEER transport of libfusgpu.so unless
+    ``FUS_HALO=native`` (grouped RCCL send / recv) or ``FUS_HALO=torch`` (``all_to_all_single``).  Bootstrap: the
+    ``torch.distributed`` group if one is initialised; otherwise ``MPI.COMM_WORLD`` when mpi4py is importable (a driver
+    started with ``mpirun``, as the reference's are: cuda/demo_linear_box.py:41); otherwise a one-rank world.  Creation fails
+    on all ranks or on none."""
     import os
 
     kind = os.environ.get("FUS_HALO", "peer")
-    if kind == "torch":
-        return TorchComm(group)
-    return NativeComm(group, transport="peer" if kind == "peer" else "rccl")
+    if dist.is_available() and dist.is_initialized():
+        if kind == "torch":
+            return TorchComm(group)
+        return NativeComm(group, transport="peer" if kind == "peer" else "rccl")
+    from . import mpi_bootstrap
+
+    world = mpi_bootstrap.world_if_available()
+    if world is not None:
+        return as_comm(world)
+    return NativeComm(transport="peer" if kind != "native" else "rccl")
+
+
+_MPI_COMMS = {}  # id(MPI communicator) -> (the communicator itself, its NativeComm): one library communicator per MPI communicator
+
+
+def as_comm(comm):
+    """The package communicator behind whatever a driver passes as ``comm``:
+
+      * ``NativeComm`` / ``TorchComm`` (or a stand-in with their ``rank`` / ``size`` / ``alltoallv`` members): itself;
+      * an ``mpi4py.MPI.Comm`` -- what the reference's drivers pass (cuda/demo_linear_box.py:41, 206-207;
+        cuda/scatterer.py:104-110): a ``NativeComm`` bootstrapped over it (``mpi_bootstrap.MpiBootstrap``), transport PEER
+        unless ``FUS_HALO=native`` (RCCL); built once per MPI communicator (collectively: every rank must pass it at the same
+        point, as every rank of the reference's driver reaches its ``scatter_reverse(comm, ...)`` line);
+      * ``None``: ``None``.
+
+    Anything else raises ``TypeError`` naming the accepted kinds."""
+    import os
+
+    from . import mpi_bootstrap
+
+    if comm is None or isinstance(comm, (NativeComm, TorchComm)):
+        return comm
+    if mpi_bootstrap.is_mpi_comm(comm):
+        hit = _MPI_COMMS.get(id(comm))
+        if hit is None or hit[0] is not comm or not hit[1].handle:
+            kind = os.environ.get("FUS_HALO", "peer")
+            hit = (comm, NativeComm(transport="rccl" if kind == "native" else "peer", bootstrap=mpi_bootstrap.MpiBootstrap(comm)))
+            _MPI_COMMS[id(comm)] = hit
+        return hit[1]
+    if isinstance(getattr(comm, "rank", None), int) and isinstance(getattr(comm, "size", None), int) and \
+            (comm.size == 1 or callable(getattr(comm, "alltoallv", None))):
+        return comm  # a TorchComm-shaped object (tests, bench.py's staged rehearsal communicator)
+    raise TypeError(f"comm: expected a NativeComm, a TorchComm, or an MPI communicator (mpi4py.MPI.Comm: Get_rank / Get_size / allgather / "
+                    f"alltoall / bcast), got {type(comm).__name__}")
 
 
 class _NativeScatter:
@@ -550,10 +617,16 @@ class _Scatter:
         self.end(buffer, self.begin(buffer))
 
 
-def begin_all(pairs):
+def begin_all(pairs, arm_join=None):
     """Post the exchanges of several ``(scatter closure, vector)`` pairs; returns ``[(closure, vector, handle)]``
     for ``closure.end(vector, handle)``.  Native closures of one communicator and one direction go out as ONE
-    RCCL group (``fus_halo_*_begin_group``): the RK4 stage's two forward scatters cost one launch, not two."""
+    RCCL group (``fus_halo_*_begin_group``): the RK4 stage's two forward scatters cost one launch, not two.
+
+    ``arm_join`` (a ``NativeComm``): these exchanges are the LAST work of an apply on the communicator's stream; the receive
+    kernel of the last one publishes the join flag (``fus_comm_arm_join``).  The library hands the join to the last halo of
+    ONE begin call, so it is armed right before the call that posts the last exchange -- the group, or, when the pairs go out
+    one by one (more than 8, mixed closures), the last ``begin`` (armed before the first of several calls, the
+    first receive kernel would publish the flag while the later exchanges are still queued)."""
     import ctypes as C
 
     pairs = list(pairs)
@@ -566,18 +639,30 @@ def begin_all(pairs):
         halos = (C.c_void_p * len(pairs))(*[sc.handle for sc, _ in pairs])
         bufs = (C.c_void_p * len(pairs))(*[vec.data_ptr() for _, vec in pairs])
         fn = getattr(_lib.load(), "fus_halo_reverse_begin_group" if native[0].reverse else "fus_halo_forward_begin_group")
+        if arm_join is not None and native[0].comm is arm_join:
+            arm_join.arm_join()
         _lib.check(fn(halos, bufs, len(pairs), _lib.stream_ptr()), "fus_halo_begin_group", native[0].comm.handle)
         return [(sc, vec, None) for sc, vec in pairs]
-    return [(sc, vec, sc.begin(vec)) for sc, vec in pairs]
+    out = []
+    for i, (sc, vec) in enumerate(pairs):
+        if arm_join is not None and i == len(pairs) - 1 and isinstance(sc, _NativeScatter) and sc.comm is arm_join:
+            sc._ensure_connected()  # nothing that can fail between arming and the begin that takes the join
+            arm_join.arm_join()
+        out.append((sc, vec, sc.begin(vec)))
+    return out
 
 
 def scatter_reverse(comm, owners_data, ghosts_data, N, float_type, kernels=None):
+    """cuda/scatterer.py:104-188 / numba-cpu/scatterer.py:78-141.  ``comm``: see ``as_comm`` (an ``MPI.Comm`` is accepted)."""
+    comm = as_comm(comm)
     if isinstance(comm, NativeComm):
         return _NativeScatter(comm, owners_data, ghosts_data, N, float_type, True)
     return _Scatter(comm, owners_data, ghosts_data, N, float_type, True, kernels)
 
 
 def scatter_forward(comm, owners_data, ghosts_data, N, float_type, kernels=None):
+    """cuda/scatterer.py:191-277 / numba-cpu/scatterer.py:144-207.  ``comm``: see ``as_comm`` (an ``MPI.Comm`` is accepted)."""
+    comm = as_comm(comm)
     if isinstance(comm, NativeComm):
         return _NativeScatter(comm, owners_data, ghosts_data, N, float_type, False)
     return _Scatter(comm, owners_data, ghosts_data, N, float_type, False, kernels)
@@ -613,6 +698,7 @@ class HaloApply:
         # the sub-launches of one apply run next to each other and next to the reverse exchange's receive kernel, all adding
         # into the same y: an operator with an atomic-free default (mass_operator) hands over its atomic twin
         self.op = getattr(op, "atomic", op)
+        comm = as_comm(comm)
         self.comm = comm
         # plan = (owners_data, ghosts_data) already computed (e.g. by the reference-style
         # compute_scatterer_data of a driver); default: exchange the indices over ``comm`` now
@@ -668,6 +754,14 @@ class HaloApply:
         self._warm = set()  # interior cell ranges (by the pointers of their per-cell arrays) that have been applied once
         self._hs = None
 
+    @staticmethod
+    def concurrent_safe(op):
+        """The operator to use for anything that adds into the apply's output vector WHILE the apply runs -- the cell
+        operator's sub-launches (done by ``HaloApply`` itself) and whatever a caller's ``boundary_terms`` launches: an operator
+        with an atomic-free default (``mass_operator``: plain load + store per dof) hands over its float-atomic twin, every
+        other operator is returned as it is."""
+        return getattr(op, "atomic", op)
+
     def neighbour_ranks(self):
         """Neighbour ranks of this rank (either direction)."""
         od, gd = self.owners_data, self.ghosts_data
@@ -717,7 +811,8 @@ class HaloApply:
         contiguous sub-range of cells, given views of the per-cell tensors ``percell`` (constants,
         G, detJ, dofmap, ...).  ``forward`` / ``reverse``: lists of ``(scatter closure, vector)``.
         ``boundary_terms()`` adds boundary-facet contributions; it runs after every forward scatter
-        has landed and before the reverse scatters are posted (facet dofs can be ghosts)."""
+        has landed and before the reverse scatters are posted (facet dofs can be ghosts).  In the concurrent schedule it
+        runs NEXT TO the interior launch: whatever it launches must add with atomics (``concurrent_safe(op)``)."""
         for _ in self.schedule(cell_fn, percell, forward, reverse, boundary_terms):
             pass
 
@@ -786,9 +881,7 @@ class HaloApply:
                 part("boundary")
                 if boundary_terms is not None:
                     boundary_terms()
-                if fold and len(reverse) > 0:
-                    self.comm.arm_join()
-                rv = begin_all(reverse)
+                rv = begin_all(reverse, arm_join=self.comm if (fold and len(reverse) > 0) else None)
             yield "reverse"
             with torch.cuda.stream(side):
                 for sc, vec, wk in rv:

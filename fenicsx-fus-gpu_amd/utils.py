@@ -81,19 +81,27 @@ def compute_scatterer_data_all(index_maps, stable=True):
 
 def compute_scatterer_data_flat(index_map, comm=None, stable=True):
     """One rank's halo plan, flat format; the index exchange uses ``comm``
-    (``.rank``, ``.size``, ``.alltoallv_int64(send, send_counts, recv_counts)``)."""
+    (``.rank``, ``.size``, ``.alltoallv_int64(send, send_counts, recv_counts)``: a package communicator, or an
+    ``mpi4py.MPI.Comm`` as the reference uses -- wrapped here)."""
     uo, osz, ooff, order = _owners_side(index_map, stable)
     ug, gsz = _ghosting_ranks(index_map)
     goff = np.concatenate(([0], np.cumsum(gsz))).astype(np.int64)
+    from . import mpi_bootstrap
+
     if comm is None:
-        # the reference hard-codes MPI.COMM_WORLD (cuda/utils.py:62,68); the counterpart here is the
-        # default torch.distributed group, if one is up
+        # the reference hard-codes MPI.COMM_WORLD (cuda/utils.py:62,68): the default torch.distributed group if one is up,
+        # else MPI.COMM_WORLD itself when mpi4py is importable (a driver started with mpirun)
         import torch.distributed as dist
 
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            from .scatterer import TorchComm
+        if dist.is_available() and dist.is_initialized():
+            if dist.get_world_size() > 1:
+                from .scatterer import TorchComm
 
-            comm = TorchComm()
+                comm = TorchComm()
+        else:
+            comm = mpi_bootstrap.world_if_available()
+    if comm is not None and mpi_bootstrap.is_mpi_comm(comm):  # a raw MPI communicator: only its collectives are needed here
+        comm = mpi_bootstrap.MpiBootstrap(comm)
     size = 1 if comm is None else comm.size
     if size == 1:
         if uo.size or ug.size:

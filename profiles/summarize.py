@@ -111,13 +111,27 @@ if "FETCH_SIZE" in counters and "WRITE_SIZE" in counters:
 for a_ in sys.argv[3:]:
     # --aux=rk4_step / --aux=rk4_step_in_kernel_geometry: HBM bytes of one fused RK4 step = sum over the step's kernels of
     # (mean per-launch bytes) x (launches per step: 4 of each), from the FETCH_SIZE / WRITE_SIZE passes of a --mode rk4 run
-    if a_.startswith("--aux=rk4_step"):
+    if a_ == "--aux=geom":  # what bench.py replays as aux.stiffness_in_kernel_geometry.roofline.traffic
+        sys.path.insert(0, ROOT)
+        import bench as bench_py
+
+        files = ("plan.hpp", "stiffness.hpp", "stiffness_plan.hpp", "stiffness_geom.hpp")
+        latest_path = os.path.join(out, "traffic_latest.json")
+        latest = json.load(open(latest_path))
+        latest.setdefault("aux", {})["stiffness_in_kernel_geometry"] = {
+            "P": bench["config"]["degree"], "ncell": bench["config"].get("cells_per_gpu"), "dtype": bench.get("dtype", "f64"),
+            "hbm_bytes_per_launch": res.get("hbm_bytes_per_launch"), "source": f"profiles/{_tag_for_files}_counters.json", "lib_sha": res["lib_sha"],
+            "kernel": "fus::stiffness_plan_geom_kernel", "kernel_src_files": list(files), "kernel_src_sha": bench_py.kernel_src_sha(files),
+            "atomic_requests_per_launch": counters.get("TCC_EA0_ATOMIC_sum", {}).get("mean_per_launch")}
+        json.dump(latest, open(latest_path, "w"), indent=1)
+    if a_.startswith("--aux=rk4_step") or a_.startswith("--aux=westervelt_step"):
         key = a_[6:]
         per = {}
         for sub, name in (("pmc_fetch", "fetch"), ("pmc_write", "write")):
             pth = os.path.join(src, sub, f"{name}_counter_collection.csv")
             for r in csv.DictReader(open(pth)):
-                for kn in ("stiffness_plan_geom_kernel", "stiffness_plan_kernel", "facet_terms_kernel", "rk4_stage_kernel"):
+                for kn in ("stiffness_plan_geom_kernel", "stiffness_plan_kernel", "westervelt_cell_geom_kernel", "westervelt_cell_kernel",
+                           "facet_terms_kernel", "rk4_stage_nl2_kernel", "rk4_stage_kernel"):
                     if kn + "<" in r["Kernel_Name"] or r["Kernel_Name"].split("(")[0].endswith(kn):
                         per.setdefault(kn, {}).setdefault(r["Counter_Name"], []).append(float(r["Counter_Value"]))
                         break
@@ -132,6 +146,8 @@ for a_ in sys.argv[3:]:
 
         geo = "geometry" in key
         files = ("plan.hpp", "stiffness.hpp", "stiffness_plan.hpp") + (("stiffness_geom.hpp",) if geo else ()) + ("mass.hpp", "rk4.hpp", "vecops.hpp")
+        if key.startswith("westervelt_step"):
+            files = files + ("westervelt.hpp",) + (("westervelt_geom.hpp",) if geo else ())
         latest_path = os.path.join(out, "traffic_latest.json")
         latest = json.load(open(latest_path))
         latest.setdefault("aux", {})[key] = {

@@ -218,6 +218,31 @@ def test_default_line_carries_the_aux_entries():
     assert aux["rk4_step"]["roofline"]["algorithmic_bytes_per_step"] > 0
     assert aux["stiffness_in_kernel_geometry"]["roofline"]["algorithmic_bytes_per_cell"] == 2100
     assert out["cpu_baseline"]["value"] > 0 and out["roofline"]["frac"] > 0
+    # a result check bound to the timed region, the aux scalars inside a key the driver keeps, the halo proxy
+    for ck in (out["check"], out["config"]["check"]):
+        assert ck["ok"] is True and ck["rel_l2"] <= 1e-12 and ck["rel_max"] <= 1e-11 and abs(ck["sum_y"] - ck["sum_y_oracle"]) <= 1e-9 * ck["norm_y_oracle"]
+    sec = out["roofline"]["secondary"]
+    assert len(json.dumps(sec)) <= 1024, len(json.dumps(sec))
+    for k in ("mass", "geom", "rk4", "rk4_geom", "westervelt", "westervelt_geom", "sustained", "halo_proxy", "check"):
+        assert k in sec, k
+    assert sec["check"]["ok"] is True and sec["mass"]["ms"] > 0 and 0 < sec["rk4"]["frac"] < 1
+    hp = aux["halo_proxy"]["transports"]
+    assert hp["peer"]["failed_waits"] == 0 and hp["peer"]["single_launch_us"] > 0 and "exposed_pct" in hp["peer"]
+    assert sec["halo_proxy"]["peer"]["pct"] == round(hp["peer"]["exposed_pct"], 1)
+    assert aux["westervelt_step_in_kernel_geometry"]["value"] > 0
+
+
+@pytest.mark.gpu
+def test_bench_result_check_fails_loudly(monkeypatch):
+    """A wrong result must not produce a valid line: with the oracle's constants perturbed (test hook) the check fails, the line
+    says ``valid: false`` and the exit code is non-zero."""
+    env = dict(_env(), FUS_BENCH_TEST_BREAK_CHECK="1")
+    r = subprocess.run([sys.executable, BENCH, "--steps", "3", "--warmup", "1", "--cells", "8", "--no-aux", "--no-cpu-baseline"], env=env,
+                       capture_output=True, text=True, timeout=600)
+    assert r.returncode != 0
+    out = _one_json_line(r.stdout)
+    assert out["valid"] is False and out["check"]["ok"] is False and out["check"]["rel_l2"] > 1e-6
+    assert "RESULT CHECK FAILED" in r.stderr
 
 
 @pytest.mark.gpu

@@ -129,3 +129,82 @@ def test_partitioned_westervelt_solver_on_one_gpu(tmp_path, oracle_c):
     assert np.max(np.abs(u_ref)) > 0
     for d in res:
         assert rel_l2(d["u_owned"], u_ref[d["lex_owned"]]) < 1e-11
+
+
+# ---- the reference's communicator: an MPI.Comm handed over as it is -------------------------------------
+@pytest.mark.parametrize("P,cells,grid,ghost_order", [(2, (4, 3, 2), (2, 1, 1), "owner"), (3, (4, 4, 2), (2, 2, 1), 5), (2, (4, 4, 4), (2, 2, 2), "lex")],
+                         ids=["2ranks", "4ranks-permuted", "8ranks"])
+def test_compute_scatterer_data_over_an_mpi_communicator(tmp_path, P, cells, grid, ghost_order):
+    """``compute_scatterer_data(index_map, comm)`` with what the reference uses -- an mpi4py-style communicator (cuda/utils.py:54-71
+    exchanges the indices over ``MPI.COMM_WORLD``) -- here tests/fake_mpi.py's file-backed stand-in, one thread per rank: the plan
+    of every rank equals the all-ranks-in-one-process builder's, element for element."""
+    import threading
+
+    from fake_mpi import FileComm
+
+    boxmesh, utils, boot = pkg("boxmesh"), pkg("utils"), pkg("mpi_bootstrap")
+    R = int(np.prod(grid))
+    meshes = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r, ghost_order=ghost_order) for r in range(R)]
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    got, errs = [None] * R, []
+
+    def rank_main(r):
+        try:
+            comm = FileComm(str(tmp_path), r, R, timeout=60)
+            assert boot.is_mpi_comm(comm)
+            got[r] = (utils.compute_scatterer_data(meshes[r].index_map, comm), comm.calls["alltoall"])
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(R)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs
+    for r in range(R):
+        (owners_data, ghosts_data), ncalls = got[r]
+        assert ncalls == 1 and len(owners_data) == 3 and len(ghosts_data) == 3  # the reference's 3-element lists
+        for mine, ref in ((utils.to_flat(owners_data), od[r]), (utils.to_flat(ghosts_data), gd[r])):
+            assert all(np.array_equal(np.asarray(a), np.asarray(b)) for a, b in zip(mine, ref))
+
+
+def test_mpi_bootstrap_collectives_and_rejected_communicators(tmp_path):
+    """``MpiBootstrap`` over 3 thread-ranks: votes, byte all-gather, broadcast, the index all-to-all-v; and ``as_comm`` /
+    ``scatter_*`` refuse what is neither a package communicator nor an MPI one with a TypeError naming the accepted kinds."""
+    import threading
+
+    from fake_mpi import FileComm
+
+    boot, scat = pkg("mpi_bootstrap"), pkg("scatterer")
+    R, out, errs = 3, [None] * 3, []
+
+    def rank_main(r):
+        try:
+            b = boot.MpiBootstrap(FileComm(str(tmp_path), r, R, timeout=60))
+            res = {"ok_all": b.all_ok(True), "ok_one_bad": b.all_ok(r != 1), "gather": b.allgather_bytes(bytes([r]) * (r + 1)),
+                   "bcast": b.bcast_bytes(b"id-of-rank-0" if r == 0 else b"", 0)}
+            b.barrier()
+            send = np.arange(100 * r, 100 * r + sum(range(1, R + 1)), dtype=np.int64)  # 1 to rank 0, 2 to rank 1, 3 to rank 2
+            res["a2a"] = b.alltoallv_int64(send, [1, 2, 3], [r + 1] * R)
+            out[r] = res
+        except Exception as e:  # noqa: BLE001
+            errs.append((r, repr(e)))
+
+    ts = [threading.Thread(target=rank_main, args=(r,)) for r in range(R)]
+    [t.start() for t in ts]
+    [t.join(120) for t in ts]
+    assert not errs, errs
+    off = [0, 1, 3]
+    for r in range(R):
+        assert out[r]["ok_all"] is True and out[r]["ok_one_bad"] is False and out[r]["bcast"] == b"id-of-rank-0"
+        assert out[r]["gather"] == [bytes([q]) * (q + 1) for q in range(R)]
+        assert np.array_equal(out[r]["a2a"], np.concatenate([np.arange(100 * q + off[r], 100 * q + off[r] + r + 1) for q in range(R)]))
+    assert not boot.is_mpi_comm(object()) and not boot.is_mpi_comm(None)
+    with pytest.raises(TypeError, match="MPI"):
+        boot.MpiBootstrap(object())
+    for bad in (object(), "MPI.COMM_WORLD", 3):
+        with pytest.raises(TypeError, match="NativeComm.*TorchComm.*MPI"):
+            scat.as_comm(bad)
+        with pytest.raises(TypeError, match="NativeComm.*TorchComm.*MPI"):
+            scat.scatter_forward(bad, [np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int32)],
+                                 [np.zeros(0, np.int64), np.zeros(0, np.int64), np.zeros(1, np.int64), np.zeros(0, np.int32)], 4, np.float64)
+    assert scat.as_comm(None) is None

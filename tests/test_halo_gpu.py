@@ -326,6 +326,59 @@ def test_peer_transport_real_processes_partitioned_apply(gpu, P, cells, grid, gh
     _run_peer_world(int(np.prod(grid)), "apply", [P, *cells, *grid, ghost_order, schedule])
 
 
+def _run_mpi_world(world, mode, args, tmp_path, timeout=300):
+    """``world`` real processes sharing cuda:0 whose ONLY communicator is an MPI-style one (tests/fake_mpi.py over ``tmp_path``):
+    no torch.distributed group anywhere (tests/_mpi_worker.py asserts it)."""
+    import os
+    import subprocess
+    import sys
+
+    root = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for k in ("RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "LOCAL_RANK"):
+        env.pop(k, None)
+    procs = [subprocess.Popen([sys.executable, os.path.join(root, "tests", "_mpi_worker.py"), mode, str(r), str(world), str(tmp_path)]
+                              + [str(a) for a in args], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True)
+             for r in range(world)]
+    outs = []
+    try:
+        for p in procs:
+            out, _ = p.communicate(timeout=timeout)
+            outs.append(out)
+    finally:
+        for p in procs:
+            if p.poll() is None:
+                p.kill()
+    bad = [r for r, (p, out) in enumerate(zip(procs, outs)) if p.returncode != 0 or f"MPI_WORKER_OK {r}" not in out]
+    assert not bad, "\n".join(f"---- process {r} (exit {procs[r].returncode}):\n{outs[r][-1500:]}" for r in bad)
+
+
+@pytest.mark.parametrize("dtype", ["float64", "float32"])
+@pytest.mark.parametrize("fixture", ["scatter_P2_4x2x2_grid2x1x1", "scatter_P2_4x4x2_grid2x2x1"])
+def test_mpi_communicator_real_processes_vs_reference_closures(gpu, tmp_path, fixture, dtype):
+    """the reference's own lines -- ``compute_scatterer_data(index_map)``, ``scatter_reverse / scatter_forward(comm,
+    owners_data, ghosts_data, N, float_type)`` with ``comm`` an MPI communicator (cuda/demo_linear_box.py:41, 192, 206-207) -- on 2 and 4
+    real processes sharing cuda:0, PEER transport bootstrapped over that communicator alone, against the reference closures'
+    outputs (tests/golden/scatter_*.npz)."""
+    import os
+
+    path = os.path.join(os.path.dirname(__file__), "golden", fixture + ".npz")
+    d = np.load(path)
+    _run_mpi_world(int(np.prod(d["grid"])), "golden", [path, dtype], tmp_path)
+
+
+@pytest.mark.parametrize("fused", [0, 1], ids=["reference-sequence", "fused"])
+def test_mpi_communicator_real_processes_rk4_solver(gpu, tmp_path, fused):
+    """``LinearSpectral3D(mesh, comm=<MPI communicator>)`` on two real processes == the reference-driven loop's fixture."""
+    import os
+
+    _run_mpi_world(2, "solver", [os.path.join(os.path.dirname(__file__), "golden", "rk4_P2_4x2x2_pert_2ranks.npz"), fused], tmp_path)
+
+
+def test_scatter_rejects_what_is_not_a_communicator(gpu, tmp_path):
+    _run_mpi_world(1, "badcomm", [], tmp_path)
+
+
 @pytest.mark.parametrize("transport", TRANSPORTS)
 @pytest.mark.parametrize("seed,permute", [(0, False), (1, True), (2, True)])
 def test_random_plans_uneven_multi_chunk_segments(gpu, seed, permute, transport):

@@ -353,6 +353,49 @@ def test_partitioned_linear_solver_async_transport_one_gpu(oracle_c, grid, ghost
     assert np.all(seen == 1)
 
 
+def test_partitioned_reference_sequence_large_facet_sets_use_atomic_facet_mass(oracle_c):
+    """in the reference launch sequence on a partitioned mesh the two facet mass applies are
+    ``boundary_terms`` of ``HaloApply`` -- in the concurrent schedule they run on the communicator's stream while the interior
+    stiffness launch adds into the same ``b`` with float atomics.  From 32 768 facet entries up ``mass_operator`` takes the
+    atomic-free gather kernel (plain load + store per dof), which would lose those adds; the solver must hand HaloApply the
+    float-atomic twin.  P = 4, 4 x 37 x 37 cells on 2 in-process ranks over the PEER transport: 1 369 facets = 34 225 entries
+    per face, interior cells of rank 0 on the x = 0 face, of rank 1 on the x = L face; against the serial oracle loop."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, scat, utils, ops = pkg("boxmesh"), pkg("linear_solver"), pkg("scatterer"), pkg("utils"), pkg("operators")
+    P, cells, grid, L = 4, (4, 37, 37), (2, 1, 1), (0.004, 0.037, 0.037)
+    R = 2
+    meshes = [boxmesh.BoxMesh(P, cells, grid=grid, rank=r, length=L) for r in range(R)]
+    serial = boxmesh.BoxMesh(P, cells, length=L)
+    h = ls.time_step_parameters(serial, P, 1500.0, 0.5e6, L[0])
+    dt, tf, _ = ls.snap_time_step(h, P, 1500.0, 0.5e6, L[0])
+    od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
+    wid = 7050
+    solvers = [ls.LinearSpectral3D(meshes[r], np.float64, comm=scat.NativeComm(local=(wid, R, r), transport="peer"), fused=False,
+                                   halo_plan=(od[r], gd[r]), defer_setup_exchange=True) for r in range(R)]
+    for s in solvers:
+        assert s.halo.schedule_kind == "concurrent"
+        assert s._mass_facet_stage is s.mass_facet.atomic  # what the stage launches next to the interior cells
+    # the premise: left to itself the facet operator of this size IS the gather kernel
+    big = solvers[0].fdm1  # rank 0 holds the source face x = 0
+    assert big.shape[0] * big.shape[1] >= ops._MASS_PLAN_MIN_ENTRIES
+    assert ops.mass_kernel_name(big, solvers[0].ndofs) == "fus::mass_gather_kernel"
+    assert ops.mass_kernel_name(big, solvers[0].ndofs, atomic=True) != "fus::mass_gather_kernel"
+    _lockstep([s._setup for s in solvers])
+    for s in solvers:
+        s.init()
+    res = _lockstep([s.rk4_schedule(0.0, tf, dt, max_steps=4) for s in solvers])
+    torch.cuda.synchronize()
+    assert all(r[1] == 4 for r in res)
+    u_ref, _ = rk4_oracle.solve(serial, 4, dt, oracle_c=oracle_c)
+    assert np.max(np.abs(u_ref)) > 0
+    for m, s in zip(meshes, solvers):
+        lex = m.global_lexicographic_ids()[: m.nlocal]
+        assert rel_l2(s.u_sol(), u_ref[lex]) < 1e-11
+        assert s.halo.health() == 0
+
+
 @pytest.mark.parametrize("geom", [False, True], ids=["general-G", "in-kernel-geometry"])
 def test_partitioned_westervelt_solver_async_transport_one_gpu(oracle_c, geom):
     """The fused Westervelt solver (BASELINE config 5 shape) on 2 in-process ranks over the asynchronous
