@@ -372,6 +372,36 @@ def make_comm(kind, scat, world, device):
     return None, err or "failed on another rank"
 
 
+AUX_STEADY_LAUNCHES, AUX_STEADY_WARM = 200, 100
+
+
+def timed_steady(fn, burst):
+    """(ms per launch in the steady state, ms per launch of the first burst): ``burst`` back-to-back launches after 3 untimed ones
+    (what the aux lines timed until round 4), then AUX_STEADY_WARM untimed + AUX_STEADY_LAUNCHES timed launches between one HIP-event pair.
+    A burst of 20 launches of a 0.15 ms kernel is over in 3 ms -- inside the ramp of the device's clocks after the idle gap before
+    it: the in-kernel-geometry kernel (VALU / LDS heavy) reads 0.16-0.185 ms in such a burst and 0.155 ms from the 50th launch on,
+    whatever ran before (profiles/r05d_geom_variance_probe.log); a time loop runs in the steady state."""
+    import torch
+
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    for _ in range(3):
+        fn()
+    e0.record()
+    for _ in range(burst):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    first = e0.elapsed_time(e1) / burst
+    for _ in range(AUX_STEADY_WARM):
+        fn()
+    e0.record()
+    for _ in range(AUX_STEADY_LAUNCHES):
+        fn()
+    e1.record()
+    torch.cuda.synchronize()
+    return e0.elapsed_time(e1) / AUX_STEADY_LAUNCHES, first
+
+
 def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, ops, pre, x_host, cc_host):
     """The cell mass apply y += M(c) x on the headline's mesh (numba-cpu/operators.py:19-68; shares the stiffness
     operator's batch plan): K back-to-back launches between one HIP-event pair, 3 044 B/cell at P = 4 / fp64."""
@@ -384,11 +414,11 @@ def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, o
         torch.from_numpy(dphi_g).to(device), torch.from_numpy(wts3).to(device))
     mop = ops.mass_operator(n**3, dt)
     kname = ops.mass_kernel_name(dm_d, mesh.ndofs)
-    K = max(1, args.steps)
+    K = AUX_STEADY_LAUNCHES  # steady state, like the other aux kernels (timed_steady)
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 
     def timed(fn):
-        for _ in range(3):
+        for _ in range(AUX_STEADY_WARM):
             fn(x_d, cc_d, y_d, detJ, dm_d)
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -401,6 +431,12 @@ def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, o
 
     # the float-atomic batch-plan kernel beside it (what the sub-launches of a partitioned apply use)
     _, atomic_ms = timed(mop.atomic)
+    # opt-in: detJ declared constant across applies -> streamed from a row-ordered copy instead of gathered through the entry ids
+    static_ms = None
+    try:
+        _, static_ms = timed(ops.mass_operator(n**3, dt, static_detJ=True))
+    except Exception as e:  # noqa: BLE001
+        log(f"aux mass, static-detJ form failed: {e!r}")
     wall_ms, ms = timed(mop)
     bpc = mass_bytes_per_cell(P, T)
     achieved = mesh.ncells * bpc / (ms * 1e-3) / 1e9
@@ -422,10 +458,14 @@ def aux_mass(args, P, T, dt, mesh, x_d, cc_d, y_d, dm_d, dphi_g, wts3, device, o
     out = {"metric": "mass_apply_dof_per_s", "value": mesh.ndofs_global / (wall_ms * 1e-3), "unit": "DOF/s", "ms_per_step": wall_ms, "steps": K,
            "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "traffic": traffic, "traffic_source": traffic_source, "kernel": kname, "kernel_ms": ms,
-                        "kernel_ms_how": "one HIP-event pair around K back-to-back launches / K",
+                        "kernel_ms_how": f"one HIP-event pair around {AUX_STEADY_LAUNCHES} back-to-back launches after {AUX_STEADY_WARM} untimed ones",
                         "algorithmic_bytes_per_cell": bpc, "cells_per_launch": mesh.ncells,
                         "atomic_kernel": "fus::mass_plan_kernel", "atomic_kernel_ms": atomic_ms,
-                        "atomic_kernel_frac": mesh.ncells * bpc / (atomic_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
+                        "atomic_kernel_frac": mesh.ncells * bpc / (atomic_ms * 1e-3) / 1e9 / HBM_PEAK_GBS,
+                        # mass_operator(N, T, static_detJ=True): same operator, same sums, priced on the SAME algorithmic bytes although
+                        # it reads fewer (2 index bytes per entry instead of 4): opt-in, the caller promises a constant detJ
+                        "static_detJ_kernel_ms": static_ms,
+                        "static_detJ_frac": None if not static_ms else mesh.ncells * bpc / (static_ms * 1e-3) / 1e9 / HBM_PEAK_GBS},
            "cpu_baseline": None}
     if x_host is not None:
         out["cpu_baseline"] = cpu_baseline_mass(P, mesh, x_host.astype(np.float64), cc_host.astype(np.float64), detJ.cpu().numpy().astype(np.float64))
@@ -473,6 +513,139 @@ def cpu_baseline_rk4(P, mesh, solver, dts, steps=2):
             "single_thread_value": mesh.ndofs / res["serial"], "s_per_step": res["omp"], "single_thread_s_per_step": res["serial"],
             "impl": "oracle/rk4_oracle.py over oracle/fus_oracle.c (stiffness, facet mass) + numpy vector updates; the reference prints this as "
                     "'Solve time per step' (numba-cpu/demo_linear_box.py:472-473)"}
+
+
+def first_contact_report(rank, world, device):
+    """N > 1, before anything is exchanged: what the transports will find, one block on rank 0's stderr and the same facts in the
+    line (``config.first_contact``) -- the devices by PCI bus id (ordinals are process-local), which of the devices visible to a
+    rank it can reach peer-to-peer, the IPC mode of the environment.  The first run on a real 8-GPU node must explain itself."""
+    import torch
+    import torch.distributed as dist
+
+    def pci(d):
+        p = torch.cuda.get_device_properties(d)
+        try:
+            return f"{p.pci_domain_id:04x}:{p.pci_bus_id:02x}:{p.pci_device_id:02x}.0"
+        except AttributeError:
+            return f"ordinal-{d}"
+
+    me = {"rank": rank, "pid": os.getpid(), "device_ordinal": device.index, "pci_bus_id": pci(device.index),
+          "name": torch.cuda.get_device_properties(device.index).name, "visible_devices": torch.cuda.device_count(), "peer_access": {}}
+    for d in range(torch.cuda.device_count()):
+        if d != device.index:
+            try:
+                me["peer_access"][pci(d)] = bool(torch.cuda.can_device_access_peer(device.index, d))
+            except Exception as e:  # noqa: BLE001
+                me["peer_access"][pci(d)] = f"error: {e!r}"
+    every = [None] * world
+    dist.all_gather_object(every, me)
+    report = {"ranks": every, "HSA_ENABLE_IPC_MODE_LEGACY": os.environ.get("HSA_ENABLE_IPC_MODE_LEGACY"), "FUS_IPC_MEMORY": os.environ.get("FUS_IPC_MEMORY"),
+              "rehearsal": rehearsal()}
+    if rank == 0:
+        log("first contact: " + ", ".join(f"rank {r['rank']} -> {r['pci_bus_id']} ({r['name']}, ordinal {r['device_ordinal']} of {r['visible_devices']})" for r in every))
+        shared = len({r["pci_bus_id"] for r in every}) < world
+        if shared:
+            log("first contact: several ranks share one device (rehearsal): peer access is not the question here")
+        for r in every:
+            no = [k for k, v in r["peer_access"].items() if v is not True]
+            log(f"first contact: rank {r['rank']} peer access to the other visible devices: " + ("all" if not no else f"NOT to {no}") + f" ({len(r['peer_access'])} checked)")
+        log(f"first contact: HSA_ENABLE_IPC_MODE_LEGACY={report['HSA_ENABLE_IPC_MODE_LEGACY']!r} (must be '0': dmabuf IPC), FUS_IPC_MEMORY={report['FUS_IPC_MEMORY']!r}")
+    return report
+
+
+def compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, chosen_kind, chosen_halo, kern_ms, rounds=5):
+    """``--halo-compare``: the apply over every transport that comes up (the chosen one + the other of peer / native), timed in
+    ALTERNATING rounds of K steps in this one process (barrier + synchronise on both sides, max over ranks), each one's exposed cost
+    against ONE launch over all local cells; the result of one apply through each extra transport is compared with the chosen
+    transport's.  One ``bench.py --gpus 8 --halo-compare`` run answers "PEER or RCCL, and by how much" (VERDICT r4 item 7)."""
+    import torch
+    import torch.distributed as dist
+
+    ops_mod = __import__("fusgpu_loader").submodule("operators")
+    halos, comms, notes = {chosen_kind: chosen_halo}, {}, {}
+    for kind in ("peer", "native"):
+        if kind in halos:
+            continue
+        comm, why = make_comm(kind, scat, world, device)
+        if comm is None:
+            notes[kind] = f"did not come up: {why}"
+            continue
+        err, h = None, None
+        try:
+            h = scat.HaloApply(mesh, op, comm, dt, overlap=os.environ.get("FUS_HALO_OVERLAP", "1") != "0")
+            h.prepare(x_d, cc_d, G_d, dm_d)
+            h.apply(x_d, cc_d, y_d, G_d, dm_d)
+            torch.cuda.synchronize()
+        except Exception as e:  # noqa: BLE001
+            err = repr(e)
+        every = gather_verdicts(rank, world, {"error": err})
+        if any(v["error"] for v in every):
+            notes[kind] = f"bring-up failed on rank(s) {[v['rank'] for v in every if v['error']]}: {[v['error'] for v in every if v['error']][:2]}"
+            try:
+                dist.barrier()
+                if h is not None:
+                    h.fwd.close(), h.rev.close()
+                comm.close()
+            except Exception:  # noqa: BLE001
+                pass
+            continue
+        halos[kind], comms[kind] = h, comm
+    # one apply through each transport into a zeroed y: the extra transports against the chosen one
+    ref, diffs = None, {}
+    for kind, h in halos.items():
+        ops_mod.fill(0.0, y_d)
+        h.apply(x_d, cc_d, y_d, G_d, dm_d)
+        torch.cuda.synchronize()
+        owned = y_d[: mesh.nlocal].clone()
+        if ref is None:
+            ref = owned
+        else:
+            t = torch.stack([(owned - ref).abs().max() if owned.numel() else owned.new_zeros(()), ref.abs().max() if ref.numel() else ref.new_zeros(())]).double().to(coll_device(device))
+            dist.all_reduce(t, op=dist.ReduceOp.MAX)
+            diffs[kind] = float(t[0].item()) / max(float(t[1].item()), 1e-300)
+    times = {k: [] for k in halos}
+    for _ in range(rounds):
+        for kind, h in halos.items():
+            h.apply(x_d, cc_d, y_d, G_d, dm_d)
+            dist.barrier()
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(args.steps):
+                h.apply(x_d, cc_d, y_d, G_d, dm_d)
+            torch.cuda.synchronize()
+            dist.barrier()
+            el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=coll_device(device))
+            dist.all_reduce(el, op=dist.ReduceOp.MAX)
+            times[kind].append(float(el.item()) / args.steps * 1e3)
+    out = {"rounds": rounds, "steps_per_round": args.steps, "one_launch_ms": kern_ms, "chosen": chosen_kind, "transports": {}, "not_compared": notes or None}
+    for kind, h in halos.items():
+        med = float(np.median(times[kind]))
+        late = torch.tensor([float(h.health())], dtype=torch.float64, device=coll_device(device))
+        dist.all_reduce(late)
+        out["transports"][kind] = {"transport": TRANSPORT_TEXT[kind], "schedule": h.schedule_kind, "ms_per_step_median": med,
+                                   "ms_per_step_rounds": times[kind], "exposed_ms": med - kern_ms, "exposed_frac": (med - kern_ms) / kern_ms,
+                                   "failed_waits_all_ranks": int(late.item()), "max_rel_diff_vs_chosen": diffs.get(kind)}
+    if rank == 0:
+        log("halo compare: " + "; ".join(f"{k}: {v['ms_per_step_median']:.4f} ms/step = one launch {v['exposed_ms'] * 1e3:+.1f} us ({100 * v['exposed_frac']:+.1f} %)"
+                                         for k, v in out["transports"].items()) + (f"; not compared: {notes}" if notes else ""))
+    try:
+        torch.cuda.synchronize()
+        dist.barrier()
+        for kind, comm in comms.items():
+            halos[kind].fwd.close(), halos[kind].rev.close()
+            comm.close()
+    except Exception as e:  # noqa: BLE001
+        log(f"rank {rank}: halo compare teardown: {e!r}")
+    return out
+
+
+def gather_verdicts(rank, world, mine):
+    """Every rank's view of one bring-up / check step, so that the line and the log name the rank that failed."""
+    import torch.distributed as dist
+
+    every = [None] * world
+    dist.all_gather_object(every, dict(mine, rank=rank))
+    return every
 
 
 def aux_traffic(key, P, ncell, dtype):
@@ -892,13 +1065,16 @@ def secondary_summary(out):
                     "tr": r3(tr / alg) if (tr and alg) else None}
 
     line("mass", "mass")
+    mrf = (aux.get("mass") or {}).get("roofline") or {}
+    if mrf.get("static_detJ_kernel_ms"):
+        sec["mass_static"] = {"ms": round(float(mrf["static_detJ_kernel_ms"]), 4), "frac": r3(mrf.get("static_detJ_frac"))}
     line("mass_diag", "mass_cached_diagonal")
     line("geom", "stiffness_in_kernel_geometry")
     line("rk4", "rk4_step")
     line("rk4_geom", "rk4_step_in_kernel_geometry")
     line("westervelt", "westervelt_step")
     line("westervelt_geom", "westervelt_step_in_kernel_geometry")
-    line("westervelt_het", "westervelt_step_heterogeneous")
+    line("westervelt_2g", "westervelt_step_two_gather")
     su = aux.get("sustained")
     if su:
         sec["sustained"] = {"ms": round(float(su["ms_per_apply"]), 4), "frac": r3(su["frac_of_hbm_roofline"])}
@@ -964,7 +1140,7 @@ def rk4_step_bytes(P, T, ncells, ndofs, nfacets_source, nfacets_absorbing, mode,
             "bytes_per_step": 4 * (ncells * cell + facets) + touches * T * ndofs}
 
 
-def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, steps, warmup, comm=None, cpu_leg=False):
+def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, steps, warmup, comm=None, cpu_leg=False, two_gather=False):
     """Full RK4 steps of the linear (BASELINE config 3: demo_linear_box, P = 4, ~10 M dofs per GPU) or Westervelt
     (config 5 shape) solver, fused stage kernels; returns the bench line as a dict."""
     import torch
@@ -999,8 +1175,10 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
             return out
 
         mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, length=tuple(L * g for g in grid), dtype=dt_np, warp=bowl)
+        # two_gather: the cell pass a heterogeneous medium takes (c4 / c3 not uniform: u_n and v_n are gathered separately);
+        # forced here on the homogeneous test medium, the kernel does the same work either way
         solver = nls.WesterveltSpectral3D(mesh, dt_np, speed_of_sound=1500.0, source_frequency=0.5e6, comm=comm, fused=True,
-                                          in_kernel_geometry=in_kernel_geometry)
+                                          in_kernel_geometry=in_kernel_geometry, uniform_ratio=False if two_gather else "auto")
         solver.affine = False
         single_gather = solver.kappa is not None
     else:
@@ -1146,9 +1324,12 @@ def main():
                          "libfusgpu.so (default); native = grouped ncclSend/ncclRecv issued by libfusgpu.so; torch = "
                          "torch.distributed all_to_all_single.  A transport that does not come up on every rank or "
                          "fails the run's halo check is replaced by the next one (peer -> native -> torch)")
+    ap.add_argument("--halo-compare", action="store_true",
+                    help="N > 1: after the timed region, time the apply over EVERY transport that comes up (peer, native = RCCL) in alternating "
+                         "rounds in this one process and put each one's exposed cost in config.halo_compare")
     ap.add_argument("--mass-atomic", action="store_true",
-                    help="--mode mass: the float-atomic batch-plan kernel instead of the atomic-free transposed-dofmap kernel (what a "
-                         "partitioned apply uses anyway: its sub-launches and the reverse exchange add into one y concurrently)")
+                    help="--mode mass: the float-atomic batch-plan kernel instead of the atomic-free transposed-dofmap kernel (a partitioned "
+                         "apply keeps the atomic-free kernel too: HaloApply splits it by dof, not by cell)")
     ap.add_argument("--exclusive", action="store_true",
                     help="--mode mass: the batch plan carries exclusive-dof marks (plain load + store instead of an atomic for dofs "
                          "one batch touches alone; opt-in, measured slower from P = 4 up: profiles/r04d_ab_mass_exclusive_marks.log)")
@@ -1291,7 +1472,7 @@ def main():
     else:
         op = ops.stiffness_operator(P, D.flatten(), dt)
 
-    halo, transport, halo_check, tried = None, None, None, []
+    halo, transport, halo_check, tried, first_contact, halo_compare = None, None, None, [], None, None
 
     def step():
         if halo is None:
@@ -1333,6 +1514,7 @@ def main():
     else:
         scat = fusgpu_loader.submodule("scatterer")
         os.environ.setdefault("FUS_IPC_SPIN_SECONDS", "10")  # a transport that does not deliver fails its check in seconds
+        first_contact = first_contact_report(rank, world, device)
         for kind in transport_candidates(args):
             comm, why = make_comm(kind, scat, world, device)
             if comm is None:
@@ -1349,18 +1531,32 @@ def main():
             except Exception as e:  # noqa: BLE001
                 err = repr(e)
                 log(f"rank {rank}: halo transport {kind!r} failed during bring-up: {err}")
-            flag = torch.tensor([1.0 if err is None else 0.0], dtype=torch.float64, device=coll_device(device))
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            if float(flag.item()) == 1.0:
+            arena = None
+            try:
+                arena = halo.fwd.status().get("arena_memory") if (err is None and kind == "peer" and hasattr(halo.fwd, "status")) else None
+            except Exception:  # noqa: BLE001
+                pass
+            bring_up = gather_verdicts(rank, world, {"error": err, "arena_memory": arena})
+            failed_ranks = [v["rank"] for v in bring_up if v["error"] is not None]
+            entry = {"transport": kind, "bring_up_failed_on_ranks": failed_ranks,
+                     "arena_memory_by_rank": [v["arena_memory"] for v in bring_up] if kind == "peer" else None}
+            if not failed_ranks:
                 verdict = check_halo()
+                per_rank = gather_verdicts(rank, world, {"forward_max_abs_err": verdict["forward_max_abs_err"], "device_wait_timeouts": int(halo.health())})
+                entry["check_failed_on_ranks"] = [v["rank"] for v in per_rank if v["forward_max_abs_err"] != 0.0 or v["device_wait_timeouts"] != 0]
                 if kind in os.environ.get("FUS_BENCH_TEST_REJECT", "").split(","):  # test hook: exercise the fall-back path
                     verdict = dict(verdict, ok=False, rejected_by="FUS_BENCH_TEST_REJECT")
+            else:
+                entry["bring_up_errors"] = {v["rank"]: v["error"] for v in bring_up if v["error"] is not None}
             if verdict is not None and verdict["ok"]:
                 transport, halo_check = kind, verdict
-                tried.append({"transport": kind, "result": "ok"})
+                tried.append(dict(entry, result="ok"))
+                if rank == 0:
+                    log(f"halo transport {kind!r}: came up on all {world} ranks, halo check passed ({verdict}); arena memory by rank: {entry['arena_memory_by_rank']}; CHOSEN")
                 break
-            tried.append({"transport": kind, "result": f"rejected: {verdict if verdict is not None else 'bring-up failed on some rank'}"})
-            log(f"halo transport {kind!r} rejected ({tried[-1]['result']}); trying the next one")
+            tried.append(dict(entry, result=f"rejected: {verdict if verdict is not None else 'bring-up failed on rank(s) ' + str(failed_ranks)}"))
+            if rank == 0:
+                log(f"halo transport {kind!r} rejected: {tried[-1]}; trying the next one")
             try:
                 torch.cuda.synchronize()
                 dist.barrier()  # nobody frees an arena a neighbour may still write into
@@ -1437,6 +1633,12 @@ def main():
             op.prepare(dm_d)
         kern_ms = timed_launches(lambda: op(x_d, cc_d, y_d, G_d, dm_d))
         sched_ms = timed_launches(lambda: halo.apply_no_exchange(x_d, cc_d, y_d, G_d, dm_d))
+        if args.halo_compare:
+            try:
+                halo_compare = compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, transport, halo, kern_ms)
+            except Exception as e:  # noqa: BLE001
+                log(f"rank {rank}: --halo-compare failed: {e!r}")
+                halo_compare = {"error": repr(e)}
     else:
         kern_ms = region_ms  # N = 1: the step IS the stiffness kernel launch
 
@@ -1479,7 +1681,8 @@ def main():
     elif mass_diag:
         kname = "fus::muladd_kernel"
     elif mass:
-        kname = ops.mass_kernel_name(dm_d, mesh.ndofs, atomic=args.mass_atomic or args.exclusive or halo is not None)
+        rows = halo is not None and halo.row_split(dm_d, mesh.ndofs) is not None  # partitioned: split by dof, atomic-free kernel
+        kname = ops.mass_kernel_name(dm_d, mesh.ndofs, atomic=args.mass_atomic or args.exclusive or (halo is not None and not rows))
     else:
         kname = "fus::stiffness_plan_kernel" if ops._USE_PLAN else "fus::stiffness_col_kernel"
 
@@ -1515,6 +1718,8 @@ def main():
             "halo_check": halo_check,
             "halo_transport": None if halo is None else TRANSPORT_TEXT[transport],
             "halo_transports_tried": tried or None,
+            "first_contact": first_contact,
+            "halo_compare": halo_compare,
             # the step against ONE launch over all local cells (the kernel of the N = 1 line) ...
             "halo_exposed_ms": None if halo is None else ms_per_step - kern_ms,
             "halo_exposed_frac": None if halo is None else (ms_per_step - kern_ms) / kern_ms,
@@ -1582,23 +1787,18 @@ def main():
         try:  # the same apply with G formed in the kernel -- own bytes contract, own line
             gop = ops.stiffness_operator(P, D.flatten(), dt, geometry=(mesh.x_dofs, mesh.x_g, pts, wts))
             gop.prepare(dm_d) if hasattr(gop, "prepare") else None
-            K = max(1, args.steps)
-            for _ in range(3):
-                gop(x_d, cc_d, y_d, None, dm_d)
-            g0, g1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-            g0.record()
-            for _ in range(K):
-                gop(x_d, cc_d, y_d, None, dm_d)
-            g1.record()
-            torch.cuda.synchronize()
-            gms = g0.elapsed_time(g1) / K
+            K = AUX_STEADY_LAUNCHES
+            gms, gms_burst = timed_steady(lambda: gop(x_d, cc_d, y_d, None, dm_d), max(1, args.steps))
             gb = geom_bytes_per_cell(P, T)
             gach = mesh.ncells * gb / (gms * 1e-3) / 1e9
             gtr, gtr_src = aux_traffic("stiffness_in_kernel_geometry", P, mesh.ncells, args.dtype)
             out["aux"]["stiffness_in_kernel_geometry"] = {
                 "metric": "stiffness_apply_in_kernel_geometry_dof_per_s", "value": mesh.ndofs_global / (gms * 1e-3), "unit": "DOF/s", "ms_per_step": gms, "steps": K,
                 "roofline": {"bound": "hbm", "achieved": gach, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": gach / HBM_PEAK_GBS, "traffic": gtr, "traffic_source": gtr_src,
-                             "kernel": "fus::stiffness_plan_geom_kernel", "kernel_ms": gms, "algorithmic_bytes_per_cell": gb, "cells_per_launch": mesh.ncells,
+                             "kernel": "fus::stiffness_plan_geom_kernel", "kernel_ms": gms,
+                             "kernel_ms_how": f"one HIP-event pair around {AUX_STEADY_LAUNCHES} back-to-back launches after {AUX_STEADY_WARM} untimed ones (steady state)",
+                             "kernel_ms_first_burst": gms_burst, "first_burst_launches": max(1, args.steps),
+                             "algorithmic_bytes_per_cell": gb, "cells_per_launch": mesh.ncells,
                              "bytes_contract": "no G array: dofmap + x once + y RMW + constant + 8 vertex ids + one vertex per cell (DESIGN 3.3); NOT the headline contract",
                              "bound_note": "float-atomic request rate of the flush, not HBM bytes (DESIGN 3.3 / 3.4)"},
                 "cpu_baseline": None}
@@ -1615,9 +1815,11 @@ def main():
                 out["aux"][name] = None
         try:  # BASELINE config 5's step on one GPU: Westervelt, P = 6, 36^3 bowl-warped cells (10.2 M dofs), fused stage
             wargs = argparse.Namespace(**{**vars(args), "degree": 6, "cells": max(4, round(args.cells * 2 / 3))})  # 54 -> 36: the same dof count
-            for name, geo_k in (("westervelt_step", False), ("westervelt_step_in_kernel_geometry", True)):  # the reference's G stream | the solver's default
+            # the reference's G stream | the solver's default | the default for a heterogeneous medium (two-gather cell pass)
+            for name, geo_k, two in (("westervelt_step", False, False), ("westervelt_step_in_kernel_geometry", True, False),
+                                     ("westervelt_step_two_gather", True, True)):
                 try:
-                    r = measure_rk4(wargs, rank, world, device, "westervelt", True, geo_k, max(1, min(args.steps, 20)), 2, cpu_leg=False)
+                    r = measure_rk4(wargs, rank, world, device, "westervelt", True, geo_k, max(1, min(args.steps, 20)), 2, cpu_leg=False, two_gather=two)
                     out["aux"][name] = {k: r[k] for k in keys}
                 except Exception as e:  # noqa: BLE001
                     log(f"aux {name} line failed: {e!r}")

@@ -38,6 +38,12 @@ def _signatures():
         "fus_plan_mark_exclusive": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_mass_gather_plan_bytes": [_int, _i64, _i64],
         "fus_mass_gather_plan_build": [_vp, _int, _i64, _i64, _vp, _i64, _vp],
+        "fus_mass_gather_plan_build_rows": [_vp, _int, _i64, _i64, _vp, _int, _vp, _i64, _vp],
+        "fus_mass_gather_static_bytes": [_int, _i64, _int],
+        "fus_mass_gather_static_build_f64": [_vp, _vp, _vp, _i64, _vp],
+        "fus_mass_gather_static_build_f32": [_vp, _vp, _vp, _i64, _vp],
+        "fus_mass_apply_gather_static_f64": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp],
+        "fus_mass_apply_gather_static_f32": [_vp, _vp, _vp, _vp, _vp, _int, _i64, _vp],
         "fus_mass_gather_plan_info": [_vp, _vp],
         "fus_stiffness_plan_build": [_vp, _int, _i64, _vp, _i64, _vp],
         # communicator + halo exchange (csrc/halo_comm.hpp)
@@ -140,7 +146,7 @@ def load():
         fn = getattr(lib, name)  # AttributeError if the library lacks a declared symbol
         fn.argtypes = argtypes
         fn.restype = {"fus_stiffness_plan_bytes": _i64, "fus_plan_bytes": _i64, "fus_comm_stream": _vp,
-                      "fus_mass_gather_plan_bytes": _i64,
+                      "fus_mass_gather_plan_bytes": _i64, "fus_mass_gather_static_bytes": _i64,
                       "fus_halo_ipc_blob_bytes": _i64, "fus_comm_last_error": C.c_char_p}.get(name, _int)
     lib.fus_error_string.argtypes = [_int]
     lib.fus_error_string.restype = C.c_char_p

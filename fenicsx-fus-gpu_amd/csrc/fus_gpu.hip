@@ -369,6 +369,51 @@ int mass_apply_gather(const T* x, const T* c, T* y, const T* detJ, const void* w
                                            g_mass_variant.load(std::memory_order_relaxed)));
 }
 
+// static companions of transposed-dofmap plans (detJ in row order), keyed by their own workspace address
+struct GatherStaticInfo {
+  const void* plan;
+  int elem_bytes;
+};
+std::unordered_map<const void*, GatherStaticInfo> g_gather_static;
+
+template <typename T>
+int mass_gather_static_build(const void* ws, const T* detJ, void* sws, int64_t sws_bytes, void* stream) {
+  fus::GatherHeader h{};
+  {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    auto it = g_gather_plans.find(ws);
+    if (it == g_gather_plans.end()) return FUS_ERR_PLAN_MISMATCH;
+    h = it->second;
+  }
+  if (!sws || misaligned(sws, 256) || (h.nent > 0 && !detJ)) return FUS_ERR_INVALID_ARGUMENT;
+  if (sws_bytes < fus::gather_static_bytes(h.nent, (int)h.N, h.nent * h.N, (int)sizeof(T))) return FUS_ERR_INVALID_ARGUMENT;
+  int too_wide = 0;
+  const hipError_t e = fus::gather_static_build<T>(ws, h, detJ, sws, static_cast<hipStream_t>(stream), &too_wide);
+  if (e != hipSuccess) return hip_rc(e);
+  if (too_wide) return FUS_ERR_UNSUPPORTED_ENTITY;
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  g_gather_static[sws] = GatherStaticInfo{ws, (int)sizeof(T)};
+  return FUS_OK;
+}
+
+template <typename T>
+int mass_apply_gather_static(const T* x, const T* c, T* y, const void* ws, const void* sws, int N, int64_t nent, void* stream) {
+  if (nent < 0 || N < 1) return FUS_ERR_INVALID_ARGUMENT;
+  fus::GatherHeader h{};
+  {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    auto it = g_gather_plans.find(ws);
+    if (it == g_gather_plans.end() || it->second.N != N || it->second.nent != nent) return FUS_ERR_PLAN_MISMATCH;
+    auto st = g_gather_static.find(sws);
+    if (st == g_gather_static.end() || st->second.plan != ws || st->second.elem_bytes != (int)sizeof(T)) return FUS_ERR_PLAN_MISMATCH;
+    h = it->second;
+  }
+  if (nent == 0) return FUS_OK;
+  if (!x || !c || !y) return FUS_ERR_INVALID_ARGUMENT;
+  return hip_rc(fus::launch_mass_gather_static<T>(x, c, y, ws, h, const_cast<void*>(sws), static_cast<hipStream_t>(stream),
+                                                  g_mass_variant.load(std::memory_order_relaxed)));
+}
+
 }  // namespace
 
 extern "C" {
@@ -493,6 +538,9 @@ int fus_plan_release(const void* workspace) {
   std::lock_guard<std::mutex> lk(g_plans_mu);
   g_plans.erase(workspace);
   g_gather_plans.erase(workspace);
+  g_gather_static.erase(workspace);
+  for (auto it = g_gather_static.begin(); it != g_gather_static.end();)  // companions of a released plan go with it
+    it = (it->second.plan == workspace) ? g_gather_static.erase(it) : std::next(it);
   return FUS_OK;
 }
 
@@ -519,6 +567,24 @@ int fus_mass_gather_plan_build(const int32_t* dofmap, int N, int64_t nent, int64
   return FUS_OK;
 }
 
+int fus_mass_gather_plan_build_rows(const int32_t* dofmap, int N, int64_t nent, int64_t ndofs, const uint8_t* row_set, int which,
+                                    void* workspace, int64_t workspace_bytes, void* stream) {
+  const int64_t need = fus_mass_gather_plan_bytes(N, nent, ndofs);
+  if (need < 0) return (int)need;
+  if (!workspace || misaligned(workspace, 256) || workspace_bytes < need || !row_set || which < 0 || which > 255)
+    return FUS_ERR_INVALID_ARGUMENT;
+  if (ndofs >= 0x7fffffffLL) return FUS_ERR_INVALID_ARGUMENT;  // the sentinel key of the dropped rows is ndofs itself
+  if (nent > 0 && !dofmap) return FUS_ERR_INVALID_ARGUMENT;
+  fus::GatherHeader h{};
+  int bad = 0;
+  const hipError_t e = fus::gather_plan_build(dofmap, N, nent, ndofs, workspace, static_cast<hipStream_t>(stream), &h, &bad, row_set, which);
+  if (e != hipSuccess) return hip_rc(e);
+  if (bad) return FUS_ERR_UNSUPPORTED_ENTITY;
+  std::lock_guard<std::mutex> lk(g_plans_mu);
+  g_gather_plans[workspace] = h;
+  return FUS_OK;
+}
+
 int fus_mass_gather_plan_info(const void* workspace, int64_t* out4) {
   if (!workspace || !out4) return FUS_ERR_INVALID_ARGUMENT;
   std::lock_guard<std::mutex> lk(g_plans_mu);
@@ -531,6 +597,26 @@ int fus_mass_gather_plan_info(const void* workspace, int64_t* out4) {
   return FUS_OK;
 }
 
+
+int64_t fus_mass_gather_static_bytes(int N, int64_t nent, int elem_bytes) {
+  if (N < 1 || nent < 0 || (elem_bytes != 4 && elem_bytes != 8)) return FUS_ERR_INVALID_ARGUMENT;
+  if (nent * (int64_t)N >= (int64_t)1 << 31) return FUS_ERR_INVALID_ARGUMENT;
+  return fus::gather_static_bytes(nent, N, nent * (int64_t)N, elem_bytes);
+}
+int fus_mass_gather_static_build_f64(const void* ws, const double* detJ, void* sws, int64_t sws_bytes, void* stream) {
+  return mass_gather_static_build<double>(ws, detJ, sws, sws_bytes, stream);
+}
+int fus_mass_gather_static_build_f32(const void* ws, const float* detJ, void* sws, int64_t sws_bytes, void* stream) {
+  return mass_gather_static_build<float>(ws, detJ, sws, sws_bytes, stream);
+}
+int fus_mass_apply_gather_static_f64(const double* x, const double* c, double* y, const void* ws, const void* sws, int N, int64_t nent,
+                                     void* stream) {
+  return mass_apply_gather_static<double>(x, c, y, ws, sws, N, nent, stream);
+}
+int fus_mass_apply_gather_static_f32(const float* x, const float* c, float* y, const void* ws, const void* sws, int N, int64_t nent,
+                                     void* stream) {
+  return mass_apply_gather_static<float>(x, c, y, ws, sws, N, nent, stream);
+}
 
 int fus_mass_apply_gather_f64(const double* x, const double* c, double* y, const double* detJ, const void* ws, int N,
                               int64_t nent, void* stream) {

@@ -65,10 +65,20 @@ inline void gather_layout(int64_t nent, int N, int64_t ndofs, GatherHeader* h) {
 // live on L1 re-use); the ids of a batch in one 8 / 16-byte load per row -- no change (0.1056; fp32 -3 %).  HBM traffic is 1.06 x the algorithmic bytes already (r04t_mass_gather_counters.json); an ablation
 // prices the parts: without the gather of the entity constant 0.097, without the entry indirection (detJ read in row
 // order, 79 MB fewer) 0.084, without both 0.076 -- the kernel pays for its vector-memory instructions, not for bytes.
-template <typename T, int NT, bool DENSE, int R>
+// STATIC (opt-in: the caller declared detJ constant across applies, fus_mass_gather_static_build): detJ is read from a copy
+// in ROW order -- detJ_sorted[beg + j], the same contiguous stream the entry ids were -- and the entity of an entry from a
+// 16-bit offset to its 256-row block's first entity: the entry indirection (one dependent gather per entry, what keeps the
+// texture addresser 82 % busy in the default kernel) is gone; the constants are still gathered, so they may change per apply.
+struct GatherStatic {
+  const void* detJ_sorted;   // T[nent * N], row order
+  const uint16_t* ent16;     // entity of entry k = ent_base[block of its row] + ent16[k]
+  const int32_t* ent_base;   // int32[nblocks]
+};
+
+template <typename T, int NT, bool DENSE, int R, bool STATIC = false>
 __global__ void __launch_bounds__(kGatherThreads)
     mass_gather_kernel(const T* __restrict__ x, const T* __restrict__ cc, T* __restrict__ y, const T* __restrict__ detJ,
-                       GatherView v, double inv_n, int chunk, int64_t nkb) {
+                       GatherView v, double inv_n, int chunk, int64_t nkb, GatherStatic gs) {
   // consecutive blocks of rows stay on one XCD (workgroups are dealt round-robin to the 8 XCDs): neighbouring rows gather
   // from the same detJ lines, which then hit in that XCD's L2 (natural block order: 0.1065 against 0.1004 ms)
   const int64_t b = (int64_t)(blockIdx.x & 7) * chunk + (blockIdx.x >> 3);
@@ -128,10 +138,30 @@ __global__ void __launch_bounds__(kGatherThreads)
   int maxlen = len[0];
 #pragma unroll
   for (int k = 1; k < R; ++k) maxlen = len[k] > maxlen ? len[k] : maxlen;
+  int32_t ebase[R];
+  if constexpr (STATIC) {
+#pragma unroll
+    for (int k = 0; k < R; ++k) ebase[k] = gs.ent_base[b * R + k];  // row r0 + k * 256 lies in 256-row block b * R + k
+  }
   auto batch = [&](auto bc, int j0) {
     constexpr int B = decltype(bc)::value;
     uint32_t e[R][B];
     T dv[R][B], cv[R][B];
+    if constexpr (STATIC) {
+      const T* ds = static_cast<const T*>(gs.detJ_sorted);
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+#pragma unroll
+        for (int q = 0; q < B; ++q) {
+          const bool on = j0 + q < len[k];
+          e[k][q] = on ? (uint32_t)gs.ent16[beg[k] + j0 + q] : 0u;
+          dv[k][q] = on ? ds[beg[k] + j0 + q] : T(0);
+        }
+#pragma unroll
+      for (int k = 0; k < R; ++k)
+#pragma unroll
+        for (int q = 0; q < B; ++q) cv[k][q] = j0 + q < len[k] ? cc[ebase[k] + (int32_t)e[k][q]] : T(0);
+    } else {
 #pragma unroll
     for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -144,6 +174,7 @@ __global__ void __launch_bounds__(kGatherThreads)
         dv[k][q] = on ? detJ[e[k][q]] : T(0);
         cv[k][q] = on ? cc[(int)(((double)e[k][q] + 0.5) * inv_n)] : T(0);  // e / N, exact for e < 2^31, N <= 2^11
       }
+    }
 #pragma unroll
     for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -194,11 +225,27 @@ __global__ void gather_len_kernel(const int32_t* start, const int32_t* rows, uin
   if (r == 0) base[nblocks] = (int32_t)total;
 }
 
-// Builds the plan in ``ws`` (>= gather_layout(...).bytes).  Scratch: four int32 arrays of nent * N entries and hipCUB's
+// keys of a ROW SUBSET: dofs whose mark is not ``want`` get the sentinel key ``ndofs`` (sorted behind every real dof and dropped);
+// invalid dofmap values stay invalid (negative, or beyond the sentinel) so that the range check of the builder still sees them
+__global__ void gather_subset_keys_kernel(const int32_t* dofmap, const uint8_t* row_set, int want, int64_t ndofs, int32_t* keys,
+                                          int64_t n) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int32_t d = dofmap[i];
+  int32_t k;
+  if (d < 0) k = d;
+  else if ((int64_t)d >= ndofs) k = 0x7fffffff;
+  else k = (row_set[d] == (uint8_t)want) ? d : (int32_t)ndofs;
+  keys[i] = k;
+}
+
+// Builds the plan in ``ws`` (>= gather_layout(...).bytes).  ``row_set`` != nullptr: a plan of the rows (dofs) d with
+// row_set[d] == want only -- the partitioned apply splits the touched dofs into the rows no exchange touches and the rest
+// (scatterer.HaloApply), every row still sums ALL its entries.  Scratch: four int32 arrays of nent * N entries and hipCUB's
 // temporaries, carved from ONE allocation made and released here (set-up path, once per dofmap: 25 ms at config 3).
 // *bad = 1: a dofmap value outside [0, ndofs) or a dof with more than 255 entries (nothing usable was built)
 inline hipError_t gather_plan_build(const int32_t* dofmap, int N, int64_t nent, int64_t ndofs, void* ws, hipStream_t stream,
-                                    GatherHeader* out, int* bad) {
+                                    GatherHeader* out, int* bad, const uint8_t* row_set = nullptr, int want = 0) {
   GatherHeader h{};
   *bad = 0;
   gather_layout(nent, N, ndofs, &h);
@@ -227,19 +274,23 @@ inline hipError_t gather_plan_build(const int32_t* dofmap, int N, int64_t nent, 
   const int64_t arr = gather_align(total * 4);
   const int64_t tmp_bytes = gather_align((int64_t)(sort_bytes > scan_bytes ? sort_bytes : scan_bytes));
   char* scratch = nullptr;
-  e = hipMalloc(&scratch, 4 * arr + tmp_bytes + 256);
+  const int narr = row_set ? 5 : 4;
+  e = hipMalloc(&scratch, narr * arr + tmp_bytes + 256);
   if (e != hipSuccess) return e;
   int32_t* iota = reinterpret_cast<int32_t*>(scratch);
   int32_t* keys = reinterpret_cast<int32_t*>(scratch + arr);
   int32_t* flag = reinterpret_cast<int32_t*>(scratch + 2 * arr);  // later: start[]
   int32_t* rowid = reinterpret_cast<int32_t*>(scratch + 3 * arr);
-  void* tmp = scratch + 4 * arr;
-  int32_t* stats = reinterpret_cast<int32_t*>(scratch + 4 * arr + tmp_bytes);
+  int32_t* keys_in = row_set ? reinterpret_cast<int32_t*>(scratch + 4 * arr) : nullptr;
+  void* tmp = scratch + narr * arr;
+  int32_t* stats = reinterpret_cast<int32_t*>(scratch + narr * arr + tmp_bytes);
   const int T = 256;
   const unsigned gb = (unsigned)((total + T - 1) / T);
   hipLaunchKernelGGL(gather_iota_kernel, dim3(gb), dim3(T), 0, stream, iota, total);
+  if (row_set) hipLaunchKernelGGL(gather_subset_keys_kernel, dim3(gb), dim3(T), 0, stream, dofmap, row_set, want, ndofs, keys_in, total);
   size_t sb = sort_bytes;
-  e = hipcub::DeviceRadixSort::SortPairs(tmp, sb, dofmap, keys, (const int32_t*)iota, entries, (int)total, 0, 32, stream);
+  e = hipcub::DeviceRadixSort::SortPairs(tmp, sb, row_set ? (const int32_t*)keys_in : dofmap, keys, (const int32_t*)iota, entries, (int)total, 0,
+                                         32, stream);
   if (e == hipSuccess) {
     hipLaunchKernelGGL(gather_flag_kernel, dim3(gb), dim3(T), 0, stream, keys, flag, total);
     size_t cb = scan_bytes;
@@ -250,17 +301,26 @@ inline hipError_t gather_plan_build(const int32_t* dofmap, int N, int64_t nent, 
   if (e == hipSuccess) e = hipMemcpyAsync(&kmin, keys, 4, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipMemcpyAsync(&kmax, keys + (total - 1), 4, hipMemcpyDeviceToHost, stream);
   if (e == hipSuccess) e = hipStreamSynchronize(stream);
-  if (e == hipSuccess && (kmin < 0 || (int64_t)kmax >= ndofs)) *bad = 1;
+  // a row subset: the largest legal key is the sentinel ``ndofs`` itself (the dofs of the other subset)
+  if (e == hipSuccess && (kmin < 0 || (int64_t)kmax >= ndofs + (row_set ? 1 : 0))) *bad = 1;
   int32_t st[2] = {0, 0};
   if (e == hipSuccess && !*bad) {
-    const int64_t nrows = nrows32;
-    const int64_t nblocks = (nrows + kGatherThreads - 1) / kGatherThreads;
+    int64_t nrows = nrows32;
+    int64_t used = total;  // entries of the kept rows
     int32_t* start = iota;  // iota is no longer needed
     hipLaunchKernelGGL(gather_rows_kernel, dim3(gb), dim3(T), 0, stream, keys, flag, rowid, rows, start, total);
-    e = hipMemsetAsync(stats, 0, 8, stream);
-    if (e == hipSuccess) {
+    if (row_set && (int64_t)kmax == ndofs) {  // the last row is the sentinel's: drop it
+      nrows -= 1;
+      int32_t s32 = 0;
+      e = hipMemcpyAsync(&s32, start + nrows, 4, hipMemcpyDeviceToHost, stream);
+      if (e == hipSuccess) e = hipStreamSynchronize(stream);
+      used = s32;
+    }
+    const int64_t nblocks = (nrows + kGatherThreads - 1) / kGatherThreads;
+    if (e == hipSuccess) e = hipMemsetAsync(stats, 0, 8, stream);
+    if (e == hipSuccess && nrows > 0) {
       hipLaunchKernelGGL(gather_len_kernel, dim3((unsigned)((nrows + T - 1) / T)), dim3(T), 0, stream, start, rows, len, base,
-                         nrows, total, nblocks, stats);
+                         nrows, used, nblocks, stats);
       e = hipMemcpyAsync(st, stats, 8, hipMemcpyDeviceToHost, stream);
     }
     if (e == hipSuccess) e = hipStreamSynchronize(stream);
@@ -278,6 +338,127 @@ inline hipError_t gather_plan_build(const int32_t* dofmap, int N, int64_t nent, 
   return e;
 }
 
+// ---- static companion of a plan (opt-in): detJ in row order + 16-bit entity offsets per 256-row block
+// pass 1: per 256-row block, the smallest entity among its entries (entries of a block are the contiguous range base[b] .. base[b + 1])
+__global__ void __launch_bounds__(256) gather_static_base_kernel(GatherView v, int N, int32_t* ent_base, int32_t* span_max) {
+  const int64_t b = blockIdx.x;
+  const int64_t k0 = v.base[b], k1 = v.base[b + 1];
+  int32_t lo = 0x7fffffff, hi = 0;
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+    const int32_t ent = v.entries[k] / N;
+    lo = ent < lo ? ent : lo;
+    hi = ent > hi ? ent : hi;
+  }
+  __shared__ int32_t slo[256], shi[256];
+  slo[threadIdx.x] = lo;
+  shi[threadIdx.x] = hi;
+  __syncthreads();
+  for (int o = 128; o > 0; o >>= 1) {
+    if ((int)threadIdx.x < o) {
+      slo[threadIdx.x] = slo[threadIdx.x + o] < slo[threadIdx.x] ? slo[threadIdx.x + o] : slo[threadIdx.x];
+      shi[threadIdx.x] = shi[threadIdx.x + o] > shi[threadIdx.x] ? shi[threadIdx.x + o] : shi[threadIdx.x];
+    }
+    __syncthreads();
+  }
+  if (threadIdx.x == 0) {
+    const int32_t base = k1 > k0 ? slo[0] : 0;
+    ent_base[b] = base;
+    if (k1 > k0) atomicMax(span_max, shi[0] - base);
+  }
+}
+// pass 2: detJ_sorted[k] = detJ[entries[k]], ent16[k] = entries[k] / N - ent_base[block of k]
+template <typename T>
+__global__ void __launch_bounds__(256) gather_static_fill_kernel(GatherView v, int N, const T* __restrict__ detJ, const int32_t* __restrict__ ent_base,
+                                                                 T* __restrict__ detJ_sorted, uint16_t* __restrict__ ent16) {
+  const int64_t b = blockIdx.x;
+  const int64_t k0 = v.base[b], k1 = v.base[b + 1];
+  const int32_t base = ent_base[b];
+  for (int64_t k = k0 + threadIdx.x; k < k1; k += 256) {
+    const int32_t e = v.entries[k];
+    detJ_sorted[k] = detJ[e];
+    ent16[k] = (uint16_t)(e / N - base);
+  }
+}
+
+// layout of the static companion: [detJ_sorted: total * sizeof(T)] [ent16: total * 2] [ent_base: nblocks * 4], each 256-aligned
+inline int64_t gather_static_bytes(int64_t nent, int N, int64_t ndofs, int elem_bytes) {
+  const int64_t total = nent * N;
+  const int64_t maxrows = total < ndofs ? total : ndofs;
+  const int64_t maxblocks = (maxrows + kGatherThreads - 1) / kGatherThreads;
+  return gather_align(total * elem_bytes) + gather_align(total * 2) + gather_align((maxblocks + 1) * 4) + 256;
+}
+inline GatherView gather_view_of(const void* ws, const GatherHeader& h) {
+  const char* w = static_cast<const char*>(ws);
+  return GatherView{h.nrows, h.nblocks, h.dense ? nullptr : reinterpret_cast<const int32_t*>(w + h.off_rows),
+                    reinterpret_cast<const uint8_t*>(w + h.off_len), reinterpret_cast<const int32_t*>(w + h.off_base),
+                    reinterpret_cast<const int32_t*>(w + h.off_entries)};
+}
+inline GatherStatic gather_static_of(void* sws, const GatherHeader& h, int elem_bytes) {
+  char* w = static_cast<char*>(sws);
+  const int64_t total = h.nent * h.N;
+  char* p_ent16 = w + gather_align(total * elem_bytes);
+  char* p_base = p_ent16 + gather_align(total * 2);
+  return GatherStatic{w, reinterpret_cast<const uint16_t*>(p_ent16), reinterpret_cast<const int32_t*>(p_base)};
+}
+// *too_wide = 1: some 256-row block spans more than 65 535 entities (a numbering without locality): no static companion
+template <typename T>
+inline hipError_t gather_static_build(const void* ws, const GatherHeader& h, const T* detJ, void* sws, hipStream_t stream, int* too_wide) {
+  *too_wide = 0;
+  if (h.nrows == 0) return hipSuccess;
+  const GatherView v = gather_view_of(ws, h);
+  GatherStatic gs = gather_static_of(sws, h, (int)sizeof(T));
+  int32_t* span = const_cast<int32_t*>(gs.ent_base) + h.nblocks;  // one spare word behind the bases
+  hipError_t e = hipMemsetAsync(span, 0, 4, stream);
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(gather_static_base_kernel, dim3((unsigned)h.nblocks), dim3(256), 0, stream, v, (int)h.N, const_cast<int32_t*>(gs.ent_base), span);
+  int32_t smax = 0;
+  e = hipMemcpyAsync(&smax, span, 4, hipMemcpyDeviceToHost, stream);
+  if (e == hipSuccess) e = hipStreamSynchronize(stream);
+  if (e != hipSuccess) return e;
+  if (smax > 65535) {
+    *too_wide = 1;
+    return hipSuccess;
+  }
+  hipLaunchKernelGGL((gather_static_fill_kernel<T>), dim3((unsigned)h.nblocks), dim3(256), 0, stream, v, (int)h.N, detJ, gs.ent_base,
+                     static_cast<T*>(const_cast<void*>(gs.detJ_sorted)), const_cast<uint16_t*>(gs.ent16));
+  return hipGetLastError();
+}
+
+template <typename T, int R>
+inline hipError_t launch_mass_gather_static_r(const T* x, const T* cc, T* y, const GatherView& v, const GatherHeader& h, const GatherStatic& gs,
+                                              hipStream_t stream) {
+  const int64_t nkb = (h.nrows + (int64_t)kGatherThreads * R - 1) / ((int64_t)kGatherThreads * R);
+  const int chunk = (int)((nkb + 7) / 8);
+  const dim3 grid((unsigned)(chunk * 8)), block(kGatherThreads);
+  const int nt = vector_stream(h.nrows * (int64_t)sizeof(T)) == 1 ? 1 : 0;
+#define FUS_GS(NT_, DENSE_) \
+  hipLaunchKernelGGL((mass_gather_kernel<T, NT_, DENSE_, R, true>), grid, block, 0, stream, x, cc, y, (const T*)nullptr, v, 0.0, chunk, nkb, gs)
+  if (h.dense) {
+    if (nt) FUS_GS(1, true);
+    else FUS_GS(0, true);
+  } else {
+    if (nt) FUS_GS(1, false);
+    else FUS_GS(0, false);
+  }
+#undef FUS_GS
+  return hipGetLastError();
+}
+template <typename T>
+inline hipError_t launch_mass_gather_static(const T* x, const T* cc, T* y, const void* ws, const GatherHeader& h, void* sws, hipStream_t stream,
+                                            int variant = 0) {
+  if (h.nrows == 0) return hipSuccess;
+  const GatherView v = gather_view_of(ws, h);
+  const GatherStatic gs = gather_static_of(sws, h, (int)sizeof(T));
+  int rows_per_thread = variant;
+  if (rows_per_thread != 1 && rows_per_thread != 2 && rows_per_thread != 4)
+    rows_per_thread = h.nrows < (1 << 19) ? 1 : ((sizeof(T) == 4 && h.nrows >= (1 << 22)) ? 4 : 2);
+  switch (rows_per_thread) {
+    case 1: return launch_mass_gather_static_r<T, 1>(x, cc, y, v, h, gs, stream);
+    case 4: return launch_mass_gather_static_r<T, 4>(x, cc, y, v, h, gs, stream);
+    default: return launch_mass_gather_static_r<T, 2>(x, cc, y, v, h, gs, stream);
+  }
+}
+
 template <typename T, int R>
 inline hipError_t launch_mass_gather_r(const T* x, const T* cc, T* y, const T* detJ, const GatherView& v, const GatherHeader& h,
                                        hipStream_t stream) {
@@ -288,14 +469,14 @@ inline hipError_t launch_mass_gather_r(const T* x, const T* cc, T* y, const T* d
   const int nt = vector_stream(h.nrows * (int64_t)sizeof(T)) == 1 ? 1 : 0;
   if (h.dense) {
     if (nt)
-      hipLaunchKernelGGL((mass_gather_kernel<T, 1, true, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+      hipLaunchKernelGGL((mass_gather_kernel<T, 1, true, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb, GatherStatic{nullptr, nullptr, nullptr});
     else
-      hipLaunchKernelGGL((mass_gather_kernel<T, 0, true, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+      hipLaunchKernelGGL((mass_gather_kernel<T, 0, true, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb, GatherStatic{nullptr, nullptr, nullptr});
   } else {
     if (nt)
-      hipLaunchKernelGGL((mass_gather_kernel<T, 1, false, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+      hipLaunchKernelGGL((mass_gather_kernel<T, 1, false, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb, GatherStatic{nullptr, nullptr, nullptr});
     else
-      hipLaunchKernelGGL((mass_gather_kernel<T, 0, false, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb);
+      hipLaunchKernelGGL((mass_gather_kernel<T, 0, false, R>), grid, block, 0, stream, x, cc, y, detJ, v, inv_n, chunk, nkb, GatherStatic{nullptr, nullptr, nullptr});
   }
   return hipGetLastError();
 }

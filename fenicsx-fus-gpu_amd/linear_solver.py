@@ -207,9 +207,9 @@ class LinearSpectral3D(StepGraphMixin):
 
         # ---- lumped mass: m = M(1/(rho c^2)) 1, reverse-scattered (:421-428) ---------------------
         ops.fill(1.0, self.g)
-        # one apply in the solver's life: the float-atomic twin (it shares the stiffness operator's batch plan) instead of
-        # sorting a transposed dofmap for it
-        self.mass_cell.atomic(self.g, self.cell_coeff1, self.m, self.detJ, self.dofmap)
+        # the default operator (atomic-free, bitwise reproducible): nothing else adds into m while it runs -- the reverse scatter
+        # of m follows it in stream order
+        self.mass_cell(self.g, self.cell_coeff1, self.m, self.detJ, self.dofmap)
         self.minv = z()
         # the reverse scatter of m: now, or (several ranks driven from one process: every rank must have
         # posted before any completes) by the driver through setup_schedule()

@@ -97,7 +97,9 @@ class WesterveltSpectral3D(StepGraphMixin):
         self.fdm2 = torch.from_numpy(mesh.facet_dofmap(bd2)).to(dev)
         self.nlocal, self.ndofs = mesh.nlocal, mesh.ndofs
         self.stiff = ops.stiffness_operator(P, D.flatten(), ft)
-        self.mass_cell = ops.mass_operator(n**3, ft)
+        # detJ never changes in the life of a solver: the reference-sequence stage applies the cell mass operator twice per stage
+        # with it (cuda/demo_nonlinear_bowl.py:612-616, 630-632) -- streamed from a row-ordered copy instead of gathered
+        self.mass_cell = ops.mass_operator(n**3, ft, static_detJ=not bool(fused))
         self.mass_facet = ops.mass_operator(n * n, ft)
         self.axpy = ops.axpy(self.ndofs)
         self.halo = None
@@ -115,9 +117,9 @@ class WesterveltSpectral3D(StepGraphMixin):
          self.g, self.dg, self.b, self.m, self.m0) = (z() for _ in range(16))
         # steady part of the lumped mass (:458-475)
         ops.fill(1.0, self.g)
-        # set-up applies (three in the solver's life): the float-atomic twin on the stiffness operator's batch plan; the
-        # reference-sequence stage (two cell mass applies per stage) uses the atomic-free default
-        self.mass_cell.atomic(self.g, self.cc1, self.m0, self.detJ, self.dofmap)
+        # set-up applies on the default operator (atomic-free, bitwise reproducible), like the reference-sequence stage's two
+        # cell mass applies: each runs alone on this stream, the reverse scatters follow in stream order
+        self.mass_cell(self.g, self.cc1, self.m0, self.detJ, self.dofmap)
         self.mass_facet(self.g, self.fc1_2, self.m0, self.dF2, self.fdm2)
 
         self.cell_fused = ops.westervelt_cell_operator(P, D.flatten(), ft)
@@ -126,8 +128,8 @@ class WesterveltSpectral3D(StepGraphMixin):
         # cuda/demo_nonlinear_bowl.py:612-616,630-632) are pointwise products with two diagonals assembled
         # once, like m0; the cell pass is then the stiffness part alone and m needs no reverse scatter
         self.w2, self.w5 = z(), z()
-        self.mass_cell.atomic(self.g, self.cc2, self.w2, self.detJ, self.dofmap)  # g == 1 here
-        self.mass_cell.atomic(self.g, self.cc5, self.w5, self.detJ, self.dofmap)
+        self.mass_cell(self.g, self.cc2, self.w2, self.detJ, self.dofmap)  # g == 1 here
+        self.mass_cell(self.g, self.cc5, self.w5, self.detJ, self.dofmap)
         # the reverse scatters of the three assembled diagonals (m0, w2, w5), as one grouped exchange: now, or
         # by a driver that runs several ranks from one process (setup_schedule, see LinearSpectral3D)
         # the third reverse closure of the set-up exchange is built HERE, with the others: building a closure is a collective

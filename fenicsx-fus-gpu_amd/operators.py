@@ -51,9 +51,12 @@ def use_plan(flag: bool):
 # consecutive cells adjacent (BoxMesh, a bandwidth-reordered dolfinx mesh) is left alone; a random cell
 # order goes from 0.365 back to 0.243 ms per apply at P = 4, 10 M dofs (profiles/r02c_numbering.log).
 _LOCALITY_ORDER = os.environ.get("FUS_PLAN_LOCALITY_ORDER", "1") != "0"
-# Two-row strip order for the plans of the scatter-bound kernels (plan_tiles.py; FUS_PLAN_STRIP_ORDER=0 / use_strip_order(False)
-# turns it off)
-_STRIP_ORDER = os.environ.get("FUS_PLAN_STRIP_ORDER", "1") != "0"
+# Two-row strip order for the plans of the scatter-bound kernels (plan_tiles.py).  OFF by default -- a measured negative
+# (profiles/r05d_geom_variance_probe.log, r05e_*): 2 x 5 pieces touch 8 % fewer distinct dofs than 10 cells in a row (94.8 against 102.9
+# per cell at P = 4) but flush them in MORE 64-byte atomic requests (45 runs of 21 dofs instead of 25 runs of 41), and the request
+# count is what bounds these kernels: 156 us against 153.5 us for the in-kernel-geometry kernel at config 3.
+# FUS_PLAN_STRIP_ORDER=1 / use_strip_order(True) turns it on (experiments).
+_STRIP_ORDER = os.environ.get("FUS_PLAN_STRIP_ORDER", "0") == "1"
 
 
 def use_strip_order(flag: bool):
@@ -185,6 +188,9 @@ class _PlanCache:
         gather = globals().get("_GATHER_PLANS")  # the transposed-dofmap plans of the mass apply go with them
         if gather is not None:
             gather.clear()
+        static = globals().get("_STATIC_DETJ")
+        if static is not None:
+            static.clear()
 
 
 _PLANS = _PlanCache()
@@ -212,10 +218,18 @@ class _GatherPlanCache:
         self._plans = {}
         self.capacity = capacity
 
-    def get(self, dofmap: torch.Tensor, ndofs: int):
+    def get(self, dofmap: torch.Tensor, ndofs: int, rows=None):
+        """``rows = (row_set, which)``: the plan of the dofs d with ``row_set[d] == which`` only (device uint8[ndofs]; the
+        partitioned apply's split into rows next to the exchanges and rows between them)."""
         lib = _lib.load()
         nent, N = dofmap.shape
         key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index, int(ndofs))
+        if rows is not None:
+            row_set, which = rows
+            _req(row_set, torch.uint8, "row_set")
+            if row_set.numel() != int(ndofs):
+                raise ValueError("row_set must have one mark per dof")
+            key = key + (row_set.data_ptr(), row_set._version, int(which))
         if key in self._plans:
             hit = self._plans[key]
         else:
@@ -225,12 +239,17 @@ class _GatherPlanCache:
             nbytes = lib.fus_mass_gather_plan_bytes(N, nent, int(ndofs))
             if nbytes > 0:
                 ws = torch.empty(int(nbytes), dtype=torch.uint8, device=dofmap.device)
-                rc = lib.fus_mass_gather_plan_build(dofmap.data_ptr(), N, nent, int(ndofs), ws.data_ptr(), int(nbytes), _lib.stream_ptr())
+                if rows is None:
+                    rc = lib.fus_mass_gather_plan_build(dofmap.data_ptr(), N, nent, int(ndofs), ws.data_ptr(), int(nbytes), _lib.stream_ptr())
+                else:
+                    rc = lib.fus_mass_gather_plan_build_rows(dofmap.data_ptr(), N, nent, int(ndofs), rows[0].data_ptr(), int(rows[1]),
+                                                             ws.data_ptr(), int(nbytes), _lib.stream_ptr())
                 if rc == 0:
                     info = (C.c_int64 * 4)()
                     _lib.check(lib.fus_mass_gather_plan_info(ws.data_ptr(), info), "fus_mass_gather_plan_info")
-                    if info[0] > 0 and nent * N <= _GATHER_MAX_MEAN_ENTRIES * info[0]:
-                        hit = (ws, dofmap, tuple(int(v) for v in info))
+                    # (a row subset is judged by the full plan: the caller asks for it only when the full plan was kept)
+                    if rows is not None or (info[0] > 0 and nent * N <= _GATHER_MAX_MEAN_ENTRIES * info[0]):
+                        hit = (ws, dofmap, tuple(int(v) for v in info)) + ((rows[0],) if rows is not None else ())
                     else:
                         lib.fus_plan_release(ws.data_ptr())
                 elif rc != _lib.ERR_UNSUPPORTED_ENTITY:
@@ -246,6 +265,9 @@ class _GatherPlanCache:
 
     def clear(self):
         lib = _lib.load()
+        static = globals().get("_STATIC_DETJ")  # row-ordered detJ copies belong to these plans
+        if static is not None:
+            static.clear()
         for hit in self._plans.values():
             if hit is not None:
                 lib.fus_plan_release(hit[0].data_ptr())
@@ -263,6 +285,44 @@ class _Launchable:
 
 
 # --------------------------------------------------------------------------- mass
+def _mass_gather_usable(nent, n_per):
+    return _USE_GATHER and nent * n_per >= _MASS_PLAN_MIN_ENTRIES and n_per <= 2048 and nent * n_per < 2**31
+
+
+def mass_rows_available(entity_dofmap, ndofs, row_set):
+    """True if ``mass_operator``'s apply can run as two row-subset launches of the atomic-free kernel for this dofmap (the
+    full transposed plan is one the operator would use, and both subsets build): what ``HaloApply`` asks before it splits a
+    mass apply by dof instead of by cell.  Builds and caches the three plans."""
+    nent, n_per = entity_dofmap.shape
+    if nent == 0 or not _mass_gather_usable(nent, n_per):
+        return False
+    if _GATHER_PLANS.get(entity_dofmap, int(ndofs)) is None:
+        return False
+    return all(_GATHER_PLANS.get(entity_dofmap, int(ndofs), (row_set, w)) is not None for w in (0, 1))
+
+
+def _mass_apply_rows(x, entity_constants, y, entity_detJ, entity_dofmap, row_set, which, N=None):
+    """The rows ``row_set[d] == which`` of ``y += M(c) x`` with the atomic-free kernel (every row sums all its entries)."""
+    lib = _lib.load()
+    dt = x.dtype if isinstance(x, torch.Tensor) else None
+    for name, t in (("x", x), ("entity_constants", entity_constants), ("y", y), ("entity_detJ", entity_detJ)):
+        _req(t, dt, name)
+    _req(entity_dofmap, torch.int32, "entity_dofmap")
+    if entity_dofmap.dim() != 2 or entity_detJ.shape != entity_dofmap.shape:
+        raise ValueError("entity_dofmap must be [num_entities, N] and entity_detJ must have the same shape")
+    nent, n_per = entity_dofmap.shape
+    if (N is not None and n_per != N) or entity_constants.numel() != nent:
+        raise ValueError("dofs per entity / number of constants do not match the dofmap")
+    if nent == 0:
+        return
+    hit = _GATHER_PLANS.get(entity_dofmap, min(x.numel(), y.numel()), (row_set, int(which)))
+    if hit is None:
+        raise _lib.FusGpuError("no row-subset plan for this dofmap (mass_rows_available() says when there is one)")
+    fn = getattr(lib, f"fus_mass_apply_gather_{_lib.suffix(dt)}")
+    _lib.check(fn(x.data_ptr(), entity_constants.data_ptr(), y.data_ptr(), entity_detJ.data_ptr(), hit[0].data_ptr(), int(n_per), int(nent),
+                  _lib.stream_ptr()), "fus_mass_apply_gather (row subset)")
+
+
 def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, exclusive=False, atomic=False):
     lib = _lib.load()
     dt = x.dtype if isinstance(x, torch.Tensor) else None
@@ -280,7 +340,7 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, excl
         raise ValueError("entity_constants must have one value per entity")
     if nent == 0:
         return
-    if _USE_GATHER and not atomic and nent * n_per >= _MASS_PLAN_MIN_ENTRIES and n_per <= 2048 and nent * n_per < 2**31:
+    if not atomic and _mass_gather_usable(nent, n_per):
         hit = _GATHER_PLANS.get(entity_dofmap, min(x.numel(), y.numel()))  # every dofmap value is checked against both vectors
         if hit is not None:
             fn = getattr(lib, f"fus_mass_apply_gather_{_lib.suffix(dt)}")
@@ -316,22 +376,108 @@ def mass_kernel_name(entity_dofmap, ndofs, atomic=False):
     return "fus::mass_plan_kernel" if (_USE_PLAN and 2 <= n_per <= 4096 and big) else "fus::mass_kernel"
 
 
+class _StaticDetJCache:
+    """Static companions of transposed-dofmap plans (``fus_mass_gather_static_*``): detJ in row order, keyed on the plan's
+    workspace and on the identity of the detJ array (pointer, shape, torch version counter).  An entry is ``None`` when the library
+    refused (a block of 256 dofs spanning more than 65 535 entities)."""
+
+    def __init__(self, capacity: int = 8):
+        self._entries = {}
+        self.capacity = capacity
+
+    def get(self, plan_ws, detJ, n_per, nent):
+        lib = _lib.load()
+        key = (plan_ws.data_ptr(), detJ.data_ptr(), tuple(detJ.shape), detJ._version, detJ.dtype)
+        if key not in self._entries:
+            hit = None
+            nbytes = lib.fus_mass_gather_static_bytes(int(n_per), int(nent), detJ.element_size())
+            if nbytes > 0:
+                sws = torch.empty(int(nbytes), dtype=torch.uint8, device=detJ.device)
+                fn = getattr(lib, f"fus_mass_gather_static_build_{_lib.suffix(detJ.dtype)}")
+                rc = fn(plan_ws.data_ptr(), detJ.data_ptr(), sws.data_ptr(), int(nbytes), _lib.stream_ptr())
+                if rc == 0:
+                    hit = (sws, plan_ws, detJ)  # holds the plan and detJ: their addresses cannot be re-used while this lives
+                elif rc != _lib.ERR_UNSUPPORTED_ENTITY:
+                    _lib.check(rc, "fus_mass_gather_static_build")
+            if len(self._entries) >= self.capacity:
+                old = self._entries.pop(next(iter(self._entries)))
+                if old is not None:
+                    lib.fus_plan_release(old[0].data_ptr())
+            self._entries[key] = hit
+        hit = self._entries[key]
+        if hit is not None and _PLANS._recording is not None:
+            _PLANS._recording.append((hit[0], hit[2]))
+        return hit
+
+    def clear(self):
+        lib = _lib.load()
+        for hit in self._entries.values():
+            if hit is not None:
+                lib.fus_plan_release(hit[0].data_ptr())
+        self._entries.clear()
+
+
+_STATIC_DETJ = _StaticDetJCache()
+
+
 class _MassApply:
     """``operator(x, entity_constants, y, entity_detJ, entity_dofmap)`` returned by ``mass_operator(N, float_type)``;
     ``.atomic``: the same operator on the float-atomic kernels (safe next to concurrent writers of ``y``)."""
 
-    def __init__(self, N, tdt, exclusive, atomic):
-        self.N, self.dtype, self._exclusive, self._atomic = N, tdt, exclusive, atomic
+    def __init__(self, N, tdt, exclusive, atomic, static_detJ=False):
+        self.N, self.dtype, self._exclusive, self._atomic, self._static = N, tdt, exclusive, atomic, bool(static_detJ) and not atomic
         self.atomic = self if atomic else _MassApply(N, tdt, exclusive, True)
 
     def __call__(self, x, entity_constants, y, entity_detJ, entity_dofmap):
         if isinstance(x, torch.Tensor) and x.dtype != self.dtype:
             raise TypeError(f"x: expected dtype {self.dtype}, got {x.dtype}")
+        if self._static and self._apply_static(x, entity_constants, y, entity_detJ, entity_dofmap):
+            return
         _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, self.N, exclusive=self._exclusive, atomic=self._atomic)
+
+    def _apply_static(self, x, entity_constants, y, entity_detJ, entity_dofmap):
+        """The apply with detJ streamed in row order (``static_detJ=True``); False when this dofmap has no transposed plan or no
+        static companion (the caller then takes the default path: same result)."""
+        dt = self.dtype
+        for name, t in (("x", x), ("entity_constants", entity_constants), ("y", y), ("entity_detJ", entity_detJ)):
+            _req(t, dt, name)
+        _req(entity_dofmap, torch.int32, "entity_dofmap")
+        if entity_dofmap.dim() != 2 or entity_detJ.shape != entity_dofmap.shape:
+            raise ValueError("entity_dofmap must be [num_entities, N] and entity_detJ must have the same shape")
+        nent, n_per = entity_dofmap.shape
+        if n_per != self.N or entity_constants.numel() != nent:
+            raise ValueError("dofs per entity / number of constants do not match the dofmap")
+        if nent == 0 or not _mass_gather_usable(nent, n_per):
+            return False
+        plan = _GATHER_PLANS.get(entity_dofmap, min(x.numel(), y.numel()))
+        if plan is None:
+            return False
+        st = _STATIC_DETJ.get(plan[0], entity_detJ, n_per, nent)
+        if st is None:
+            return False
+        fn = getattr(_lib.load(), f"fus_mass_apply_gather_static_{_lib.suffix(dt)}")
+        _lib.check(fn(x.data_ptr(), entity_constants.data_ptr(), y.data_ptr(), plan[0].data_ptr(), st[0].data_ptr(), int(n_per), int(nent),
+                      _lib.stream_ptr()), "fus_mass_apply_gather_static")
+        return True
+
+    def refresh(self):
+        """``static_detJ=True``: forget the row-ordered copies of detJ (after changing a detJ array IN PLACE through anything
+        but torch -- torch's own in-place operations are noticed by themselves)."""
+        _STATIC_DETJ.clear()
+
+    def apply_rows(self, x, entity_constants, y, entity_detJ, entity_dofmap, row_set, which):
+        """``y[d] += (M(c) x)[d]`` for the dofs with ``row_set[d] == which`` only (atomic-free kernel): the two halves of a
+        partitioned apply (``HaloApply``), which never add into one ``y[d]`` concurrently."""
+        if isinstance(x, torch.Tensor) and x.dtype != self.dtype:
+            raise TypeError(f"x: expected dtype {self.dtype}, got {x.dtype}")
+        _mass_apply_rows(x, entity_constants, y, entity_detJ, entity_dofmap, row_set, which, self.N)
+
+    def rows_available(self, entity_dofmap, ndofs, row_set):
+        return (not self._atomic) and mass_rows_available(entity_dofmap, ndofs, row_set)
 
 
 class _MassOperator(_Launchable):
-    def __call__(self, N: int, float_type, exclusive=False, atomic=False):
+    def __call__(self, N: int, float_type, exclusive=False, atomic=False, static_detJ=False):
         """``mass_operator(N, float_type)`` -> ``operator(x, entity_constants, y, entity_detJ, entity_dofmap)``
         (numba-cpu/operators.py:19-68).
 
@@ -345,8 +491,13 @@ class _MassOperator(_Launchable):
         sub-launches.  Dofmaps the gather does not pay for (P = 2: 3.4 entries per dof) or cannot hold (a dof in more than 255
         entities) take the atomic batch plan by themselves.
         ``exclusive=True`` (atomic batch plan with exclusive-dof marks, round 4's first attempt): kept for the atomic path,
-        measured slower than the unmarked plan."""
-        return _MassApply(int(N), _lib.torch_dtype(float_type), exclusive, atomic)
+        measured slower than the unmarked plan.
+        ``static_detJ=True`` (opt-in): the caller declares ``entity_detJ`` constant across applies -- it is what the reference's
+        drivers do (one detJ array for the whole run, cuda/demo_nonlinear_bowl.py:603-632) -- and the operator keeps a copy of it
+        in ROW order next to the transposed dofmap: the kernel streams detJ instead of gathering it through the entry ids
+        (bitwise the same result; ``op.refresh()`` after changing detJ in place behind torch's back).  The constants are read per
+        apply and may change."""
+        return _MassApply(int(N), _lib.torch_dtype(float_type), exclusive, atomic, static_detJ)
 
     @staticmethod
     def launch(x, entity_constants, y, detJ_entity, entity_dofmap):

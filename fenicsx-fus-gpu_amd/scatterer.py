@@ -698,6 +698,14 @@ class HaloApply:
         # the sub-launches of one apply run next to each other and next to the reverse exchange's receive kernel, all adding
         # into the same y: an operator with an atomic-free default (mass_operator) hands over its atomic twin
         self.op = getattr(op, "atomic", op)
+        # ... unless the operator can be applied ROW BY ROW (``mass_operator``: y[d] depends on x[d] alone): the apply is then
+        # split by dof instead of by cell -- set A: owned dofs the reverse exchange does not add into (one launch next to the
+        # exchanges, all their entries, whatever cells those are in); set B: ghost dofs (their x arrives with the forward
+        # exchange) and owned dofs that are ghosted elsewhere (the reverse receive adds into them), launched between the two
+        # exchanges on the communicator's stream.  No launch and no receive kernel ever adds into the same y[d] concurrently,
+        # so the atomic-free kernel stays valid at N > 1 (csrc/mass_gather.hpp).
+        self._op_rows = op if hasattr(op, "apply_rows") and hasattr(op, "rows_available") else None
+        self._row_sets = {}  # (dofmap pointer, vector length) -> uint8 marks or None (not available: cell split + atomics)
         comm = as_comm(comm)
         self.comm = comm
         # plan = (owners_data, ghosts_data) already computed (e.g. by the reference-style
@@ -762,6 +770,21 @@ class HaloApply:
         other operator is returned as it is."""
         return getattr(op, "atomic", op)
 
+    def row_split(self, dofmap, ndofs):
+        """The uint8 marks of the row split for ``dofmap`` on vectors of ``ndofs`` entries (0: set A, 1: set B), or ``None`` when
+        the operator is not row-wise or its atomic-free kernel is not available for this dofmap (decided once per dofmap)."""
+        if self._op_rows is None or self._apply_fn is not None or not isinstance(dofmap, torch.Tensor) or not dofmap.is_cuda:
+            return None
+        key = (dofmap.data_ptr(), int(ndofs), dofmap._version)
+        if key not in self._row_sets:
+            marks = torch.zeros(int(ndofs), dtype=torch.uint8, device=dofmap.device)
+            marks[self.mesh.nlocal:] = 1
+            ghosted = torch.from_numpy(np.ascontiguousarray(to_flat(self.ghosts_data)[0], dtype=np.int64)).to(dofmap.device)
+            if ghosted.numel():
+                marks[ghosted] = 1
+            self._row_sets[key] = marks if self._op_rows.rows_available(dofmap, int(ndofs), marks) else None
+        return self._row_sets[key]
+
     def neighbour_ranks(self):
         """Neighbour ranks of this rank (either direction)."""
         od, gd = self.owners_data, self.ghosts_data
@@ -816,13 +839,22 @@ class HaloApply:
         for _ in self.schedule(cell_fn, percell, forward, reverse, boundary_terms):
             pass
 
-    def schedule(self, cell_fn, percell, forward, reverse, boundary_terms=None):
-        """The stage of ``run`` as a generator that yields each time this rank has POSTED a set of
+    def schedule(self, cell_fn, percell, forward, reverse, boundary_terms=None, by_rows=False):
+        """``by_rows``: ``cell_fn(which)`` applies the operator to row set ``which`` (0: A, 1: B; see ``row_split``) over ALL cells;
+        ``percell`` is unused.
+
+        The stage of ``run`` as a generator that yields each time this rank has POSTED a set of
         exchanges (``"forward"`` / ``"reverse"``) and is about to do work that does not depend on
         them.  One rank per process never needs the yields (``run`` just exhausts them); a host
         that drives several ranks from one thread (``NativeComm(local=...)``) advances all ranks'
         generators in lock step, so every rank has posted before any rank completes."""
         def part(name):
+            if by_rows:  # set A where the schedule has its (first) interior launch, set B in place of the boundary cells
+                if name in ("interior", "interior1"):
+                    cell_fn(0)
+                elif name == "boundary":
+                    cell_fn(1)
+                return
             a, b = self.ranges[name]
             if b > a:
                 cell_fn(*self._views(name, percell))
@@ -841,7 +873,9 @@ class HaloApply:
             for sc, vec, wk in rv:
                 sc.end(vec, wk)
             return
-        if self.schedule_kind == "concurrent" and len(percell) > 0 and percell[0].is_cuda:
+        if by_rows and boundary_terms is not None:
+            raise ValueError("a row-split apply takes no boundary_terms (they would add into rows of set A next to its launch)")
+        if self.schedule_kind == "concurrent" and (by_rows or (len(percell) > 0 and percell[0].is_cuda)):
             # main stream: ONE launch over all interior cells.  Side stream (the communicator's own high-priority stream
             # where the library has one: send, receive and the boundary kernels then follow each other in stream order,
             # no event edge between them): forward exchange -> boundary cells -> reverse exchange.
@@ -860,8 +894,8 @@ class HaloApply:
             # forward exchange is posted after it; it still runs under the interior kernel), and only once this cell
             # range has been applied before -- its batch plan exists, no first-use set-up inside the launch call.
             a_, b_ = self.ranges["interior"]
-            warm_key = ("interior",) + tuple(t.data_ptr() for t in percell)
-            attach = (lib_sync and self._attach_sync and self._apply_fn is None and b_ > a_ and warm_key in self._warm
+            warm_key = ("interior",) + (() if by_rows else tuple(t.data_ptr() for t in percell))
+            attach = (lib_sync and self._attach_sync and self._apply_fn is None and not by_rows and b_ > a_ and warm_key in self._warm
                       and self._plans_ready(self._views("interior", percell)))
             if lib_sync:
                 self.comm.fork(lazy=fold and len(forward) > 0, attach=attach)
@@ -959,6 +993,11 @@ class HaloApply:
 
     def apply_schedule(self, x, cell_constants, y, G, dofmap, extra_forward=(), boundary_terms=None):
         """``apply`` as a generator (see ``schedule``)."""
+        marks = self.row_split(dofmap, min(x.numel(), y.numel())) if boundary_terms is None else None
+        if marks is not None:
+            op = self._op_rows
+            return self.schedule(lambda which: op.apply_rows(x, cell_constants, y, G, dofmap, marks, which), (),
+                                 [(self.fwd, x)] + list(extra_forward), [(self.rev, y)], None, by_rows=True)
         fn = self._apply_fn if self._apply_fn is not None else self.op
         return self.schedule(lambda c_, G_, d_: fn(x, c_, y, G_, d_), (cell_constants, G, dofmap),
                              [(self.fwd, x)] + list(extra_forward), [(self.rev, y)], boundary_terms)
@@ -968,10 +1007,11 @@ class HaloApply:
         communicator up (RCCL creates its channels on first use) with two no-effect exchanges --
         a forward scatter of x (ghosts receive their owners' values) and a reverse scatter of a
         zero vector."""
-        for name in self._launch_names():
-            a, b = self.ranges[name]
-            if b > a and self.op is not None and hasattr(self.op, "prepare"):
-                self.op.prepare(self._views(name, (cell_constants, G, dofmap))[2])
+        if self.row_split(dofmap, x.numel()) is None:  # (a row-split apply has built its three transposed plans by now)
+            for name in self._launch_names():
+                a, b = self.ranges[name]
+                if b > a and self.op is not None and hasattr(self.op, "prepare"):
+                    self.op.prepare(self._views(name, (cell_constants, G, dofmap))[2])
         # the device-side waits of the PEER transport are bounded: line the ranks up on the host before the first
         # exchange, so that a rank whose set-up took longer is not mistaken for a dead one
         if hasattr(self.comm, "barrier") and getattr(self.comm, "_world_id", None) is None:
@@ -981,6 +1021,11 @@ class HaloApply:
 
     def apply_local_only(self, x, cell_constants, y, G, dofmap):
         """The three kernel launches without any exchange (bench: kernel time at N > 1)."""
+        marks = self.row_split(dofmap, min(x.numel(), y.numel()))
+        if marks is not None:
+            for which in (1, 0):
+                self._op_rows.apply_rows(x, cell_constants, y, G, dofmap, marks, which)
+            return
         fn = self._apply_fn if self._apply_fn is not None else self.op
         for name in self._launch_names():
             a, b = self.ranges[name]
@@ -991,6 +1036,12 @@ class HaloApply:
     def apply_no_exchange(self, x, cell_constants, y, G, dofmap):
         """The launches of ``apply`` in its own schedule (streams, events, sub-ranges) with NO exchange: what cutting
         the apply into sub-launches costs by itself (bench.py: ``halo_split_cost_ms``).  Not an apply."""
+        marks = self.row_split(dofmap, min(x.numel(), y.numel()))
+        if marks is not None:
+            op = self._op_rows
+            for _ in self.schedule(lambda which: op.apply_rows(x, cell_constants, y, G, dofmap, marks, which), (), [], [], None, by_rows=True):
+                pass
+            return
         fn = self._apply_fn if self._apply_fn is not None else self.op
         for _ in self.schedule(lambda c_, G_, d_: fn(x, c_, y, G_, d_), (cell_constants, G, dofmap), [], []):
             pass

@@ -52,7 +52,8 @@ extern "C" {
  *      flags it publishes, so its neighbours fail too instead of consuming stale data; fus_comm_fork / fus_comm_join
  *      enforce their one-caller-stream contract (FUS_ERR_INVALID_ARGUMENT); new: fus_comm_fork_lazy, fus_comm_arm_join,
  *      fus_comm_health; the PEER blob identifies the exporting process by a random token and its device by PCI bus id.
- *      Added since without a bump (new symbols only): fus_mass_gather_plan_bytes / _build / _info, fus_mass_apply_gather_*.
+ *      Added since without a bump (new symbols only): fus_mass_gather_plan_bytes / _build / _info, fus_mass_apply_gather_*,
+ *      fus_mass_gather_plan_build_rows, fus_mass_gather_static_bytes / _build_* , fus_mass_apply_gather_static_*.
  * There are deliberately NO fus_cpu_* twins of the entry points (SURVEY.md 8b proposed them): a CPU path inside the
  * product would be a silent fallback; the CPU restatement of the reference is test infrastructure and lives outside the product tree.
  */
@@ -241,6 +242,34 @@ int64_t fus_mass_gather_plan_bytes(int ndof_per_entity, int64_t nent, int64_t nd
 int fus_mass_gather_plan_build(const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, int64_t ndofs,
                                void* workspace, int64_t workspace_bytes, void* stream);
 int fus_mass_gather_plan_info(const void* workspace, int64_t* out4);
+/*
+ * The plan of a ROW SUBSET: only the dofs d with row_set[d] == which (row_set: device uint8[ndofs]) get a row; every row still
+ * sums ALL its entries.  What a partitioned apply needs (scatterer.HaloApply; the reference applies the operator between its two
+ * scatters, cuda/demo_linear_box.py:546-553): the rows whose dof neither needs the forward exchange (an owned dof) nor is added
+ * into by the reverse exchange run next to the exchanges, the rest between them -- no launch and no receive ever adds into
+ * the same y[d] concurrently, so the atomic-free kernel stays valid at N > 1.  Same workspace size as the full plan.
+ */
+int fus_mass_gather_plan_build_rows(const int32_t* entity_dofmap, int ndof_per_entity, int64_t nent, int64_t ndofs,
+                                    const uint8_t* row_set, int which, void* workspace, int64_t workspace_bytes, void* stream);
+/*
+ * STATIC companion of a transposed-dofmap plan (opt-in; the caller declares entity_detJ constant across applies, as the
+ * reference's drivers keep it: cuda/demo_nonlinear_bowl.py:603-632 re-applies the mass operator with the same detJ every stage):
+ * a copy of detJ in ROW order plus a 16-bit entity offset per entry, in a second caller-owned workspace.  The apply then
+ * streams detJ contiguously instead of gathering it through the entry ids (the dependent gather that keeps the texture
+ * addresser 82 % busy in fus_mass_apply_gather_*); the entity constants are still read per apply and may change.  Same sums
+ * in the same order as fus_mass_apply_gather_* (bitwise identical results).  FUS_ERR_UNSUPPORTED_ENTITY: some block of 256
+ * consecutive dofs touches entities more than 65 535 apart (a numbering without locality) -- use fus_mass_apply_gather_*.
+ * fus_plan_release(static_workspace) forgets it.  Rebuild after changing detJ.
+ */
+int64_t fus_mass_gather_static_bytes(int ndof_per_entity, int64_t nent, int elem_bytes);
+int fus_mass_gather_static_build_f64(const void* workspace, const double* entity_detJ, void* static_workspace,
+                                     int64_t static_workspace_bytes, void* stream);
+int fus_mass_gather_static_build_f32(const void* workspace, const float* entity_detJ, void* static_workspace,
+                                     int64_t static_workspace_bytes, void* stream);
+int fus_mass_apply_gather_static_f64(const double* x, const double* entity_constants, double* y, const void* workspace,
+                                     const void* static_workspace, int ndof_per_entity, int64_t nent, void* stream);
+int fus_mass_apply_gather_static_f32(const float* x, const float* entity_constants, float* y, const void* workspace,
+                                     const void* static_workspace, int ndof_per_entity, int64_t nent, void* stream);
 int fus_mass_apply_gather_f64(const double* x, const double* entity_constants, double* y, const double* entity_detJ,
                               const void* workspace, int ndof_per_entity, int64_t nent, void* stream);
 int fus_mass_apply_gather_f32(const float* x, const float* entity_constants, float* y, const float* entity_detJ,

@@ -94,7 +94,13 @@ def test_distributed_code_path_on_one_gpu(halo):
     assert cfg["halo_split_cost_ms"] is not None and cfg["halo_exchange_exposed_ms"] is not None
     assert ("libfusgpu" in cfg["halo_transport"]) == (halo in ("peer", "native")) and ("PEER" in cfg["halo_transport"]) == (halo == "peer")
     assert cfg["halo_schedule"] == ("concurrent" if halo == "peer" else "split")
-    assert cfg["halo_transports_tried"] == [{"transport": halo, "result": "ok"}]
+    tried = cfg["halo_transports_tried"]
+    assert [t["transport"] for t in tried] == [halo] and tried[0]["result"] == "ok" and tried[0]["bring_up_failed_on_ranks"] == []
+    assert tried[0]["check_failed_on_ranks"] == [] and (tried[0]["arena_memory_by_rank"] is not None) == (halo == "peer")
+    fc = cfg["first_contact"]  # who sits where, before anything is exchanged
+    assert len(fc["ranks"]) == 1 and fc["ranks"][0]["rank"] == 0 and ":" in fc["ranks"][0]["pci_bus_id"] and fc["HSA_ENABLE_IPC_MODE_LEGACY"] == "0"
+    assert "first contact: rank 0 ->" in r.stderr and "CHOSEN" in r.stderr
+    assert out["check"]["ok"] is True and out["check"]["rel_l2"] <= 1e-12 and cfg["check"]["ok"] is True  # N > 1 form of the result check
     assert cfg["lib_built_from_tree"] is True
     assert cfg["halo_check"]["ok"] is True and cfg["halo_check"]["forward_max_abs_err"] == 0.0
     assert out["roofline"]["kernel_ms"] > 0 and cfg["lib_sha"]
@@ -173,12 +179,36 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
         # the run checks its own exchanges before timing anything (forward: exact copy; reverse: owned sums)
         assert cfg["halo_check"]["ok"] is True and cfg["halo_check"]["owned_sum_defect_over_sum_abs"] < 1e-9
         assert "PEER" in cfg["halo_transport"] and cfg["halo_check"]["device_wait_timeouts"] == 0
-        if mode == "mass":  # overlapped sub-launches + the reverse receive add into one y: the float-atomic twin, not the gather kernel
-            assert out["roofline"]["kernel"] in ("fus::mass_plan_kernel", "fus::mass_kernel")
+        if mode == "mass":  # the partitioned apply keeps the atomic-free kernel: HaloApply splits it by dof
+            assert out["roofline"]["kernel"] == "fus::mass_gather_kernel"
+        assert out["check"]["ok"] is True and out["check"]["rel_l2"] <= 1e-12  # every rank's owned dofs against the oracle, reverse-scattered
+        fc = cfg["first_contact"]
+        assert [r_["rank"] for r_ in fc["ranks"]] == list(range(n)) and len({r_["pid"] for r_ in fc["ranks"]}) == n and fc["rehearsal"] is True
     else:  # the solver lines check the exchange they are about to use, too
         hc = out["config"]["halo_check"]
         assert hc["ok"] is True and hc["forward_wrong_ghosts"] == 0 and hc["reverse_sum"] == hc["global_ghosts"] > 0
         assert out["config"]["halo_schedule"] == "concurrent"
+
+
+@pytest.mark.gpu
+def test_halo_compare_one_run_times_every_transport():
+    """``--halo-compare``: ONE run times the apply over every transport that comes up, in alternating rounds, and puts each one's
+    exposed cost in ``config.halo_compare``.  1-rank world through the N > 1 code path: PEER and RCCL both come up; 2 rehearsal
+    ranks sharing the GPU: RCCL cannot (two ranks on one device) and the line says so."""
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "4", "--warmup", "1", "--cells", "12", "--no-cpu-baseline", "--halo-compare"],
+                       env=_env(FUS_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    hc = _one_json_line(r.stdout)["config"]["halo_compare"]
+    assert hc["chosen"] == "peer" and set(hc["transports"]) == {"peer", "native"} and hc["rounds"] == 5
+    for k, v in hc["transports"].items():
+        assert v["ms_per_step_median"] > 0 and len(v["ms_per_step_rounds"]) == 5 and v["failed_waits_all_ranks"] == 0
+        assert abs(v["exposed_ms"] - (v["ms_per_step_median"] - hc["one_launch_ms"])) < 1e-12
+    assert hc["transports"]["native"]["max_rel_diff_vs_chosen"] < 1e-12 and "halo compare: peer:" in r.stderr
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--cells", "8", "--no-cpu-baseline", "--halo-compare"],
+                       env=_env(FUS_BENCH_REHEARSAL="1"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    hc = _one_json_line(r.stdout)["config"]["halo_compare"]
+    assert set(hc["transports"]) == {"peer"} and "rehearsal" in hc["not_compared"]["native"]
 
 
 @pytest.mark.gpu

@@ -275,6 +275,87 @@ def test_partitioned_apply_async_transport_one_gpu(gpu, oracle_c, P, cells, grid
     assert all(h.health() == 0 for h in halos)
 
 
+@pytest.mark.parametrize("transport,overlap", [("peer", "concurrent"), ("peer", "split"), ("local", "concurrent"), ("local", False)],
+                         ids=["peer-concurrent", "peer-split", "local-concurrent", "local-sequential"])
+@pytest.mark.parametrize("P,cells,grid,ghost_order", [
+    (4, (12, 7, 7), (2, 1, 1), "owner"),
+    (3, (16, 16, 9), (2, 2, 1), 7),
+    (4, (14, 14, 14), (2, 2, 2), 5),
+], ids=["2ranks-direct", "4ranks-permuted", "8ranks-permuted"])
+def test_partitioned_mass_apply_row_split_one_gpu(gpu, oracle_c, P, cells, grid, ghost_order, transport, overlap):
+    """the partitioned MASS apply on the atomic-free kernel.  ``HaloApply`` splits a row-wise operator by DOF,
+    not by cell: set A (owned dofs the reverse exchange does not add into) in one launch next to the exchanges, set B (ghost dofs
+    and owned dofs ghosted elsewhere) between them -- so no launch and no receive kernel adds into one y[d] concurrently.  2 / 4 / 8
+    in-process ranks, every rank's owned part == the serial oracle's cell mass apply (numba-cpu/operators.py:19-68), twice in a row;
+    the kernel really is the gather kernel (>= 32 768 entries per rank)."""
+    torch = gpu
+    schedule = overlap if overlap else "split"
+    overlap = bool(overlap)
+    boxmesh, scat, ops, gll, pre, utils = (pkg(m) for m in ("boxmesh", "scatterer", "operators", "gll", "precompute", "utils"))
+    R = int(np.prod(grid))
+    wid = next(_world_ids)
+    dev = torch.device("cuda", 0)
+    pts, wts, D = gll.tabulate_1d(P)
+    n = P + 1
+    w3 = gll.tensor_weights_3d(wts)
+    dg = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))
+    op = ops.mass_operator(n**3, np.float64)
+    ranks = []
+    for r in range(R):
+        mesh = boxmesh.BoxMesh(P, cells, grid=grid, rank=r, perturb=0.16, seed=3, ghost_order=ghost_order)
+        assert mesh.ncells * n**3 >= ops._MASS_PLAN_MIN_ENTRIES
+        detJ = np.zeros((mesh.ncells, n**3))
+        pre.compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), mesh.ncells, dg, w3)
+        x = ref_field(mesh.dof_coordinates())
+        x[mesh.nlocal:] = -777.0  # ghosts are stale until the forward scatter
+        ranks.append(dict(mesh=mesh, x=torch.from_numpy(x).to(dev), y=torch.zeros(mesh.ndofs, dtype=torch.float64, device=dev),
+                          cc=torch.from_numpy(global_cell_constants(mesh)).to(dev), detJ=torch.from_numpy(detJ).to(dev),
+                          dm=torch.from_numpy(mesh.dofmap).to(dev)))
+    od, gd = utils.compute_scatterer_data_all([rk["mesh"].index_map for rk in ranks])
+    halos = [scat.HaloApply(rk["mesh"], op, _local_comm(scat, wid, R, r, transport), np.float64, overlap=overlap, plan=(od[r], gd[r]),
+                            schedule=schedule) for r, rk in enumerate(ranks)]
+    for h, rk in zip(halos, ranks):
+        marks = h.row_split(rk["dm"], rk["mesh"].ndofs)
+        assert marks is not None and marks.dtype == torch.uint8  # the row split is what this apply uses
+        nl = rk["mesh"].nlocal
+        assert bool((marks[nl:] == 1).all()) and int(marks[:nl].sum().item()) == np.unique(np.asarray(gd[halos.index(h)][0])).size
+    for rep in range(2):
+        for rk in ranks:
+            rk["y"].zero_()
+        live = [h.apply_schedule(rk["x"], rk["cc"], rk["y"], rk["detJ"], rk["dm"]) for h, rk in zip(halos, ranks)]
+        while live:
+            nxt = []
+            for g in live:
+                try:
+                    next(g)
+                    nxt.append(g)
+                except StopIteration:
+                    pass
+            live = nxt
+    torch.cuda.synchronize()
+    ms = boxmesh.BoxMesh(P, cells, perturb=0.16, seed=3)
+    detJ_s = np.zeros((ms.ncells, n**3))
+    pre.compute_scaled_jacobian_determinant(detJ_s, (ms.x_dofs, ms.x_g), ms.ncells, dg, w3)
+    x_s = ref_field(ms.dof_coordinates())
+    y_ser = np.zeros(ms.ndofs)
+    oracle_c.mass_apply(x_s, global_cell_constants(ms), y_ser, detJ_s, ms.dofmap)
+    seen = np.zeros(ms.ndofs, dtype=int)
+    for rk in ranks:
+        m = rk["mesh"]
+        lex = m.global_lexicographic_ids()
+        seen[lex[: m.nlocal]] += 1
+        assert rel_l2(rk["y"].cpu().numpy()[: m.nlocal], y_ser[lex[: m.nlocal]]) < 1e-13
+        assert np.allclose(rk["x"].cpu().numpy(), x_s[lex], rtol=0, atol=1e-12)  # ghosts refreshed
+    assert np.all(seen == 1) and all(h.health() == 0 for h in halos)
+    # the launch schedule without exchange and the plain sequence of launches add the same local contributions
+    rk, h = ranks[0], halos[0]
+    ya, yb = torch.zeros_like(rk["y"]), torch.zeros_like(rk["y"])
+    h.apply_no_exchange(rk["x"], rk["cc"], ya, rk["detJ"], rk["dm"])
+    h.apply_local_only(rk["x"], rk["cc"], yb, rk["detJ"], rk["dm"])
+    torch.cuda.synchronize()
+    assert torch.equal(ya, yb)  # the atomic-free kernel is bitwise reproducible
+
+
 def _run_peer_world(world, mode, args, timeout=300):
     """``world`` real processes sharing cuda:0, halo transport PEER over HIP IPC handles (tests/_peer_worker.py)."""
     import os
@@ -703,6 +784,9 @@ def test_fork_join_enforce_one_caller_stream(gpu):
     side = comm.stream()
     s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
     big = torch.zeros(1 << 28, dtype=torch.float64, device="cuda")  # 2 GiB: a fill takes ~0.5 ms
+    # the fill runs on the default stream and every stream below is non-blocking: without this the first adds overtake the fill on
+    # part of the vector (what made this test fail now and then: tools/stream_visibility_probe.py, profiles/r05c_stream_visibility_probe.log)
+    torch.cuda.synchronize()
     with torch.cuda.stream(s_a):
         comm.fork()
         with torch.cuda.stream(side):

@@ -791,7 +791,8 @@ def test_lists_and_run_tables_of_one_plan(gpu, oracle_c, P, dtype):
                 y = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
                 fn(y)
                 _check(y.copy_to_host(), ref, dtype, f"{what}, run-table mode {mode}, P={P}")
-        assert len(ops._PLANS._plans) == 1
+        # one row-ordered plan for the three kernels (+ the in-kernel-geometry operator's strip-ordered twin where it was kept)
+        assert len([k for k in ops._PLANS._plans if k[-1] != "strips"]) == 1 and len(ops._PLANS._plans) <= 2
     finally:
         ops._MASS_PLAN_MIN_ENTRIES = old_min
         lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
@@ -1006,6 +1007,23 @@ def test_mass_gather_kernel(gpu, oracle_c, P, cells, order, dtype):
     _check(ya.cpu().numpy(), y_ref, dtype, "atomic twin")
     info = ops._GATHER_PLANS.get(dm, mesh.ndofs)[2]
     assert info[0] == mesh.ndofs and info[1] == 1 and info[2] == 8  # every dof touched, rows 0..ndofs-1, vertex dofs in 8 cells
+    # static_detJ=True: detJ streamed from a row-ordered copy (fus_mass_gather_static_*): the same sums in the same order
+    ops._STATIC_DETJ.clear()
+    ops_static = ops.mass_operator(n**3, dtype, static_detJ=True)
+    ys = torch.zeros_like(y)
+    ops_static(x_d, cc_d, ys, dj_d, dm)
+    assert torch.equal(ys, y1), "static-detJ apply must equal the default apply bitwise"
+    assert len([v for v in ops._STATIC_DETJ._entries.values() if v is not None]) == 1  # ... and it really took the static path
+    cc2 = cc_d * 3.0  # the constants may change per apply
+    ys2, yd2 = torch.zeros_like(y), torch.zeros_like(y)
+    ops_static(x_d, cc2, ys2, dj_d, dm)
+    op(x_d, cc2, yd2, dj_d, dm)
+    assert torch.equal(ys2, yd2)
+    dj_d.mul_(2.0)  # a torch in-place change of detJ is noticed (version counter): the copy is rebuilt
+    ys3 = torch.zeros_like(y)
+    ops_static(x_d, cc_d, ys3, dj_d, dm)
+    _check(ys3.cpu().numpy(), 2 * y_ref, dtype, "static-detJ apply after detJ changed")
+    dj_d.mul_(0.5)
     # every build of the kernel (rows per thread)
     lib = pkg("_lib")
     for variant in (1, 2, 4):
@@ -1014,6 +1032,9 @@ def test_mass_gather_kernel(gpu, oracle_c, P, cells, order, dtype):
             yv = torch.zeros_like(y)
             op(x_d, cc_d, yv, dj_d, dm)
             assert torch.equal(yv, y1), f"variant {variant}"
+            yv.zero_()
+            ops_static(x_d, cc_d, yv, dj_d, dm)
+            assert torch.equal(yv, y1), f"static, variant {variant}"
         finally:
             lib.set_tuning(lib.TUNE_MASS_VARIANT, 0)
     # boundary facets (N = n^2): only the boundary dofs are touched
@@ -1035,6 +1056,9 @@ def test_mass_gather_kernel(gpu, oracle_c, P, cells, order, dtype):
         y = torch.full((mesh.ndofs,), 0.5, dtype=tdt, device="cuda")  # untouched dofs keep their values
         ops.mass_operator(n * n, dtype)(x_d, dev.to_device(fc.astype(dtype)), y, dev.to_device(dF.astype(dtype)), fdm_d)
         _check(y.cpu().numpy(), y_ref, dtype, "gather facet mass")
+        yfs = torch.full((mesh.ndofs,), 0.5, dtype=tdt, device="cuda")
+        ops.mass_operator(n * n, dtype, static_detJ=True)(x_d, dev.to_device(fc.astype(dtype)), yfs, dev.to_device(dF.astype(dtype)), fdm_d)
+        assert torch.equal(yfs, y), "static-detJ facet mass (sparse row list)"
         finfo = ops._GATHER_PLANS.get(fdm_d, mesh.ndofs)[2]
         assert finfo[0] == np.unique(fdm).size and finfo[1] == 0
     finally:
@@ -1103,9 +1127,43 @@ def test_mass_gather_random_dofmaps(gpu, seed):
                 torch.cuda.synchronize()
                 err = np.abs(y.cpu().numpy().astype(np.float64) - ref).max() / max(np.abs(ref).max(), 1.0)
                 assert err < tol * max(1, int(counts.max())), f"N={N} nent={nent} nd={nd} {dt.__name__} variant {variant}: {err}"
+                # the static companion (detJ in row order, 16-bit entity offsets): bitwise the same sums
+                sbytes = int(L.fus_mass_gather_static_bytes(N, nent, 8 if dt == np.float64 else 4))
+                sws = torch.empty(sbytes, dtype=torch.uint8, device="cuda")
+                sfx = "f64" if dt == np.float64 else "f32"
+                assert getattr(L, f"fus_mass_gather_static_build_{sfx}")(ws.data_ptr(), djd.data_ptr(), sws.data_ptr(), sbytes, None) == 0
+                ys = torch.from_numpy(y0.astype(dt)).cuda()
+                assert getattr(L, f"fus_mass_apply_gather_static_{sfx}")(xd.data_ptr(), cd.data_ptr(), ys.data_ptr(), ws.data_ptr(), sws.data_ptr(), N, nent, None) == 0
+                torch.cuda.synchronize()
+                assert torch.equal(ys, y), f"static companion, {dt.__name__} variant {variant}"
+                other = "f32" if dt == np.float64 else "f64"  # a companion built for another element size is refused
+                assert getattr(L, f"fus_mass_apply_gather_static_{other}")(xd.data_ptr(), cd.data_ptr(), ys.data_ptr(), ws.data_ptr(), sws.data_ptr(), N, nent, None) == -6
+                L.fus_plan_release(sws.data_ptr())
+                assert getattr(L, f"fus_mass_apply_gather_static_{sfx}")(xd.data_ptr(), cd.data_ptr(), ys.data_ptr(), ws.data_ptr(), sws.data_ptr(), N, nent, None) == -6
+        # row subsets (the partitioned apply's split): two plans over disjoint dof sets add up to the full apply, each touches
+        # only its own rows
+        marks = torch.from_numpy((rng.random(nd) < 0.4).astype(np.uint8)).cuda()
+        ws_ab = [torch.empty(nbytes, dtype=torch.uint8, device="cuda") for _ in range(2)]
+        for w, wsub in enumerate(ws_ab):
+            assert L.fus_mass_gather_plan_build_rows(dm_d.data_ptr(), N, nent, nd, marks.data_ptr(), w, wsub.data_ptr(), nbytes, None) == 0
+        xd, cd, djd = (torch.from_numpy(a).cuda() for a in (x, c, dj))
+        mk = marks.cpu().numpy().astype(bool)
+        for w, wsub in enumerate(ws_ab):
+            assert L.fus_mass_gather_plan_info(wsub.data_ptr(), info) == 0
+            assert info[0] == int(((counts > 0) & (mk == bool(w))).sum())
+            y = torch.from_numpy(y0).cuda()
+            assert L.fus_mass_apply_gather_f64(xd.data_ptr(), cd.data_ptr(), y.data_ptr(), djd.data_ptr(), wsub.data_ptr(), N, nent, None) == 0
+            torch.cuda.synchronize()
+            got = y.cpu().numpy()
+            mine = mk == bool(w)
+            assert np.array_equal(got[~mine], y0[~mine]), "a row-subset launch must not touch the other rows"
+            assert np.abs(got[mine] - ref[mine]).max(initial=0.0) < 1e-13 * max(1, int(counts.max())) * max(np.abs(ref).max(), 1.0)
+        assert L.fus_mass_gather_plan_build_rows(dm_d.data_ptr(), N, nent, nd, None, 0, ws_ab[0].data_ptr(), nbytes, None) == -1
     finally:
         lib.set_tuning(lib.TUNE_MASS_VARIANT, 0)
         L.fus_plan_release(ws.data_ptr())
+        for wsub in locals().get("ws_ab", []):
+            L.fus_plan_release(wsub.data_ptr())
 
 
 def test_mass_gather_policy_and_errors(gpu, oracle_c):

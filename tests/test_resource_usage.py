@@ -42,6 +42,11 @@ SHIPPED = [
     (r"stiffness_plan_kernel<float, 2, 28, false, true, 5, 3>", 96, 5),
     (r"stiffness_plan_kernel<float, 4, 10, false, true, 5, 5>", 96, 5),
     (r"stiffness_plan_kernel<float, 6, 5, true, true, 1, 4>", 96, 4),   # 4 by LDS: fp32 sums are kept in double
+    # high degrees: the ring of G slabs keeps P = 9 at three waves per SIMD (ring of 1: 165 VGPRs); P = 10 is bound by its LDS (66 kB per
+    # workgroup of two cells: 2 workgroups per CU whatever the registers do), see test_high_degree_builds
+    (r"stiffness_plan_kernel<double, 8, 3, true, false, 1, 2>", 168, 3),
+    (r"stiffness_plan_kernel<double, 9, 2, true, true, 1, 1>", 168, 3),
+    (r"westervelt_cell_kernel<double, 9, 2, 1, 1, false>", 168, 3),
     # in-kernel geometry
     (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true>", 128, 4),
     (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, 1, false>", 168, 3),
@@ -57,8 +62,10 @@ SHIPPED = [
     (r"westervelt_cell_kernel<double, 4, 10, 1, 5, false>", 128, 4),
     (r"westervelt_cell_kernel<float, 4, 10, 1, 3, true>", 96, 4),
     # atomic-free mass apply (transposed dofmap): latency-bound unless eight waves per SIMD are resident
-    (r"mass_gather_kernel<double, 1, true, 2>", 64, 8),
-    (r"mass_gather_kernel<float, 1, true, 4>", 64, 8),
+    (r"mass_gather_kernel<double, 1, true, 2, false>", 64, 8),
+    (r"mass_gather_kernel<float, 1, true, 4, false>", 64, 8),
+    (r"mass_gather_kernel<double, 1, true, 2, true>", 64, 8),   # detJ streamed in row order (static companion)
+    (r"mass_gather_kernel<double, 1, false, 2, false>", 64, 8),  # row subsets of the partitioned apply (row list)
     # plan-free column kernel
     (r"stiffness_col_kernel<double, 4, 10>", 128, 4),
     # PEER halo transport: the whole design rests on these fitting NEXT TO an operator launch that holds every
@@ -92,6 +99,17 @@ def test_no_scratch(table):
         if d["scratch"] > lim:
             bad.append((name, d["scratch"]))
     assert not bad, f"kernels with scratch (register spills): {bad}"
+
+
+def test_high_degree_builds(table):
+    """VERDICT r4 item 6 (second half): P = 9 runs at three waves per SIMD (165 VGPRs with a ring of ONE G slab); what limits P = 10
+    is LDS, not registers: three cubes of two 11^3 cells are 66 kB, so a CU holds 2 workgroups = 2 waves per SIMD even at 168 VGPRs
+    (one cell per workgroup would be 33 kB and 4 workgroups of 2 waves: the same 8 waves per CU)."""
+    p9 = _find(table, r"stiffness_plan_kernel<double, 9, 2, true, true, 1, 1>")
+    assert p9["vgpr"] <= 168 and p9["occupancy"] >= 3 and 3 * p9["lds"] <= 160 * 1024
+    p10 = _find(table, r"stiffness_plan_kernel<double, 10, 2, true, true, 1, 6>")
+    assert p10["scratch"] == 0 and 2 * p10["lds"] <= 160 * 1024 < 3 * p10["lds"]  # LDS admits two workgroups per CU, not three
+    assert p10["occupancy"] >= 2
 
 
 def test_headline_kernel_lds_allows_four_workgroups(table):

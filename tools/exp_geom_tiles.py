@@ -23,7 +23,8 @@ sys.path.insert(0, os.path.join(ROOT, "tests"))
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--rounds", type=int, default=5)
-    ap.add_argument("--reps", type=int, default=40)
+    ap.add_argument("--reps", type=int, default=200)
+    ap.add_argument("--warm", type=int, default=2000, help="applies before the first timed round (the device's clocks settle under load)")
     a = ap.parse_args()
     import torch
 
@@ -72,6 +73,7 @@ def main():
         ops._PLANS.clear()
         ops.use_strip_order(True)
         ws_strips, _ = ops._PLANS.get(dm, strips=True)
+        perm = ops._PLANS.last_order  # the strip order, if the plan cache kept it
         d_strips = distinct(ws_strips, epb)
         y.zero_()
         op(x, cc, y, None, dm)
@@ -90,7 +92,23 @@ def main():
         ops.use_strip_order(False)
         ops._PLANS.get(dm, strips=True)
         variants[f"rows ({epb} cells / batch)"] = (run_rows, d_rows)
-        variants["two-row strips"] = (run_strips, d_strips)
+        variants["two-row strips (order inside the plan)"] = (run_strips, d_strips)
+        # the same strips with the per-cell arrays physically permuted (no order indirection in the kernel's prologue)
+        if perm is not None:
+            pl = perm.long()
+            dm_p, xd_p, cc_p = dm[pl].contiguous(), xd[pl].contiguous(), cc[pl].contiguous()
+            op_p = ops.stiffness_operator(P, D.flatten(), np.float64, geometry=(xd_p, mesh.x_g, pts, wts))
+            ops.use_strip_order(False)
+            ws_p, _ = ops._PLANS.get(dm_p, strips=True)
+            y.zero_()
+            op_p(x, cc_p, y, None, dm_p)
+            assert float((y - y_rows).norm() / y_rows.norm()) < 1e-13
+
+            def run_phys():
+                ops.use_strip_order(False)
+                op_p(x, cc_p, y, None, dm_p)
+
+            variants["two-row strips (arrays permuted)"] = (run_phys, distinct(ws_p, epb))
         if P == 4:
             # 2 x 2 x 5 tiles of 20 cells: the order from the cell lattice, the plan through the generic entry points
             ijk = mesh._cell_ijk
@@ -119,6 +137,9 @@ def main():
             else:
                 print(f"P={P}: 2x2x5 skipped (this library has no 20-cell build: rc {rc})", flush=True)
         res = {k: [] for k in variants}
+        for _ in range(a.warm):
+            run_rows()
+        torch.cuda.synchronize()
         for _ in range(a.rounds):
             for k, (fn, _) in variants.items():
                 res[k].append(timed(fn))
@@ -127,7 +148,7 @@ def main():
             t = float(np.median(res[k]))
             print(f"P={P} {N}^3 cells  {k:46s} distinct dofs / cell {d:6.1f}   {t:7.1f} us   {100 * (t / base - 1):+5.1f} %", flush=True)
         ops._PLANS.clear()
-        ops.use_strip_order(True)
+        ops.use_strip_order(False)  # the default
         del op, x, y, cc, dm, xd
 
 

@@ -6,6 +6,11 @@ AFTER a device synchronise?  Repeats the scenario in variants to see which ingre
   B  the same on the communicator's stream (an ExternalStream over the library's high-priority non-blocking stream)
   C  B with the library's fork / join around the add (the test's phase 2)
   D  the whole test sequence (40 adds behind a fork from s_a, refused join / fork from s_b, join, then phase 2)
+  D1-D4  D with none / some of the refused calls;  D5  D with a device synchronise between ``torch.zeros`` and the first use
+
+Finding (profiles/r05c_stream_visibility_probe.log): A, B, C never fail; D and D1-D4 fail in about half of the repetitions whatever
+sits in the middle -- the vector is allocated and ZERO-FILLED ON THE DEFAULT STREAM and first used on non-blocking streams with
+no ordering in between, so the first adds overtake the fill on part of the vector.  A test bug, not a library one; D5 is the fix.
 
 Each variant is repeated ``--reps`` times; prints the number of repetitions with a wrong count and the worst count."""
 import argparse
@@ -69,8 +74,10 @@ def main():
         torch.cuda.synchronize()
         return count(big, 3.0)
 
-    def variant_d(comm, middle="both"):
-        big = torch.zeros(n, dtype=torch.float64, device="cuda")
+    def variant_d(comm, middle="both", sync_after_fill=False):
+        big = torch.zeros(n, dtype=torch.float64, device="cuda")  # the fill runs on the DEFAULT stream; every stream below is non-blocking
+        if sync_after_fill:
+            torch.cuda.synchronize()
         side = comm.stream()
         s_a, s_b = torch.cuda.Stream(), torch.cuda.Stream()
         with torch.cuda.stream(s_a):
@@ -104,7 +111,8 @@ def main():
     for name, fn in (("A torch high-priority stream", variant_a), ("B communicator stream", lambda: variant_b(comm)),
                      ("C fork / add / join x 3", lambda: variant_c(comm)), ("D the test's sequence", lambda: variant_d(comm)),
                      ("D1 no refused calls", lambda: variant_d(comm, "none")), ("D2 hipStreamQuery only", lambda: variant_d(comm, "query")),
-                     ("D3 refused join only", lambda: variant_d(comm, "join")), ("D4 refused fork only", lambda: variant_d(comm, "fork"))):
+                     ("D3 refused join only", lambda: variant_d(comm, "join")), ("D4 refused fork only", lambda: variant_d(comm, "fork")),
+                     ("D5 = D, synchronise after the fill", lambda: variant_d(comm, "both", True))):
         bad = []
         for _ in range(a.reps):
             w = fn()
