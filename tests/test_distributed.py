@@ -100,7 +100,7 @@ def test_partitioned_rk4_solver_on_one_gpu(tmp_path, oracle_c, grid):
     """Fused linear RK4 solver on 2 / 4 ranks (all on cuda:0, gloo transport staged through the
     host) against the single-rank oracle-side solver: forward scatters of u_n and v_n, facet
     terms on partition interfaces, reverse scatter, lumped mass assembly."""
-    import rk4_oracle
+    from oracle import rk4_oracle
 
     P, cells, L = 3, (4, 4, 4), 0.012
     res = run_ranks("gpu-solver", tmp_path, P, cells, grid, 1)
@@ -119,7 +119,7 @@ def test_partitioned_rk4_solver_on_one_gpu(tmp_path, oracle_c, grid):
 def test_partitioned_westervelt_solver_on_one_gpu(tmp_path, oracle_c):
     """Fused Westervelt stage on 2 ranks: three quantities cross the partition per stage (u_n and
     v_n forward, b and the solution-dependent lumped mass m reverse)."""
-    import rk4_oracle
+    from oracle import rk4_oracle
 
     P, cells, L = 3, (4, 3, 3), 0.012
     res = run_ranks("gpu-solver-nl", tmp_path, P, cells, (2, 1, 1), 1)

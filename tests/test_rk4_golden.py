@@ -2,7 +2,7 @@
 imported reference's own operators and scatter closures (numba-cpu/operators.py, scatterer.py) through the stage sequence
 of its RK4 loop (cuda/demo_linear_box.py:487-566) -- tests/golden/generate_golden.py --only rk4.
 
-  * CPU: the oracle-side loop (tests/rk4_oracle.py, what every solver test compares with) reproduces them, for the
+  * CPU: the oracle-side loop (oracle/rk4_oracle.py, what every solver test compares with) reproduces them, for the
     source evaluated at the stage time (numba-cpu / C++ drivers) and at the step time (the CUDA demos' quirk);
   * GPU: the solver itself -- reference launch sequence and fused stages, one rank and two in-process ranks over both
     in-process transports -- reproduces them.
@@ -14,7 +14,7 @@ import numpy as np
 import pytest
 
 from conftest import GOLDEN, pkg, rel_l2
-import rk4_oracle
+from oracle import rk4_oracle
 
 
 def _case(name):

@@ -5,7 +5,7 @@ import numpy as np
 import pytest
 
 from conftest import pkg, rel_l2
-import rk4_oracle
+from oracle import rk4_oracle
 
 pytestmark = pytest.mark.gpu
 

@@ -22,7 +22,7 @@ def main():
     ap.add_argument("--dofs", type=float, default=10e6)
     ap.add_argument("--degrees", default="2,3,4,5,6,8")
     ap.add_argument("--dtypes", default="f64,f32")
-    ap.add_argument("--reps", type=int, default=20)
+    ap.add_argument("--reps", type=int, default=100)
     ap.add_argument("--affine", action="store_true")
     a = ap.parse_args()
     import torch
@@ -73,7 +73,17 @@ def main():
                     t = timeit(lambda: opa(x, cc, y, G, dm))
                     res.append(f"K[affine build {av}] {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s")
                 lib.set_tuning(lib.TUNE_PLAN_VARIANT, -1)
-            for name, fn in (("M", mop), ("M[atomic]", mop.atomic)):  # default (atomic-free from P = 3 up) and the float-atomic twin
+            gll = fusgpu_loader.submodule("gll")
+            pts1, wts1 = gll.gll_points_weights(P)
+            opg = ops.stiffness_operator(P, pb["D"].flatten(), dt, geometry=(mesh.x_dofs, mesh.x_g, pts1, wts1))
+            for _ in range(100):  # the in-kernel-geometry kernel needs the steady state (profiles/r05d_geom_variance_probe.log)
+                opg(x, cc, y, None, dm)
+            t = timeit(lambda: opg(x, cc, y, None, dm))
+            gbs = mesh.ncells * bench.geom_bytes_per_cell(P, T) / (t * 1e-3) / 1e9
+            res.append(f"K[in-kernel geometry] {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s {100 * gbs / 8000:5.1f}% of its own contract")
+            mops = ops.mass_operator((P + 1) ** 3, dt, static_detJ=True)
+            # default (atomic-free from P = 3 up), detJ streamed in row order (opt-in), the float-atomic twin
+            for name, fn in (("M", mop), ("M[static detJ]", mops), ("M[atomic]", mop.atomic)):
                 t = timeit(lambda: fn(x, cc, y, detJ, dm))
                 gbs = mesh.ncells * mass_bytes_per_cell(P, T) / (t * 1e-3) / 1e9
                 res.append(f"{name} {t:.4f} ms {mesh.ndofs / t / 1e6:6.2f} GDOF/s {100 * gbs / 8000:5.1f}%")
