@@ -1289,7 +1289,7 @@ def bench_rk4(args, rank, world, device):
     scat = fusgpu_loader.submodule("scatterer")
     comm = first_comm(args, scat, world, device)[0] if world > 1 else None
     out = measure_rk4(args, rank, world, device, args.mode, args.perturbed, args.in_kernel_geometry, args.steps, args.warmup, comm,
-                      cpu_leg=not args.no_cpu_baseline)
+                      cpu_leg=not args.no_cpu_baseline, two_gather=args.two_gather)
     if rank == 0:
         emit(out)
     if world > 1:
@@ -1327,6 +1327,10 @@ def main():
     ap.add_argument("--halo-compare", action="store_true",
                     help="N > 1: after the timed region, time the apply over EVERY transport that comes up (peer, native = RCCL) in alternating "
                          "rounds in this one process and put each one's exposed cost in config.halo_compare")
+    ap.add_argument("--two-gather", action="store_true",
+                    help="--mode westervelt: the cell pass a heterogeneous medium takes (u_n and v_n gathered separately), forced on the homogeneous test medium")
+    ap.add_argument("--mass-static", action="store_true",
+                    help="--mode mass: mass_operator(N, T, static_detJ=True) -- detJ streamed from a row-ordered copy (opt-in: the caller promises a constant detJ)")
     ap.add_argument("--mass-atomic", action="store_true",
                     help="--mode mass: the float-atomic batch-plan kernel instead of the atomic-free transposed-dofmap kernel (a partitioned "
                          "apply keeps the atomic-free kernel too: HaloApply splits it by dof, not by cell)")
@@ -1468,7 +1472,7 @@ def main():
         def op(x_, cc_, y_, detJ_, dm_):
             dmo(x_, y_)
     elif mass:
-        op = ops.mass_operator(n**3, dt, exclusive=args.exclusive, atomic=args.mass_atomic or args.exclusive)
+        op = ops.mass_operator(n**3, dt, exclusive=args.exclusive, atomic=args.mass_atomic or args.exclusive, static_detJ=args.mass_static)
     else:
         op = ops.stiffness_operator(P, D.flatten(), dt)
 

@@ -38,7 +38,6 @@ def _signatures():
         "fus_plan_mark_exclusive": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_mass_gather_plan_bytes": [_int, _i64, _i64],
         "fus_mass_gather_plan_build": [_vp, _int, _i64, _i64, _vp, _i64, _vp],
-        "fus_plan_chain": [_vp, _int, _int, _i64, _int, _int, _vp, _vp],
         "fus_mass_gather_plan_build_rows": [_vp, _int, _i64, _i64, _vp, _int, _vp, _i64, _vp],
         "fus_mass_gather_static_bytes": [_int, _i64, _int],
         "fus_mass_gather_static_build_f64": [_vp, _vp, _vp, _i64, _vp],

@@ -57,7 +57,6 @@ struct PlanInfo {
   int64_t nent = 0;
   bool ordered = false;
   bool exclusive = false;  // fus_plan_mark_exclusive has run: the plan carries exclusive-dof marks
-  int64_t nchain = 0;      // fus_plan_chain has run: chains of batches (0: not chained)
 };
 std::mutex g_plans_mu;
 std::unordered_map<const void*, PlanInfo> g_plans;
@@ -67,7 +66,7 @@ void plan_register(const void* ws, int N, int epb, int64_t nent, bool ordered) {
   g_plans[ws] = PlanInfo{N, epb, nent, ordered, false};
 }
 // true if ``ws`` holds a plan for exactly this shape; ``ordered`` out
-bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, bool* exclusive = nullptr, int64_t* nchain = nullptr) {
+bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, bool* exclusive = nullptr) {
   std::lock_guard<std::mutex> lk(g_plans_mu);
   auto it = g_plans.find(ws);
   if (it == g_plans.end()) return false;
@@ -75,7 +74,6 @@ bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, boo
   if (p.N != N || p.epb != epb || p.nent != nent) return false;
   *ordered = p.ordered;
   if (exclusive) *exclusive = p.exclusive;
-  if (nchain) *nchain = p.nchain;
   return true;
 }
 
@@ -239,9 +237,8 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   if (!x || !cc || !y || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   bool ord = false;
-  int64_t nchain = 0;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &nchain)) {
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) {
 #ifdef FUS_EXPERIMENT_GEOM_CPB20
     // EXPERIMENT (tools/exp_geom_tiles.py): a generic plan with 20 cells per batch (2 x 2 x 5 tiles:
     // 85 instead of 103 distinct dofs per cell) takes a 512-thread build of the kernel -- 65 kB of LDS, 2 workgroups per CU
@@ -256,7 +253,7 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1)), nchain); \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -642,24 +639,6 @@ int fus_plan_build_ordered(const int32_t* dofmap, const int32_t* entity_order, i
     if (e != hipSuccess) return hip_rc(e);
   }
   plan_register(workspace, N, entities_per_batch, nent, entity_order != nullptr);
-  return FUS_OK;
-}
-
-int fus_plan_chain(void* workspace, int N, int entities_per_batch, int64_t nent, int max_chain, int min_carry, void* stream,
-                   int64_t* nchain_out) {
-  if (!workspace || max_chain < 1 || min_carry < 1) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(workspace, N, entities_per_batch, nent, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  int64_t nchain = 0;
-  if (nent > 0) {
-    const hipError_t e = fus::launch_plan_chain(workspace, N, entities_per_batch, nent, max_chain, min_carry, static_cast<hipStream_t>(stream), &nchain);
-    if (e != hipSuccess) return hip_rc(e);
-  }
-  {
-    std::lock_guard<std::mutex> lk(g_plans_mu);
-    g_plans[workspace].nchain = max_chain > 1 ? nchain : 0;
-  }
-  if (nchain_out) *nchain_out = nchain;
   return FUS_OK;
 }
 

@@ -32,17 +32,6 @@
 //                                   declared): its partial sum is finished with a plain load + store instead of an atomic --
 //                                   the float-atomic request rate of the chip (~20 G 64-byte requests/s), not HBM, bounds
 //                                   the low-intensity kernels (mass: 92 % of that rate, profiles/r03_mass_counters.json)
-//   cnum   int32 [nbatch]           optional (fus_plan_build_chained): number of CARRIED dofs of batch b -- distinct dofs it shares with
-//                                   batch b + 1 of the same chain (0: b ends its chain)
-//   cpair  uint16[nbatch][2*kPlanMaxCarry]  ... as (slot in b, slot in b + 1) pairs
-//   cmask  uint32[nbatch][ceil(CPB*Nd/32)]  bit s = slot s of batch b is carried out: NOT flushed by b
-//   chain  int32 [nbatch + 1]       first batch of every chain (nchain + 1 entries used).  A chained launch runs one workgroup per
-//                                   CHAIN: it walks the chain's batches in order and hands the partial sums of the carried dofs
-//                                   from batch to batch inside the workgroup, so that they are flushed with a global atomic ONCE, by
-//                                   the last batch that touches them.  What it buys: with a cell order that makes consecutive batches
-//                                   sideways neighbours (plan_tiles.chain_order) a batch of ten P = 4 cells carries 205 of its 1 029
-//                                   dofs = 5 of its 25 runs -- 20 % fewer 64-byte atomic requests, the unit that bounds the kernels
-//                                   without a G stream (profiles/r05e_geom_atomic_requests_rows_vs_strips.json)
 // Nd = (P+1)^3; the last batch may be ragged (cells >= ncell are never touched).
 #pragma once
 
@@ -134,7 +123,6 @@ inline LaunchSignal take_launch_signal_of(const uint64_t* flag, hipStream_t* str
 constexpr int64_t kPlanMagic = 0x46555350314c414eLL;  // "FUSP1LAN"
 constexpr int kPlanMaxRuns = 128;                      // runs of a batch: one per thread of (at least) two waves
 constexpr int kPlanHeaderBytes = 256;
-constexpr int kPlanMaxCarry = 256;                     // carried dofs per batch: one per thread of a workgroup
 
 __host__ __device__ constexpr int next_pow2(int v) {
   int p = 1;
@@ -158,10 +146,6 @@ struct PlanView {
   int32_t* order;
   uint32_t* excl;
   int64_t excl_words;  // per batch
-  int32_t* cnum;
-  uint16_t* cpair;
-  uint32_t* cmask;
-  int32_t* chain;
   int64_t bytes;
 };
 
@@ -185,14 +169,6 @@ inline PlanView plan_view_generic(void* workspace, int N, int epb, int64_t nent)
   v.excl = reinterpret_cast<uint32_t*>(base + off);
   v.excl_words = (v.entries + 31) / 32;
   off += align256(v.nbatch * v.excl_words * (int64_t)sizeof(uint32_t));
-  v.cnum = reinterpret_cast<int32_t*>(base + off);
-  off += align256(v.nbatch * (int64_t)sizeof(int32_t));
-  v.cpair = reinterpret_cast<uint16_t*>(base + off);
-  off += align256(v.nbatch * (int64_t)(2 * kPlanMaxCarry) * (int64_t)sizeof(uint16_t));
-  v.cmask = reinterpret_cast<uint32_t*>(base + off);
-  off += align256(v.nbatch * v.excl_words * (int64_t)sizeof(uint32_t));
-  v.chain = reinterpret_cast<int32_t*>(base + off);
-  off += align256((v.nbatch + 1) * (int64_t)sizeof(int32_t));
   v.bytes = off;
   return v;
 }
@@ -404,123 +380,6 @@ inline hipError_t launch_plan_mark_exclusive(void* workspace, int N, int epb, in
   hipLaunchKernelGGL(plan_mark_exclusive_kernel, dim3((unsigned)v.nbatch), dim3(256), 0, stream, v.nu, v.udofs, v.entries, use, ndofs,
                      v.excl, v.excl_words);
   return hipGetLastError();
-}
-
-// ---- chained plans (optional third pass over a built plan) ---------------------------------------------------------------
-// One workgroup per batch b < nbatch - 1: the distinct dofs b shares with b + 1 (both lists are sorted), as (slot in b, slot in
-// b + 1) pairs in ascending slot order, at most kPlanMaxCarry of them.
-template <int M2>
-__global__ void __launch_bounds__(256)
-    plan_carry_kernel(const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs, int64_t entries, int32_t* __restrict__ cnum_raw,
-                      uint16_t* __restrict__ cpair) {
-  constexpr int CH = M2 / 256;
-  __shared__ int32_t nxt[M2];
-  __shared__ int cnt[256];
-  const int tid = threadIdx.x;
-  const int64_t b = blockIdx.x;
-  const int nu_b = nu[b] & 0xffff, nu_n = nu[b + 1] & 0xffff;
-  const int32_t* ud = udofs + b * entries;
-  const int32_t* un = udofs + (b + 1) * entries;
-  for (int i = tid; i < nu_n; i += 256) nxt[i] = un[i];
-  __syncthreads();
-  int pos[CH];
-  int local = 0;
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int s = tid * CH + c;
-    pos[c] = -1;
-    if (s < nu_b) {
-      const int32_t d = ud[s];
-      int lo = 0, hi = nu_n;  // first index with nxt[i] >= d
-      while (lo < hi) {
-        const int mid = (lo + hi) >> 1;
-        if (nxt[mid] < d) lo = mid + 1;
-        else hi = mid;
-      }
-      if (lo < nu_n && nxt[lo] == d) {
-        pos[c] = lo;
-        ++local;
-      }
-    }
-  }
-  cnt[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {
-    const int v = (tid >= off) ? cnt[tid - off] : 0;
-    __syncthreads();
-    cnt[tid] += v;
-    __syncthreads();
-  }
-  int k = cnt[tid] - local;
-  uint16_t* cp = cpair + b * (int64_t)(2 * kPlanMaxCarry);
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    if (pos[c] >= 0) {
-      if (k < kPlanMaxCarry) {
-        cp[2 * k] = (uint16_t)(tid * CH + c);
-        cp[2 * k + 1] = (uint16_t)pos[c];
-      }
-      ++k;
-    }
-  }
-  if (tid == 255) cnum_raw[b] = cnt[255] < kPlanMaxCarry ? cnt[255] : kPlanMaxCarry;
-}
-// cmask[b]: bit s set for the slots batch b carries out (the first cnum[b] pairs)
-__global__ void __launch_bounds__(256)
-    plan_cmask_kernel(const int32_t* __restrict__ cnum, const uint16_t* __restrict__ cpair, uint32_t* __restrict__ cmask, int64_t words) {
-  const int64_t b = blockIdx.x;
-  uint32_t* m = cmask + b * words;
-  for (int64_t w = threadIdx.x; w < words; w += 256) m[w] = 0u;
-  __syncthreads();
-  const int nc = cnum[b];
-  const uint16_t* cp = cpair + b * (int64_t)(2 * kPlanMaxCarry);
-  for (int k = threadIdx.x; k < nc; k += 256) {
-    const int s = cp[2 * k];
-    atomicOr(&m[s >> 5], 1u << (s & 31));
-  }
-}
-// Third pass over a built plan: carry tables between consecutive batches, chains of at most ``max_chain`` batches (a chain also ends
-// where two consecutive batches share fewer than ``min_carry`` dofs).  Returns the number of chains in *nchain.  Synchronises.
-inline hipError_t launch_plan_chain(void* workspace, int N, int epb, int64_t nent, int max_chain, int min_carry, hipStream_t stream,
-                                    int64_t* nchain) {
-  PlanView v = plan_view_generic(workspace, N, epb, nent);
-  *nchain = v.nbatch;
-  if (v.nbatch <= 0) return hipSuccess;
-  const int M = epb * N;
-  std::vector<int32_t> cnum((size_t)v.nbatch, 0), chain;
-  if (v.nbatch > 1) {
-    const dim3 grid((unsigned)(v.nbatch - 1)), block(256);
-    if (M <= 256) hipLaunchKernelGGL((plan_carry_kernel<256>), grid, block, 0, stream, v.nu, v.udofs, v.entries, v.cnum, v.cpair);
-    else if (M <= 512) hipLaunchKernelGGL((plan_carry_kernel<512>), grid, block, 0, stream, v.nu, v.udofs, v.entries, v.cnum, v.cpair);
-    else if (M <= 1024) hipLaunchKernelGGL((plan_carry_kernel<1024>), grid, block, 0, stream, v.nu, v.udofs, v.entries, v.cnum, v.cpair);
-    else if (M <= 2048) hipLaunchKernelGGL((plan_carry_kernel<2048>), grid, block, 0, stream, v.nu, v.udofs, v.entries, v.cnum, v.cpair);
-    else hipLaunchKernelGGL((plan_carry_kernel<4096>), grid, block, 0, stream, v.nu, v.udofs, v.entries, v.cnum, v.cpair);
-    hipError_t e = hipGetLastError();
-    if (e == hipSuccess) e = hipMemcpyAsync(cnum.data(), v.cnum, (size_t)(v.nbatch - 1) * sizeof(int32_t), hipMemcpyDeviceToHost, stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(stream);
-    if (e != hipSuccess) return e;
-  }
-  chain.push_back(0);
-  int len = 1;
-  for (int64_t b = 0; b + 1 < v.nbatch; ++b) {
-    if (cnum[(size_t)b] >= min_carry && len < max_chain) {
-      ++len;
-    } else {
-      cnum[(size_t)b] = 0;
-      chain.push_back((int32_t)(b + 1));
-      len = 1;
-    }
-  }
-  cnum[(size_t)v.nbatch - 1] = 0;
-  *nchain = (int64_t)chain.size();
-  chain.push_back((int32_t)v.nbatch);
-  hipError_t e = hipMemcpyAsync(v.cnum, cnum.data(), (size_t)v.nbatch * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-  if (e == hipSuccess) e = hipMemcpyAsync(v.chain, chain.data(), chain.size() * sizeof(int32_t), hipMemcpyHostToDevice, stream);
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(plan_cmask_kernel, dim3((unsigned)v.nbatch), dim3(256), 0, stream, v.cnum, v.cpair, v.cmask, v.excl_words);
-  e = hipGetLastError();
-  if (e == hipSuccess) e = hipStreamSynchronize(stream);  // the host vectors above must outlive the copies
-  return e;
 }
 
 // Distinct dofs owned by this thread (slots tid, tid + BLOCK, ...), for both plan encodings.

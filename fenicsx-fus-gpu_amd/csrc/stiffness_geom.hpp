@@ -125,36 +125,23 @@ __device__ __forceinline__ void stage_vertex_coords(const T* __restrict__ x_g, c
   }
 }
 
-// Chained launch (plan.hpp, fus_plan_build_chained): one workgroup per CHAIN of consecutive batches; the partial sums of the dofs
-// batch b shares with batch b + 1 stay in the workgroup (LDS) instead of being flushed by both with global atomics.
-struct PlanChain {
-  const int32_t* chain;   // first batch of every chain
-  const int32_t* cnum;    // carried dofs of batch b (0: b ends its chain)
-  const uint16_t* cpair;  // (slot in b, slot in b + 1) pairs
-  const uint32_t* cmask;  // slots b does not flush
-  int words;              // mask words per batch
-};
-
 // PREG: form the n x 6 factors of the column BEFORE the contraction phases (between the two barriers
 // of the gather, while the u values are not yet in registers): the main loop then has the register
 // profile of the general kernel (P = 4 fp64: 4 workgroups per CU) and the geometry arithmetic runs in
 // the shadow of the gather.  Without it the factors are formed plane by plane inside the loop (fewest
 // registers: the build for P >= 6).
-// CHAIN: the workgroup walks over the batches of its chain (PlanChain above); CHAIN = false compiles to the single-batch kernel.
-template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, bool PREG, bool CHAIN = false>
+template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, bool PREG>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_geom_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                                const T* __restrict__ x_g, const int32_t* __restrict__ x_dofs,
                                const T* __restrict__ pts, const T* __restrict__ wts,
                                const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs,
                                const uint16_t* __restrict__ slot, const T* __restrict__ dphi, int64_t ncell,
-                               const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig, PlanChain pc) {
+                               const int32_t* __restrict__ order, const int32_t* __restrict__ runs, LaunchSignal sig) {
   using Sh = PlanShape<T, P, CPB, PADLDS>;
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
   launch_signal_publish(sig);
   constexpr int VPT = (CPB * 24 + BLOCK - 1) / BLOCK;  // vertex coordinates staged per thread (1 for P >= 4)
-  constexpr int KC = kPlanMaxCarry < BLOCK ? kPlanMaxCarry : BLOCK;  // carried dofs handled: one per thread
-  constexpr int MW = (M + 31) / 32;
 
   __shared__ T sD[n2];
   __shared__ T sP[n], sW[n];
@@ -163,44 +150,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
   __shared__ PlanAcc sacc[PlanOwnAcc<T, ALIAS>::value ? M : 1];
-  __shared__ PlanAcc scarry[CHAIN ? KC : 1];     // partial sums handed to the next batch of the chain
-  __shared__ uint16_t sc_in[CHAIN ? KC : 1];     // their slots in the current batch
-  __shared__ uint16_t sc_out[CHAIN ? KC : 1];    // slots of the current batch handed on
-  __shared__ uint32_t smask[CHAIN ? MW : 1];     // slots the current batch does not flush
   T* const sx = ALIAS ? sfy : reinterpret_cast<T*>(sacc);  // x values of the batch's distinct dofs
   PlanAcc* const sy = PlanOwnAcc<T, ALIAS>::value ? sacc : reinterpret_cast<PlanAcc*>(su);  // their y partial sums
 
-  if (threadIdx.x < n2) sD[threadIdx.x] = dphi[threadIdx.x];
-  if (threadIdx.x < n) {
-    sP[threadIdx.x] = pts[threadIdx.x];
-    sW[threadIdx.x] = wts[threadIdx.x];
-  }
-
-  int64_t b_first = blockIdx.x, b_last = (int64_t)blockIdx.x + 1;  // CHAIN = false: exactly one iteration, provably
-  if constexpr (CHAIN) {
-    b_first = pc.chain[blockIdx.x];
-    b_last = pc.chain[blockIdx.x + 1];
-  }
-  int cin = 0;  // carried dofs coming in from the previous batch of the chain (block-uniform)
-#pragma clang loop unroll(disable)
-  for (int64_t batch = b_first; batch < b_last; ++batch) {
-  // The derivative table and the GLL points / weights are read with scalar loads at compile-time offsets where they are used.  In a
-  // loop the compiler would hoist all of them out of it (loop-invariant loads: ~70 SGPRs that spill into 80 VGPRs and halve the
-  // occupancy).  An offset that is zero at run time but that the compiler cannot prove loop-invariant (batch < 2^31) keeps the loads
-  // scalar AND where they are.
-  const int64_t never = CHAIN ? (batch >> 40) : 0;
-  // (the thread's own indices too: every address derived from them would otherwise be precomputed before the loop and kept in
-  // registers across it -- 40 VGPRs at P = 4)
-  const int tid = (int)threadIdx.x + (int)never;
+  const int tid = threadIdx.x;
+  const unsigned batch = blockIdx.x;
   const int lc = tid / n2;
   const int t = tid - lc * n2;
   const int ty = t / n, tz = t - ty * n;
-  const T* dphi_l = dphi + never;
-  const T* pts_l = pts + never;
-  const T* wts_l = wts + never;
-  const T* sD_l = sD + never;  // (the same for the LDS copies of the tables: loop-invariant LDS loads would be hoisted too)
-  const T* sP_l = sP + never;
-  const T* sW_l = sW + never;
   const int64_t cell0 = (int64_t)batch * CPB;
   const int64_t pos = cell0 + lc;  // position in the plan's cell order
   const bool active = (lc < CPB) && (pos < ncell);
@@ -209,6 +166,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
   const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
+
+  if (tid < n2) sD[tid] = dphi[tid];
+  if (tid < n) {
+    sP[tid] = pts[tid];
+    sW[tid] = wts[tid];
+  }
 
   int32_t mydof[SPT];
   const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
@@ -221,14 +184,6 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
     coeff = cell_constants[cell];
-  }
-  int cout = 0;
-  if constexpr (CHAIN) {  // the tables of this batch, into LDS (read after the barriers below)
-    cout = pc.cnum[batch];
-    cout = cout < KC ? cout : KC;
-    if (tid < cout) sc_out[tid] = pc.cpair[(int64_t)batch * (2 * kPlanMaxCarry) + 2 * tid];
-    if (tid < cin) sc_in[tid] = pc.cpair[(int64_t)(batch - 1) * (2 * kPlanMaxCarry) + 2 * tid + 1];
-    for (int w = tid; w < MW; w += BLOCK) smask[w] = pc.cmask[(int64_t)batch * pc.words + w];
   }
   batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
   stage_vertex_coords<T, VPT, BLOCK, CPB>(x_g, vid, tid, sX);
@@ -250,11 +205,11 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   T s0 = T(0);
   T g[PREG ? n : 1][6];
   if (active) {
-    column_jacobian_rows<T>(sX + lc * 24, sP_l[ty], sP_l[tz], J0, Ja, Jba, Jc, Jdc);
-    s0 = coeff * sW_l[ty] * sW_l[tz];
+    column_jacobian_rows<T>(sX + lc * 24, sP[ty], sP[tz], J0, Ja, Jba, Jc, Jdc);
+    s0 = coeff * sW[ty] * sW[tz];
     if constexpr (PREG) {
 #pragma unroll
-      for (int qx = 0; qx < n; ++qx) column_g_at<T>(pts_l[qx], wts_l[qx] * s0, J0, Ja, Jba, Jc, Jdc, g[qx]);
+      for (int qx = 0; qx < n; ++qx) column_g_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, g[qx]);
     }
   }
 
@@ -275,8 +230,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     T dy[n], dz[n];
 #pragma unroll
     for (int i = 0; i < n; ++i) {
-      dy[i] = sD_l[ty * n + i];
-      dz[i] = sD_l[tz * n + i];
+      dy[i] = sD[ty * n + i];
+      dz[i] = sD[tz * n + i];
     }
     const T* cu_y = su + lc * S + tz;
     const T* cu_z = su + lc * S + ty * n;
@@ -285,9 +240,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 #pragma unroll
     for (int qx = 0; qx < n; ++qx) {
       T vx, vy, vz;
-      plan_grad_at<T, n, n2>(qx, dphi_l, u, dy, dz, cu_y, cu_z, vx, vy, vz);
+      plan_grad_at<T, n, n2>(qx, dphi, u, dy, dz, cu_y, cu_z, vx, vy, vz);
       T gl[6];
-      if constexpr (!PREG) column_g_at<T>(pts_l[qx], wts_l[qx] * s0, J0, Ja, Jba, Jc, Jdc, gl);  // compile-time index: scalar loads
+      if constexpr (!PREG) column_g_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, gl);  // compile-time index: scalar loads
       const T* gq = PREG ? g[PREG ? qx : 0] : gl;
       fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
       cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
@@ -299,55 +254,23 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     plan_zero<T, SPT, BLOCK>(sy, nu_b, tid);
     __syncthreads();
   }
-  if constexpr (CHAIN) {  // the previous batch's share of the carried dofs joins this batch's sums (LDS atomics commute)
-    if (tid < cin) lds_atomic_add(&sy[sc_in[tid]], scarry[tid]);
-  }
 
-  plan_backward<T, n, n2>(dphi_l, sD_l, ty, tz, active, fx, sfy + lc * S + tz, sfz + lc * S + ty * n, sl, sy);
-  if constexpr (CHAIN) {
-    if (tid < cout) scarry[tid] = sy[sc_out[tid]];  // handed on instead of flushed
-#pragma unroll
-    for (int r = 0; r < SPT; ++r) {
-      const int s = tid + r * BLOCK;
-      if (s < nu_b && !((smask[s >> 5] >> (s & 31)) & 1u)) unsafeAtomicAdd(y + mydof[r], (T)sy[s]);
-    }
-    cin = cout;
-    __syncthreads();  // the sums have been read: the next batch of the chain re-uses every LDS region
-  } else {
-    plan_flush<T, SPT, BLOCK>(y, mydof, nu_b, tid, sy);
-  }
-  }  // batches of the chain
+  plan_backward<T, n, n2>(dphi, sD, ty, tz, active, fx, sfy + lc * S + tz, sfz + lc * S + ty * n, sl, sy);
+  plan_flush<T, SPT, BLOCK>(y, mydof, nu_b, tid, sy);
 }
 
 // CPB: cells per batch = the plan's entities per batch (default: the plan builder's own choice, ~256 threads per workgroup).
-// ``nchain`` > 0: the plan is chained (plan.hpp): one workgroup per chain.
 template <typename T, int P, bool ALIAS, bool PADLDS, int MINW, bool PREG, int CPB = plan_cells_per_batch<P>()>
 inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs,
                                              const T* pts, const T* wts, const void* workspace, const T* dphi,
-                                             int64_t ncell, hipStream_t stream, bool ordered = false, bool use_runs = false,
-                                             int64_t nchain = 0) {
+                                             int64_t ncell, hipStream_t stream, bool ordered = false, bool use_runs = false) {
   if (ncell <= 0) return hipSuccess;
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   const LaunchSignal sig = take_launch_signal(stream);
-  if (nchain > 0) {
-    const PlanChain pc{v.chain, v.cnum, v.cpair, v.cmask, (int)v.excl_words};
-    // the walk over the batches is a loop: kernel arguments and thread-invariant addresses stay live across it and the register count
-    // rises (P = 4 fp64: 163 VGPRs where the single-batch build has 128); the occupancy of the single-batch build is asked for
-    // explicitly, at the price of a few spilled values (108 bytes per lane at P = 4)
-#ifdef FUS_CHAIN_NO_HINT
-    constexpr int CHAIN_MINW = MINW;
-#else
-    constexpr int CHAIN_MINW = sizeof(T) == 8 ? (P == 4 ? 4 : (P == 5 || P == 6 ? 3 : MINW)) : MINW;
-#endif
-    hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, CHAIN_MINW, PREG, true>), dim3((unsigned)nchain),
-                       dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
-                       ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig, pc);
-  } else {
-    hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG, false>), dim3((unsigned)v.nbatch),
-                       dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
-                       ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig, PlanChain{nullptr, nullptr, nullptr, nullptr, 0});
-  }
+  hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG>), dim3((unsigned)v.nbatch),
+                     dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
+                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig);
   return settle_launch_signal(stream, sig, hipGetLastError());
 }
 

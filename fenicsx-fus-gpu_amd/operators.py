@@ -64,18 +64,6 @@ def use_strip_order(flag: bool):
     _STRIP_ORDER = bool(flag)
 
 
-# CHAINED plans for the scatter-bound kernels (csrc/plan.hpp fus_plan_chain, plan_tiles.chain_order): one workgroup walks over up to
-# _CHAIN_LEN consecutive batches that are sideways neighbours and keeps the partial sums of the face they share in the workgroup
-# instead of flushing it twice.  FUS_PLAN_CHAIN=<max batches per chain> (0 / 1: off) / use_plan_chain(n).
-_CHAIN_LEN = int(os.environ.get("FUS_PLAN_CHAIN", "0") or 0)
-_CHAIN_MIN_CARRY = 32
-
-
-def use_plan_chain(max_batches: int):
-    global _CHAIN_LEN
-    _CHAIN_LEN = int(max_batches)
-
-
 
 def use_locality_order(flag: bool):
     global _LOCALITY_ORDER
@@ -91,7 +79,6 @@ class _PlanCache:
         self._plans = {}
         self.capacity = capacity
         self.last_order = None  # cell order of the plan built last (None: natural order)
-        self.last_chains = None  # workgroups (chains) of the chained plan built last
         self._recording = None  # while a hipGraph is captured: every (workspace, dofmap) handed out
 
     def start_recording(self):
@@ -114,14 +101,11 @@ class _PlanCache:
         (default: nothing -- the launch runs alone or only next to launches of the same stream)."""
         lib = _lib.load()
         nent, N = dofmap.shape
-        chain = _CHAIN_LEN if (bool(strips) and (_CHAIN_LEN > 1 or _CHAIN_LEN == -1) and exclusive_ndofs is None) else 0  # -1: the chain ORDER alone
-        strips = bool(strips) and _STRIP_ORDER and exclusive_ndofs is None and not chain
+        strips = bool(strips) and _STRIP_ORDER and exclusive_ndofs is None
         key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index,
                None if exclusive_ndofs is None else (int(exclusive_ndofs), None if external_use is None else (external_use.data_ptr(), external_use._version)))
         if strips:
             key = key + ("strips",)
-        if chain:
-            key = key + (f"chain{chain}", "strips")  # (a scatter-bound kernel's plan, like the strip-ordered one: ``has`` finds it)
         hit = self._plans.get(key)
         if hit is None:
             epb = lib.fus_plan_entities_per_batch(N)
@@ -168,25 +152,6 @@ class _PlanCache:
                         if distinct_dofs(ws2) < 0.97 * distinct_dofs(ws):
                             ws, ws2, self.last_order = ws2, ws, order
                         lib.fus_plan_release(ws2.data_ptr())
-            if chain and nent > 4 * epb:
-                n = int(round(N ** (1.0 / 3.0)))
-                if n >= 3 and n**3 == N:
-                    import ctypes as C
-
-                    from . import plan_tiles
-
-                    faces = torch.from_numpy(plan_tiles.face_interior_local_dofs(n)).to(dofmap.device)
-                    cand = plan_tiles.chain_order(dofmap[:, faces].cpu().numpy(), epb,
-                                                  None if self.last_order is None else self.last_order.cpu().numpy())
-                    if cand is not None:  # consecutive batches are sideways neighbours: link them
-                        order = torch.from_numpy(cand.astype("int32")).to(dofmap.device)
-                        lib.fus_plan_release(ws.data_ptr())
-                        ws = build(order)
-                        self.last_order = order
-                        nchain = C.c_int64(0)
-                        _lib.check(lib.fus_plan_chain(ws.data_ptr(), N, epb, nent, max(1, int(chain)), _CHAIN_MIN_CARRY, _lib.stream_ptr(), C.byref(nchain)),
-                                   "fus_plan_chain")
-                        self.last_chains = int(nchain.value)
             if exclusive_ndofs is not None:
                 use = (external_use.to(torch.int32).clone() if external_use is not None
                        else torch.zeros(int(exclusive_ndofs), dtype=torch.int32, device=dofmap.device))

@@ -145,104 +145,3 @@ def two_row_strip_order(dofmap_faces: np.ndarray, seq=None, min_row=2):
         done[r] = True
     assert w == nc
     return out
-
-
-def _rows_of(nbr, seq):
-    """Maximal runs of consecutive cells of ``seq`` that are face neighbours through opposite faces: (starts, lens, axis of each row)."""
-    nc = seq.size
-    cur, nxt = seq[:-1], seq[1:]
-    hit = nbr[cur] == nxt[:, None]
-    has_out = hit.any(axis=1)
-    out_face = np.where(has_out, hit.argmax(axis=1), -1)
-    back = nbr[nxt] == cur[:, None]
-    in_face = np.where(back.any(axis=1), back.argmax(axis=1), -1)
-    entered = np.full(nc, -1, dtype=np.int64)
-    entered[1:] = in_face
-    link = has_out & ((entered[:-1] < 0) | (out_face == (entered[:-1] ^ 1)))
-    starts = np.concatenate(([0], np.nonzero(~link)[0] + 1))
-    lens = np.diff(np.concatenate((starts, [nc])))
-    axis = np.full(starts.size, -1, dtype=np.int64)
-    multi = lens > 1
-    axis[multi] = out_face[starts[multi]] >> 1
-    return starts, lens, axis
-
-
-def chain_order(dofmap_faces: np.ndarray, cpb: int, seq=None, min_row=2):
-    """Candidate cell order for CHAINED plans (csrc/plan.hpp ``fus_plan_build_chained``), or ``None``.
-
-    A chained plan lets one workgroup walk over several consecutive batches and keep the partial sums of the dofs two consecutive
-    batches share in the workgroup instead of flushing them twice with global atomics.  That pays when consecutive batches share a
-    whole FACE of the batch: rows of cells are stacked sideways (row k + 1 is the lateral face neighbour of row k, cell by cell) and
-    the order walks, for every block of ``cpb`` cells along the rows, through the stack:
-
-        stack of rows r0, r1, r2, ...:   r0[0:cpb] r1[0:cpb] r2[0:cpb] ... | r0[cpb:2cpb] r1[cpb:2cpb] ...
-
-    so that batch k + 1 is the sideways neighbour of batch k (P = 4, ten cells in a row: 205 of their 1 029 distinct dofs, 5 of
-    their 25 runs of consecutive dofs).  Same inputs as ``two_row_strip_order``; works on any mesh whose cell order has rows."""
-    nc = dofmap_faces.shape[0]
-    if nc < 4 * cpb:
-        return None
-    nbr = face_neighbours(np.asarray(dofmap_faces))
-    seq = np.arange(nc, dtype=np.int64) if seq is None else np.asarray(seq, dtype=np.int64)
-    starts, lens, axis = _rows_of(nbr, seq)
-    nrows = starts.size
-    if nrows > nc // max(2, min_row) or lens.max() < min_row:
-        return None
-    pos_of_cell = np.empty(nc, dtype=np.int64)
-    pos_of_cell[seq] = np.arange(nc)
-    row_of = np.repeat(np.arange(nrows), lens)
-
-    def lateral_row(r, face):
-        """Row across lateral face ``face`` of row r's first cell, if it is a whole-row neighbour (same length, cell by cell)."""
-        q = nbr[seq[starts[r]], face]
-        if q < 0:
-            return -1
-        pq = pos_of_cell[q]
-        rq = row_of[pq]
-        if rq == r or lens[rq] != lens[r] or starts[rq] != pq:
-            return -1
-        a = seq[starts[r]: starts[r] + lens[r]]
-        b = seq[starts[rq]: starts[rq] + lens[rq]]
-        return rq if bool((nbr[a] == b[:, None]).any(axis=1).all()) else -1
-
-    used = np.zeros(nrows, dtype=bool)
-    out = np.empty(nc, dtype=np.int64)
-    w = 0
-    stacked = 0
-    for r0 in range(nrows):
-        if used[r0]:
-            continue
-        stack = [r0]
-        used[r0] = True
-        if lens[r0] >= min_row and axis[r0] >= 0:
-            # first step: the lateral face whose row comes first in the order; then straight on through the opposite faces
-            best, best_face = -1, -1
-            for f in range(6):
-                if (f >> 1) == axis[r0]:
-                    continue
-                rq = lateral_row(r0, f)
-                if rq >= 0 and not used[rq] and (best < 0 or starts[rq] < starts[best]):
-                    best, best_face = rq, f
-            cur, face = best, best_face
-            while cur >= 0 and not used[cur]:
-                stack.append(cur)
-                used[cur] = True
-                # leave ``cur`` through the face opposite to the one facing the previous row
-                prev_first = seq[starts[stack[-2]]]
-                back = np.nonzero(nbr[seq[starts[cur]]] == prev_first)[0]
-                if back.size == 0:
-                    break
-                face = int(back[0]) ^ 1
-                cur = lateral_row(cur, face)
-        if len(stack) > 1:
-            stacked += len(stack)
-        L = int(lens[r0])
-        for z0 in range(0, L, cpb):
-            for r in stack:
-                seg = seq[starts[r] + z0: starts[r] + min(z0 + cpb, L)]
-                out[w: w + seg.size] = seg
-                w += seg.size
-    assert w == nc
-    if stacked * 2 < nrows:  # most rows found no sideways neighbour: nothing to chain
-        return None
-    return out

@@ -53,7 +53,7 @@ extern "C" {
  *      enforce their one-caller-stream contract (FUS_ERR_INVALID_ARGUMENT); new: fus_comm_fork_lazy, fus_comm_arm_join,
  *      fus_comm_health; the PEER blob identifies the exporting process by a random token and its device by PCI bus id.
  *      Added since without a bump (new symbols only): fus_mass_gather_plan_bytes / _build / _info, fus_mass_apply_gather_*,
- *      fus_mass_gather_plan_build_rows, fus_mass_gather_static_bytes / _build_* , fus_mass_apply_gather_static_*, fus_plan_chain.
+ *      fus_mass_gather_plan_build_rows, fus_mass_gather_static_bytes / _build_* , fus_mass_apply_gather_static_*.
  * There are deliberately NO fus_cpu_* twins of the entry points (SURVEY.md 8b proposed them): a CPU path inside the
  * product would be a silent fallback; the CPU restatement of the reference is test infrastructure and lives outside the product tree.
  */
@@ -203,18 +203,6 @@ int fus_plan_build(const int32_t* entity_dofmap, int ndof_per_entity, int entiti
 int fus_plan_build_ordered(const int32_t* entity_dofmap, const int32_t* entity_order, int ndof_per_entity,
                            int entities_per_batch, int64_t nent, void* workspace, int64_t workspace_bytes,
                            void* stream);
-/*
- * CHAINS (optional third pass over a built plan; no reference counterpart): consecutive batches of the plan's cell order that share at
- * least min_carry distinct dofs are linked into chains of at most max_chain batches.  A kernel that supports chained plans
- * (fus_stiffness_apply_planned_geom_*) then runs ONE workgroup per chain: it walks the chain's batches in order and keeps the
- * partial sums of the shared dofs in the workgroup instead of flushing them from both batches with global float atomics -- the
- * 64-byte atomic request is the unit that bounds the kernels without a G stream.  It pays with a cell order in which consecutive
- * batches are sideways neighbours (plan_tiles.chain_order through fus_plan_build_ordered: ten P = 4 cells in a row share 205 of
- * their 1 029 dofs with the row beside them).  max_chain = 1 un-chains the plan.  *nchain_out: chains formed.  Synchronises the stream.
- */
-int fus_plan_chain(void* workspace, int ndof_per_entity, int entities_per_batch, int64_t nent, int max_chain, int min_carry,
-                   void* stream, int64_t* nchain_out);
-
 /*
  * Optional second pass over a BUILT plan: mark the dofs that exactly one batch of the plan touches.  The planned mass apply
  * then finishes the sums of marked dofs with a plain load + store instead of a memory-side float atomic (the low-intensity

@@ -8,7 +8,7 @@ REPO=${GRAFT_REPO_ROOT:-$(pwd)}
 OUT=$REPO/gpurun_out/prof_$TAG
 mkdir -p $OUT
 cd /tmp && export TMPDIR=/tmp
-ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-aux $@"
+ARGS="--steps 20 --warmup 3 --no-cpu-baseline --no-aux --no-check $@"
 rocprofv3 --kernel-trace --stats --output-format csv -d $OUT/trace -o trace -- python3 $REPO/bench.py $ARGS > $OUT/bench_trace.json 2> $OUT/bench_trace.err || exit 1
 rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d $OUT/pmc_fetch -o fetch -- python3 $REPO/bench.py $ARGS > $OUT/bench_fetch.json 2> $OUT/bench_fetch.err || exit 2
 rocprofv3 --pmc WRITE_SIZE --kernel-trace --output-format csv -d $OUT/pmc_write -o write -- python3 $REPO/bench.py $ARGS > $OUT/bench_write.json 2> $OUT/bench_write.err || exit 3
