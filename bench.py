@@ -342,7 +342,10 @@ TRANSPORT_TEXT = {
 def transport_candidates(args):
     """Transports this run may use, in order of preference; the first one that comes up on EVERY rank and passes the
     run's own halo check is used (decided collectively, recorded in the line)."""
-    return {"peer": ["peer", "native", "torch"], "native": ["native", "torch"], "torch": ["torch"]}[args.halo]
+    # "peer:finegrained": the PEER transport once more with its receive arenas in fine-grained instead of uncached device memory
+    # (FUS_IPC_MEMORY) -- export / open of UNCACHED memory between two different devices has never run on this pool (one GPU per box),
+    # and falling straight back to RCCL would cost 22 % per apply where another memory kind might cost nothing
+    return {"peer": ["peer", "peer:finegrained", "native", "torch"], "native": ["native", "torch"], "torch": ["torch"]}[args.halo]
 
 
 def make_comm(kind, scat, world, device):
@@ -840,6 +843,8 @@ def measure_sustained(step_fn, alg_bytes, total=2500, windows=10):
 def first_comm(args, scat, world, device):
     """(comm, kind) of the first candidate transport that comes up on every rank."""
     for kind in transport_candidates(args):
+        if ":" in kind:  # arena-memory variants of a transport are retried by the apply modes' own halo check, not here
+            continue
         comm, why = make_comm(kind, scat, world, device)
         if comm is not None:
             return comm, kind
@@ -934,18 +939,22 @@ def cpu_baseline_mass(P, mesh, x, cc, detJ, reps=5):
             "ms_per_apply": t * 1e3, "impl": "oracle/fus_oracle.c oracle_mass_apply_f64"}
 
 
-def oracle_apply(P, mesh, D, x, cc, geo, mass, ncells=None):
-    """One apply of the oracle (oracle/fus_oracle.c: numba-cpu/operators.py:71-227 / :19-68 restated) on this rank's cells,
-    all host cores: the checker of ``result_check``, never the thing measured."""
+def oracle_apply(P, mesh, D, x, cc, geo, mass, portable=False, threads=None):
+    """One apply of the oracle (oracle/fus_oracle.c: numba-cpu/operators.py:71-227 / :19-68 restated) on this rank's cells:
+    the checker of ``result_check``, never the thing measured.  ``portable``: the prebuilt x86-64-v3 library, nothing compiled
+    (N > 1: several ranks must not run the -march=native build into one file at the same time)."""
     from oracle import oracle_c
 
-    try:
-        oracle_c.build(native=True)
-        O = oracle_c.OracleLib(native=True)
-    except Exception as e:  # noqa: BLE001
-        log(f"native oracle build failed ({e}); using the portable build")
+    if portable:
         O = oracle_c.OracleLib()
-    threads = max(1, min(O.max_threads(), host_cores()))
+    else:
+        try:
+            oracle_c.build(native=True)
+            O = oracle_c.OracleLib(native=True)
+        except Exception as e:  # noqa: BLE001
+            log(f"native oracle build failed ({e}); using the portable build")
+            O = oracle_c.OracleLib()
+    threads = max(1, min(O.max_threads(), host_cores() if threads is None else threads))
     y = np.zeros(mesh.ndofs)
     if mass:
         O.mass_apply(x, cc, y, geo, mesh.dofmap)
@@ -1074,7 +1083,7 @@ def secondary_summary(out):
     line("rk4_geom", "rk4_step_in_kernel_geometry")
     line("westervelt", "westervelt_step")
     line("westervelt_geom", "westervelt_step_in_kernel_geometry")
-    line("westervelt_2g", "westervelt_step_two_gather")
+    line("westervelt_1g", "westervelt_step_single_gather")
     su = aux.get("sustained")
     if su:
         sec["sustained"] = {"ms": round(float(su["ms_per_apply"]), 4), "frac": r3(su["frac_of_hbm_roofline"])}
@@ -1140,7 +1149,7 @@ def rk4_step_bytes(P, T, ncells, ndofs, nfacets_source, nfacets_absorbing, mode,
             "bytes_per_step": 4 * (ncells * cell + facets) + touches * T * ndofs}
 
 
-def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, steps, warmup, comm=None, cpu_leg=False, two_gather=False):
+def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, steps, warmup, comm=None, cpu_leg=False, single_gather=False):
     """Full RK4 steps of the linear (BASELINE config 3: demo_linear_box, P = 4, ~10 M dofs per GPU) or Westervelt
     (config 5 shape) solver, fused stage kernels; returns the bench line as a dict."""
     import torch
@@ -1163,7 +1172,7 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
     dts, tf, nstep = ls.snap_time_step(h, P, 1500.0, 0.5e6, L * grid[0])  # the wave crosses the whole (partitioned) box
     if warmup + steps > nstep:
         raise SystemExit(f"--warmup + --steps = {warmup + steps} exceeds the {nstep} steps to the final time")
-    single_gather = False
+    want_single_gather, single_gather = bool(single_gather), False
     if mode == "westervelt":  # BASELINE config 5 shape: Westervelt, bowl-warped trilinear cells
         nls = fusgpu_loader.submodule("nonlinear_solver")
         Lx = L * grid[0]
@@ -1175,10 +1184,10 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
             return out
 
         mesh = boxmesh.BoxMesh(P, gcells, grid=grid, rank=rank, length=tuple(L * g for g in grid), dtype=dt_np, warp=bowl)
-        # two_gather: the cell pass a heterogeneous medium takes (c4 / c3 not uniform: u_n and v_n are gathered separately);
-        # forced here on the homogeneous test medium, the kernel does the same work either way
+        # default: the two-gather cell pass (what every medium takes since round 5; a heterogeneous one has no choice);
+        # single_gather: the form a uniform c4 / c3 allows (the vector pass writes w = u_n + kappa v_n, the cell pass is a plain apply)
         solver = nls.WesterveltSpectral3D(mesh, dt_np, speed_of_sound=1500.0, source_frequency=0.5e6, comm=comm, fused=True,
-                                          in_kernel_geometry=in_kernel_geometry, uniform_ratio=False if two_gather else "auto")
+                                          in_kernel_geometry=in_kernel_geometry, uniform_ratio=True if want_single_gather else "auto")
         solver.affine = False
         single_gather = solver.kappa is not None
     else:
@@ -1242,7 +1251,7 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
     if mode == "rk4" and perturbed and world == 1:
         traffic, traffic_source = rk4_step_traffic(P, mesh.ncells, args.dtype, geo_kernel)
     elif mode == "westervelt" and world == 1:
-        traffic, traffic_source = aux_traffic("westervelt_step" + ("" if single_gather else "_two_gather") + ("_in_kernel_geometry" if geo_kernel else ""),
+        traffic, traffic_source = aux_traffic("westervelt_step" + ("_in_kernel_geometry" if geo_kernel else "") + ("_single_gather" if single_gather else ""),
                                               P, mesh.ncells, args.dtype)
     else:
         traffic, traffic_source = None, "no PMC passes replayed for this configuration of the step"
@@ -1289,7 +1298,7 @@ def bench_rk4(args, rank, world, device):
     scat = fusgpu_loader.submodule("scatterer")
     comm = first_comm(args, scat, world, device)[0] if world > 1 else None
     out = measure_rk4(args, rank, world, device, args.mode, args.perturbed, args.in_kernel_geometry, args.steps, args.warmup, comm,
-                      cpu_leg=not args.no_cpu_baseline, two_gather=args.two_gather)
+                      cpu_leg=not args.no_cpu_baseline, single_gather=args.single_gather)
     if rank == 0:
         emit(out)
     if world > 1:
@@ -1327,8 +1336,8 @@ def main():
     ap.add_argument("--halo-compare", action="store_true",
                     help="N > 1: after the timed region, time the apply over EVERY transport that comes up (peer, native = RCCL) in alternating "
                          "rounds in this one process and put each one's exposed cost in config.halo_compare")
-    ap.add_argument("--two-gather", action="store_true",
-                    help="--mode westervelt: the cell pass a heterogeneous medium takes (u_n and v_n gathered separately), forced on the homogeneous test medium")
+    ap.add_argument("--single-gather", action="store_true",
+                    help="--mode westervelt: the single-gather cell pass (uniform c4 / c3: the vector pass writes w = u_n + kappa v_n) instead of the default two-gather pass")
     ap.add_argument("--mass-static", action="store_true",
                     help="--mode mass: mass_operator(N, T, static_detJ=True) -- detJ streamed from a row-ordered copy (opt-in: the caller promises a constant detJ)")
     ap.add_argument("--mass-atomic", action="store_true",
@@ -1519,8 +1528,16 @@ def main():
         scat = fusgpu_loader.submodule("scatterer")
         os.environ.setdefault("FUS_IPC_SPIN_SECONDS", "10")  # a transport that does not deliver fails its check in seconds
         first_contact = first_contact_report(rank, world, device)
+        ipc_memory_env = os.environ.get("FUS_IPC_MEMORY")
         for kind in transport_candidates(args):
-            comm, why = make_comm(kind, scat, world, device)
+            base, _, arena_kind = kind.partition(":")
+            if arena_kind:
+                os.environ["FUS_IPC_MEMORY"] = arena_kind
+            elif ipc_memory_env is None:
+                os.environ.pop("FUS_IPC_MEMORY", None)
+            else:
+                os.environ["FUS_IPC_MEMORY"] = ipc_memory_env
+            comm, why = make_comm(base, scat, world, device)
             if comm is None:
                 tried.append({"transport": kind, "result": f"did not come up: {why}"})
                 log(f"halo transport {kind!r} did not come up ({why}); trying the next one")
@@ -1537,18 +1554,18 @@ def main():
                 log(f"rank {rank}: halo transport {kind!r} failed during bring-up: {err}")
             arena = None
             try:
-                arena = halo.fwd.status().get("arena_memory") if (err is None and kind == "peer" and hasattr(halo.fwd, "status")) else None
+                arena = halo.fwd.status().get("arena_memory") if (err is None and base == "peer" and hasattr(halo.fwd, "status")) else None
             except Exception:  # noqa: BLE001
                 pass
             bring_up = gather_verdicts(rank, world, {"error": err, "arena_memory": arena})
             failed_ranks = [v["rank"] for v in bring_up if v["error"] is not None]
             entry = {"transport": kind, "bring_up_failed_on_ranks": failed_ranks,
-                     "arena_memory_by_rank": [v["arena_memory"] for v in bring_up] if kind == "peer" else None}
+                     "arena_memory_by_rank": [v["arena_memory"] for v in bring_up] if base == "peer" else None}
             if not failed_ranks:
                 verdict = check_halo()
                 per_rank = gather_verdicts(rank, world, {"forward_max_abs_err": verdict["forward_max_abs_err"], "device_wait_timeouts": int(halo.health())})
                 entry["check_failed_on_ranks"] = [v["rank"] for v in per_rank if v["forward_max_abs_err"] != 0.0 or v["device_wait_timeouts"] != 0]
-                if kind in os.environ.get("FUS_BENCH_TEST_REJECT", "").split(","):  # test hook: exercise the fall-back path
+                if base in os.environ.get("FUS_BENCH_TEST_REJECT", "").split(","):  # test hook: exercise the fall-back path
                     verdict = dict(verdict, ok=False, rejected_by="FUS_BENCH_TEST_REJECT")
             else:
                 entry["bring_up_errors"] = {v["rank"]: v["error"] for v in bring_up if v["error"] is not None}
@@ -1639,7 +1656,7 @@ def main():
         sched_ms = timed_launches(lambda: halo.apply_no_exchange(x_d, cc_d, y_d, G_d, dm_d))
         if args.halo_compare:
             try:
-                halo_compare = compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, transport, halo, kern_ms)
+                halo_compare = compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, transport.partition(":")[0], halo, kern_ms)
             except Exception as e:  # noqa: BLE001
                 log(f"rank {rank}: --halo-compare failed: {e!r}")
                 halo_compare = {"error": repr(e)}
@@ -1720,7 +1737,7 @@ def main():
             "halo_schedule": None if halo is None else halo.schedule_kind,
             "halo_lead_cells": None if halo is None else halo.lead_cells,
             "halo_check": halo_check,
-            "halo_transport": None if halo is None else TRANSPORT_TEXT[transport],
+            "halo_transport": None if halo is None else TRANSPORT_TEXT[transport.partition(":")[0]] + (f" [arenas in {transport.partition(':')[2]} memory]" if ":" in transport else ""),
             "halo_transports_tried": tried or None,
             "first_contact": first_contact,
             "halo_compare": halo_compare,
@@ -1819,11 +1836,11 @@ def main():
                 out["aux"][name] = None
         try:  # BASELINE config 5's step on one GPU: Westervelt, P = 6, 36^3 bowl-warped cells (10.2 M dofs), fused stage
             wargs = argparse.Namespace(**{**vars(args), "degree": 6, "cells": max(4, round(args.cells * 2 / 3))})  # 54 -> 36: the same dof count
-            # the reference's G stream | the solver's default | the default for a heterogeneous medium (two-gather cell pass)
-            for name, geo_k, two in (("westervelt_step", False, False), ("westervelt_step_in_kernel_geometry", True, False),
-                                     ("westervelt_step_two_gather", True, True)):
+            # the reference's G stream | the solver's default (in-kernel geometry, two-gather cell pass: any medium) | the single-gather form
+            for name, geo_k, single in (("westervelt_step", False, False), ("westervelt_step_in_kernel_geometry", True, False),
+                                        ("westervelt_step_single_gather", True, True)):
                 try:
-                    r = measure_rk4(wargs, rank, world, device, "westervelt", True, geo_k, max(1, min(args.steps, 20)), 2, cpu_leg=False, two_gather=two)
+                    r = measure_rk4(wargs, rank, world, device, "westervelt", True, geo_k, max(1, min(args.steps, 20)), 2, cpu_leg=False, single_gather=single)
                     out["aux"][name] = {k: r[k] for k in keys}
                 except Exception as e:  # noqa: BLE001
                     log(f"aux {name} line failed: {e!r}")
@@ -1885,7 +1902,12 @@ def main():
                 # N > 1: the ghost block of y keeps its partial sums from step to step, so the region's y is not K steps of one
                 # operator; one more apply into a zeroed y (same halo objects, same kernels), owned dofs of every rank against the
                 # oracle's apply over this rank's cells reverse-scattered through the transport the halo check passed
-                y_loc = oracle_apply(P, mesh, D64, x64, cc64, geo_h, mass)
+                if rank == 0:  # the portable oracle library travels prebuilt; should it be missing, ONE rank builds it
+                    from oracle import oracle_c
+
+                    oracle_c.OracleLib()
+                dist.barrier()
+                y_loc = oracle_apply(P, mesh, D64, x64, cc64, geo_h, mass, portable=True, threads=max(1, host_cores() // max(1, world)))
                 y_ref_d = torch.from_numpy(y_loc.astype(dt)).to(device)
                 halo.rev(y_ref_d)
                 ops.fill(0.0, y_d)

@@ -228,12 +228,22 @@ int main(int argc, char** argv) {
         CHECK_HIP(fetch_y());
         report("MassSpectral3D<double,4>::operator()", rel_l2(y, g["ref_y_mass"].f64()), tol);
         // the same functor on the atomic-free kernel (transposed dofmap, fus_mass_apply_gather_*)
-        mass.enable_gather(d_dm, ndofs);
-        if (!mass.gather_enabled()) throw std::runtime_error("the gather plan was declined for a hexahedral dofmap");
+        mass.enable_gather(d_dm, ndofs, nullptr, /*static_detJ=*/false);
+        if (!mass.gather_enabled() || mass.static_detJ_enabled()) throw std::runtime_error("the gather plan was declined for a hexahedral dofmap");
         CHECK_HIP(reset_y());
         mass(d_x, d_cc, d_y);
         CHECK_HIP(fetch_y());
         report("MassSpectral3D<double,4>::operator(), atomic-free kernel", rel_l2(y, g["ref_y_mass"].f64()), tol);
+        // ... and with its detJ (computed once in the constructor, like the reference's) streamed in row order
+        fus_gpu::MassSpectral3D<double, 4> mass_s(d_dm, ncell, geo);
+        mass_s.enable_gather(d_dm, ndofs);
+        if (!mass_s.static_detJ_enabled()) throw std::runtime_error("the static companion was declined for a hexahedral dofmap");
+        const std::vector<double> y_gather = y;
+        CHECK_HIP(reset_y());
+        mass_s(d_x, d_cc, d_y);
+        CHECK_HIP(fetch_y());
+        report("MassSpectral3D<double,4>::operator(), atomic-free kernel, detJ in row order", rel_l2(y, g["ref_y_mass"].f64()), tol);
+        if (y != y_gather) throw std::runtime_error("static-detJ mass apply differs bitwise from the gather apply");
       } catch (const std::exception& e) {
         std::fprintf(stderr, "functor twins: %s\n", e.what());
         ok = false;

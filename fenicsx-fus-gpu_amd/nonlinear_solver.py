@@ -39,7 +39,8 @@ class WesterveltSpectral3D(StepGraphMixin):
         cell in the caller's cell order (the DG0 material arrays of cuda/demo_nonlinear_bowl.py:166-178 -- water / skull / ...).
         ``reference_speed_of_sound`` / ``reference_density``: the scalars of the source term and of the default source amplitude
         (the reference uses those of the coupling medium); default: the scalars given, or the means over the source-facet cells.
-        A heterogeneous medium takes the two-gather cell pass by itself (c4 / c3 = delta / c^2 is no longer uniform).
+        ``uniform_ratio``: ``True`` opts into the single-gather cell pass where c4 / c3 = delta / c^2 is uniform (any homogeneous
+        medium); the default is the two-gather pass for every medium (faster since round 5, and what a heterogeneous medium needs anyway).
         ``in_kernel_geometry``: ``"auto"`` (default) -- the fused stage of degree >= 3 forms G in the cell kernel from the 8
         vertices of each (trilinear) cell and the G array is dropped unless ``keep_G``; ``False``: the reference's G stream;
         the reference launch sequence (``fused=False``) always reads G."""
@@ -145,7 +146,7 @@ class WesterveltSpectral3D(StepGraphMixin):
             for _ in self._setup:
                 pass
         # uniform ratio c4 / c3 (= delta / c^2: every homogeneous medium): K(c3) u + K(c4) v = K(c3)(u + kappa v),
-        # so the cell pass is ONE plain stiffness apply on w = u_n + kappa v_n, which the vector kernel writes
+        # so the cell pass CAN be one plain stiffness apply on w = u_n + kappa v_n, which the vector kernel writes (uniform_ratio=True)
         ratio = self.cc4 / self.cc3
         kmin, kmax = float(ratio.min().item()), float(ratio.max().item())
         # the decision (and kappa itself) must be the SAME on every rank -- a rank in single-gather mode forward-scatters
@@ -163,7 +164,11 @@ class WesterveltSpectral3D(StepGraphMixin):
                 dist.all_reduce(t, op=dist.ReduceOp.MAX)
                 kmin, kmax = -float(t[0].item()), float(t[1].item())
         self.kappa = kmin if abs(kmax - kmin) <= 1e-14 * max(abs(kmin), abs(kmax), 1e-300) else None
-        if uniform_ratio is False:  # force the general (two-gather) cell pass
+        # Which form: since the vector pass streams with non-temporal accesses (round 4) the TWO-gather cell pass is the faster one --
+        # the single-gather form pays for writing w in the vector pass and re-reading it: P = 6, 36^3 cells, paired: 1.285 against
+        # 1.458 ms per step with in-kernel geometry, 1.538 against 1.593 with the G array (profiles/r05i_ab_westervelt_gathers.log).
+        # "auto" / False: two gathers; True: the single-gather form where the medium allows it.
+        if uniform_ratio is not True:
             self.kappa = None
         self.w = z() if self.kappa is not None else None
         # opt-in (fused mode): G and detJ formed in the cell kernel from the vertices -- the cells of

@@ -130,6 +130,7 @@ def test_c_abi_golden_plain_cpp_host():
     assert "halo reverse (PEER transport, own arena)" in r.stdout and "halo forward (RCCL send/recv to self)" in r.stdout
     # the C++ functor twins of cpp/common/spectral_op.hpp (include/fus_gpu.hpp) against the reference's outputs
     assert "StiffnessSpectral3D<double,4>::operator()" in r.stdout and "MassSpectral3D<double,4>::operator()" in r.stdout
+    assert "atomic-free kernel, detJ in row order" in r.stdout
 
 
 @pytest.mark.gpu

@@ -135,7 +135,9 @@ def test_transport_fallback_after_a_failed_halo_check():
         cfg = _one_json_line(r.stdout)["config"]
         assert used in cfg["halo_transport"] and cfg["halo_check"]["ok"] is True
         tried = cfg["halo_transports_tried"]
-        assert [t["transport"] for t in tried] == ["peer", "native", "torch"][: len(reject.split(",")) + 1]
+        # (a rejected PEER transport is tried once more with its arenas in fine-grained memory before RCCL gets its turn)
+        assert [t["transport"] for t in tried] == ["peer", "peer:finegrained", "native", "torch"][: len(reject.split(",")) + 2]
+        assert tried[1]["arena_memory_by_rank"] == ["fine-grained"]
         assert all("rejected" in t["result"] for t in tried[:-1]) and tried[-1]["result"] == "ok"
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--cells", "12", "--no-cpu-baseline"],
                        env=_env(FUS_BENCH_FORCE_DIST="1", FUS_BENCH_TEST_REJECT="peer,native,torch"), capture_output=True, text=True, timeout=900)

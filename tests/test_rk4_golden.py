@@ -146,7 +146,7 @@ def test_gpu_westervelt_solver_reproduces_reference_driven_loop(variant):
     s = nls.WesterveltSpectral3D(serial, np.float64, speed_of_sound=kw["c0"], density=kw["rho0"], source_frequency=kw["f0"],
                                  source_amplitude=kw["p0"], nonlinear_coefficient=kw["beta"], attenuation_coefficient_dB=kw["att_dB"],
                                  fused=variant != "reference-sequence", in_kernel_geometry=variant.endswith("geometry"),
-                                 uniform_ratio=False if variant == "fused-two-gather" else "auto")
+                                 uniform_ratio=False if variant == "fused-two-gather" else True)
     s.init()
     _, steps = s.rk4(0.0, 1.0, float(d["dt"]), max_steps=int(d["nsteps"]))
     assert steps == int(d["nsteps"])

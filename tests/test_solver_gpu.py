@@ -77,8 +77,8 @@ def test_westervelt_bowl_pressure_field(oracle_c, P, cells, fused):
     dt, tf, _ = ls.snap_time_step(h, P, 1480.0, 1.1e6, L)
     nsteps = 10
     s = nls.WesterveltSpectral3D(mesh, np.float64, fused=bool(fused), in_kernel_geometry=str(fused).startswith("geom"),
-                                 uniform_ratio=False if str(fused).endswith("two-gather") else "auto")
-    assert (s.kappa is not None) == (fused in (True, "geom") or fused is False)
+                                 uniform_ratio=False if str(fused).endswith("two-gather") else True)
+    assert (s.kappa is not None) == (fused in (True, "geom") or fused is False)  # uniform_ratio=True: single gather on this homogeneous medium
     s.init()
     s.rk4(0.0, tf, dt, max_steps=nsteps)
     u_ref, v_ref = rk4_oracle.solve_westervelt(mesh, nsteps, dt, oracle_c=oracle_c)
@@ -502,7 +502,7 @@ def test_westervelt_solver_graph_replay_matches_rk4(mode):
     boxmesh, nls = pkg("boxmesh"), pkg("nonlinear_solver")
     P, cells, L = 4, (4, 3, 3), 0.006
     mesh = boxmesh.BoxMesh(P, cells, length=L, warp=_bowl_warp)
-    kw = dict(fused=True, in_kernel_geometry=(mode == "in-kernel-geometry"), uniform_ratio=(False if mode == "two-gather" else "auto"))
+    kw = dict(fused=True, in_kernel_geometry=(mode == "in-kernel-geometry"), uniform_ratio=(False if mode == "two-gather" else True))
     a = nls.WesterveltSpectral3D(mesh, np.float64, **kw)
     b = nls.WesterveltSpectral3D(mesh, np.float64, **kw)
     assert (a.kappa is None) == (mode == "two-gather")
