@@ -199,3 +199,9 @@ def test_committed_pmc_passes_belong_to_the_kernels_in_this_tree():
     assert tm["kernel_src_sha"] == bench.kernel_src_sha(tuple(tm.get("kernel_src_files", ("plan.hpp", "mass.hpp")))), "mass kernel sources changed"
     assert tm.get("kernel") == "fus::mass_gather_kernel"  # what aux.mass of the default line launches at config 3
     assert os.path.exists(os.path.join(ROOT, t["source"])) and os.path.exists(os.path.join(ROOT, t["aux"]["mass"]["source"]))
+    # the other replayed lines of the default bench line: in-kernel geometry, both RK4 steps, the Westervelt steps
+    for key in ("stiffness_in_kernel_geometry", "rk4_step", "rk4_step_in_kernel_geometry", "westervelt_step", "westervelt_step_in_kernel_geometry",
+                "westervelt_step_in_kernel_geometry_single_gather"):
+        e = t["aux"][key]
+        assert e["kernel_src_sha"] == bench.kernel_src_sha(tuple(e["kernel_src_files"])), f"{key}: kernel sources changed since {e['source']}"
+        assert os.path.exists(os.path.join(ROOT, e["source"])), e["source"]
