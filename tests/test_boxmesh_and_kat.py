@@ -141,3 +141,32 @@ def test_boundary_first_cell_order():
     touches = (d2 >= m.nlocal).any(axis=1)
     assert np.all(touches[:nb]) and not np.any(touches[nb:])
     assert sorted(perm.tolist()) == list(range(m.ncells))
+
+
+@pytest.mark.parametrize("P,cells,cpb", [(4, (6, 5, 12), 10), (2, (5, 6, 7), 28), (3, (4, 6, 9), 16)])
+def test_two_row_strip_order_is_a_permutation_with_more_sharing(P, cells, cpb):
+    """plan_tiles (opt-in set-up order of the scatter-bound kernels' plans): face adjacency from the six face-interior dofs of the
+    dofmap alone, rows of the cell order, adjacent rows interleaved.  The result is a permutation of the cells; consecutive cells of a
+    strip are face neighbours or row neighbours; batches of ``cpb`` cells touch fewer distinct dofs than rows do."""
+    boxmesh, pt = pkg("boxmesh"), pkg("plan_tiles")
+    mesh = boxmesh.BoxMesh(P, cells)
+    n = P + 1
+    faces = pt.face_interior_local_dofs(n)
+    assert faces.size == 6 and np.unique(faces).size == 6
+    nbr = pt.face_neighbours(mesh.dofmap[:, faces])
+    # a structured box: cell (i, j, k) has 6 neighbours minus the faces on the boundary; adjacency is symmetric through opposite faces
+    nx, ny, nz = cells
+    assert int((nbr >= 0).sum()) == 2 * ((nx - 1) * ny * nz + nx * (ny - 1) * nz + nx * ny * (nz - 1))
+    c, f = np.nonzero(nbr >= 0)
+    assert np.array_equal(nbr[nbr[c, f], f ^ 1], c)
+    order = pt.two_row_strip_order(mesh.dofmap[:, faces])
+    assert order is not None and np.array_equal(np.sort(order), np.arange(mesh.ncells))
+
+    def distinct(o):
+        return sum(np.unique(mesh.dofmap[o[b: b + cpb]]).size for b in range(0, mesh.ncells, cpb))
+
+    # (rows shorter than a batch: a batch holds several whole rows either way -- equal; rows longer than a batch: strictly fewer)
+    assert distinct(order) <= distinct(np.arange(mesh.ncells)) and (cells[2] < cpb or distinct(order) < distinct(np.arange(mesh.ncells)))
+    # a cell order without rows (random) offers nothing to pair
+    perm = np.random.default_rng(0).permutation(mesh.ncells)
+    assert pt.two_row_strip_order(mesh.dofmap[perm][:, faces]) is None

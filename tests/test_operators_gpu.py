@@ -799,6 +799,38 @@ def test_lists_and_run_tables_of_one_plan(gpu, oracle_c, P, dtype):
         ops._PLANS.clear()
 
 
+def test_strip_ordered_plan_opt_in(gpu, oracle_c):
+    """``use_strip_order(True)`` (opt-in, measured negative at config 3: docs/history.md section 11): the in-kernel-geometry operator's plan
+    takes the two-row strip order when it lowers the distinct dofs per batch -- a second cached plan next to the row-ordered one, cell
+    order inside the plan (no array moves), same result as the oracle."""
+    import torch
+
+    dev, ops = gpu
+    P = 4
+    pb = build_problem(P, (4, 6, 20), perturb=0.16, seed=5)
+    mesh = pb["mesh"]
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, pb["D"], pb["x"], pb["cc"], y_ref, pb["G"], mesh.dofmap)
+    x, cc, dm = (dev.to_device(a) for a in (pb["x"], pb["cc"], mesh.dofmap))
+    opg = ops.stiffness_operator(P, pb["D"].flatten(), np.float64, geometry=(mesh.x_dofs, mesh.x_g, pb["pts"], pb["wts"]))
+    ops._PLANS.clear()
+    try:
+        ops.use_strip_order(True)
+        y = torch.zeros(mesh.ndofs, dtype=torch.float64, device="cuda")
+        opg(x, cc, y, None, dm)
+        _check(y.cpu().numpy(), y_ref, np.float64, "in-kernel geometry on a strip-ordered plan")
+        keys = list(ops._PLANS._plans)
+        assert len(keys) == 1 and keys[0][-1] == "strips" and ops._PLANS.last_order is not None  # the strip order was kept (-8 % distinct dofs)
+        ops.use_strip_order(False)
+        y2 = torch.zeros_like(y)
+        opg(x, cc, y2, None, dm)
+        _check(y2.cpu().numpy(), y_ref, np.float64, "in-kernel geometry on the row-ordered plan")
+        assert len(ops._PLANS._plans) == 2
+    finally:
+        ops.use_strip_order(False)
+        ops._PLANS.clear()
+
+
 @pytest.mark.parametrize("path", golden_files("ops_P4_"), ids=lambda p: p.split("/")[-1][:-4])
 def test_facet_terms_one_launch(gpu, oracle_c, path):
     """fus_facet_terms_*: the stage's boundary-facet mass applies (source facets with x = g filled into a
