@@ -10,79 +10,24 @@
 #include <mutex>
 #include <unordered_map>
 
+#include "fus_dispatch.hpp"
 #include "geometry.hpp"
 #include "halo.hpp"
 #include "halo_comm.hpp"
 #include "mass.hpp"
 #include "mass_gather.hpp"
-#include "plan.hpp"
+#include "plan_build.hpp"
 #include "rk4.hpp"
 #include "stiffness.hpp"
-#include "stiffness_affine.hpp"
-#include "stiffness_geom.hpp"
-#include "stiffness_plan.hpp"
 #include "vecops.hpp"
 #include "westervelt.hpp"
-#include "westervelt_geom.hpp"
+
+using namespace fus_abi;
 
 namespace {
 
-std::atomic<int> g_stiffness_variant{0};
-std::atomic<int> g_xcd_remap{0};  // measured slower on MI355X (profiles/r01b_ab_variants.log)
-std::atomic<int> g_mass_variant{0};
-std::atomic<int> g_plan_runs{1};  // 0 never, 1 auto, 2 always
-
-// Run-length coded dof lists (8 bytes per run of consecutive dofs instead of 4 per dof; expanded in LDS by
-// the apply kernels): the builder decides per batch (a list that does not compress stays raw).
-inline int plan_allow_runs(int ndof_per_entity) {
-  (void)ndof_per_entity;
-  return g_plan_runs.load(std::memory_order_relaxed) != 0;
-}
-// which encoding of the dof lists a launch reads (the plan holds both)
-template <typename T>
-inline bool plan_use_runs(int ndof_per_entity) {
-  const int mode = g_plan_runs.load(std::memory_order_relaxed);
-  // auto: fp64 always (+2..7 % at every degree); fp32 up to P = 4 (+6.5 % at P = 2 and 4, -12 % at P = 6,
-  // where the kernel is not bandwidth-bound): profiles/r02o_ab_run_tables.log, r02y_ab_fp32.log
-  return mode == 2 || (mode == 1 && (sizeof(T) == 8 || ndof_per_entity <= 125));
-}
-std::atomic<int> g_plan_variant{-1};  // -1 = auto
-
-// Host mirror of the plans built through this library, keyed by workspace address: the apply entry
-// points check that a workspace was built, and for the (N, entities per batch, entity count) they are
-// called with, before any kernel indexes it (a mismatch would gather / scatter out of bounds), and
-// learn from it whether the plan carries a cell order.
-struct PlanInfo {
-  int N = 0, epb = 0;
-  int64_t nent = 0;
-  bool ordered = false;
-  bool exclusive = false;  // fus_plan_mark_exclusive has run: the plan carries exclusive-dof marks
-};
-std::mutex g_plans_mu;
-std::unordered_map<const void*, PlanInfo> g_plans;
-
-void plan_register(const void* ws, int N, int epb, int64_t nent, bool ordered) {
-  std::lock_guard<std::mutex> lk(g_plans_mu);
-  g_plans[ws] = PlanInfo{N, epb, nent, ordered, false};
-}
-// true if ``ws`` holds a plan for exactly this shape; ``ordered`` out
-bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, bool* exclusive = nullptr) {
-  std::lock_guard<std::mutex> lk(g_plans_mu);
-  auto it = g_plans.find(ws);
-  if (it == g_plans.end()) return false;
-  const PlanInfo& p = it->second;
-  if (p.N != N || p.epb != epb || p.nent != nent) return false;
-  *ordered = p.ordered;
-  if (exclusive) *exclusive = p.exclusive;
-  return true;
-}
-
-// transposed-dofmap plans of the atomic-free mass apply (csrc/mass_gather.hpp), keyed by workspace address
+// transposed-dofmap plans of the atomic-free mass apply (csrc/mass_gather.hpp), keyed by workspace address (under g_plans_mu)
 std::unordered_map<const void*, fus::GatherHeader> g_gather_plans;
-
-inline int hip_rc(hipError_t e) { return e == hipSuccess ? FUS_OK : FUS_ERR_HIP_BASE - (int)e; }
-
-inline bool misaligned(const void* p, size_t a) { return (reinterpret_cast<uintptr_t>(p) & (a - 1)) != 0; }
 
 template <typename T, int P>
 hipError_t stiffness_dispatch_variant(const T* x, const T* cc, T* y, const T* G, const int32_t* dofmap,
@@ -115,200 +60,6 @@ int stiffness_apply(const T* x, const T* cc, T* y, const T* G, const int32_t* do
 #define FUS_CASE(PP) \
   case PP:           \
     e = stiffness_dispatch_variant<T, PP>(x, cc, y, G, dofmap, dphi, ncell, s); \
-    break;
-    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
-    FUS_CASE(10)
-#undef FUS_CASE
-  }
-  return hip_rc(e);
-}
-
-inline int cells_per_batch(int P) {
-  const int n2 = (P + 1) * (P + 1);
-  return 256 / n2 > 0 ? 256 / n2 : 1;
-}
-
-template <int P>
-int64_t plan_bytes_p(int64_t ncell) {
-  return fus::plan_view(nullptr, P, fus::plan_cells_per_batch<P>(), ncell).bytes;
-}
-
-int64_t plan_bytes(int P, int64_t ncell) {
-  switch (P) {
-#define FUS_CASE(PP) \
-  case PP:           \
-    return plan_bytes_p<PP>(ncell);
-    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
-    FUS_CASE(10)
-#undef FUS_CASE
-  }
-  return FUS_ERR_UNSUPPORTED_DEGREE;
-}
-
-// fp32 build with 5 waves per SIMD (only instantiated for float)
-template <typename T, int P>
-hipError_t launch_plan_f32_5w(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int64_t ncell,
-                              int remap, hipStream_t s, bool ord, bool runs) {
-  if constexpr (sizeof(T) == 4 && P <= 4)
-    return fus::launch_stiffness_plan<T, P, false, true, 5>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, runs);
-  else
-    return fus::launch_stiffness_plan<T, P, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, runs);
-}
-
-template <typename T>
-int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const void* ws, const T* dphi, int P,
-                            int64_t ncell, void* stream) {
-  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
-  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
-  if (ncell == 0) return FUS_OK;
-  if (!x || !cc || !y || !G || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
-  if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  const int remap = g_xcd_remap.load(std::memory_order_relaxed);
-  hipError_t e = hipErrorInvalidValue;
-  // Builds (profiles/r01d_ab_alias_by_degree.log, r02*_ab_*.log; pinned by tests/test_resource_usage.py):
-  //   0  three LDS cubes + own x/y buffer           (P <= 3)
-  //   1  LDS-aliased, whole G slab issued up front  (P = 4, 5: 4 workgroups per CU at P = 4)
-  //   2  LDS-aliased, ring of G slabs               (P >= 6: registers are the binding limit there; P = 8 also
-  //                                                  drops the LDS padding to fit a third workgroup per CU)
-  //   30 fp32, registers allow 5 waves per SIMD     (fp32, P <= 4)
-  int pv = g_plan_variant.load(std::memory_order_relaxed);
-  if (pv < 0) {
-    if (sizeof(T) == 4)
-      pv = (P <= 4) ? 30 : 1;  // fp32: registers are not the limit, the whole G slab up front wins (r02y_ab_fp32.log)
-    else {
-      // measured per degree at ~10 M dofs (profiles/r02a_ab_builds_and_slp.log, r02b_ab_isolated_and_degrees.log,
-      // r02h_ab_degrees_3_9_10.log, r02r_ab_degrees_8_9_10.log): the ring wins where it buys a workgroup per CU
-      static const int best[11] = {0, 0, 0, 0, 1, 1, 2, 2, 2, 2, 2};
-      pv = best[P];
-    }
-  }
-  switch (P) {
-#define FUS_CASE(PP)                                                                                      \
-  case PP:                                                                                                \
-    switch (pv) {                                                                                         \
-      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, (PP != 8), fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
-      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
-      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
-    }                                                                                                     \
-    break;
-    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
-    FUS_CASE(10)
-#undef FUS_CASE
-  }
-  return hip_rc(e);
-}
-
-template <typename T>
-int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, const T* wratio, const void* ws,
-                                   const T* dphi, int P, int64_t ncell, void* stream) {
-  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
-  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
-  if (ncell == 0) return FUS_OK;
-  if (!x || !cc || !y || !G || !wratio || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
-  if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipErrorInvalidValue;
-  // P <= 4: unpadded LDS + 5 waves per SIMD (+8 %, profiles/r01f_affine_fast_path.log); above, registers do
-  // not allow 5 waves without spilling: padded build, compiler's own allocation
-  switch (P) {
-#define FUS_CASE(PP) \
-  case PP:           \
-    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
-    break;
-    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
-    FUS_CASE(10)
-#undef FUS_CASE
-  }
-  return hip_rc(e);
-}
-
-template <typename T>
-int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, const int32_t* x_dofs, const T* pts,
-                                 const T* wts, const void* ws, const T* dphi, int P, int64_t ncell, void* stream) {
-  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
-  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
-  if (ncell == 0) return FUS_OK;
-  if (!x || !cc || !y || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
-  if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) {
-#ifdef FUS_EXPERIMENT_GEOM_CPB20
-    // EXPERIMENT (tools/exp_geom_tiles.py): a generic plan with 20 cells per batch (2 x 2 x 5 tiles:
-    // 85 instead of 103 distinct dofs per cell) takes a 512-thread build of the kernel -- 65 kB of LDS, 2 workgroups per CU
-    if constexpr (std::is_same<T, double>::value) {
-      if (P == 4 && plan_check(ws, 125, 20, ncell, &ord))
-        return hip_rc(fus::launch_stiffness_plan_geom<T, 4, true, false, 1, true, 20>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, true));
-    }
-#endif
-    return FUS_ERR_PLAN_MISMATCH;
-  }
-  hipError_t e = hipErrorInvalidValue;
-  switch (P) {
-#define FUS_CASE(PP) \
-  case PP:           \
-    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
-    break;
-    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
-    FUS_CASE(10)
-#undef FUS_CASE
-  }
-  return hip_rc(e);
-}
-
-template <typename T>
-int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5, T* b, T* m, const T* G,
-                    const T* detJ, const void* ws, const T* dphi, int P, int64_t ncell, void* stream) {
-  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
-  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
-  if (ncell == 0) return FUS_OK;
-  const bool mass = c2 || c5 || m || detJ;  // all four or none: none = the stiffness part alone
-  if (!u || !v || !c3 || !c4 || !b || !G || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
-  if (mass && (!c2 || !c5 || !m || !detJ)) return FUS_ERR_INVALID_ARGUMENT;
-  if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipErrorInvalidValue;
-  switch (P) {
-#define FUS_CASE(PP) \
-  case PP:           \
-    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))) \
-             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
-    break;
-    FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
-    FUS_CASE(10)
-#undef FUS_CASE
-  }
-  return hip_rc(e);
-}
-
-template <typename T>
-int westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const T* c4, const T* c5, T* b, T* m,
-                         const T* x_g, const int32_t* x_dofs, const T* pts, const T* wts, const void* ws, const T* dphi,
-                         int P, int64_t ncell, void* stream) {
-  if (ncell < 0) return FUS_ERR_INVALID_ARGUMENT;
-  if (P < FUS_MIN_DEGREE || P > FUS_MAX_DEGREE) return FUS_ERR_UNSUPPORTED_DEGREE;
-  if (ncell == 0) return FUS_OK;
-  const bool mass = c2 || c5 || m;
-  if (!u || !v || !c3 || !c4 || !b || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
-  if (mass && (!c2 || !c5 || !m)) return FUS_ERR_INVALID_ARGUMENT;
-  if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
-  hipStream_t s = static_cast<hipStream_t>(stream);
-  hipError_t e = hipErrorInvalidValue;
-  switch (P) {
-#define FUS_CASE(PP) \
-  case PP:           \
-    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))) \
-             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)

@@ -117,14 +117,14 @@ __global__ void __launch_bounds__(256)
   const int64_t ent0 = batch * epb;
   const int64_t left = nent - ent0;
   const int valid = (int)((left < epb ? left : epb) * N);
-  const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int64_t base = batch * (int64_t)M;
   const int32_t* ud = udofs + base;
-  const int32_t* rn = runs != nullptr ? runs + batch * (int64_t)(2 * kPlanMaxRuns) : nullptr;
+  const bool use_runs = runs != nullptr;  // launch-uniform, tested at run time here (this kernel already has 18 shapes per type)
+  const int32_t* rn = use_runs ? runs + batch * (int64_t)(2 * kPlanMaxRuns) : nullptr;
 
   int32_t mydof[EPT];
-  const RunWords rt = batch_dofs_issue<EPT, 256>(ud, rn, M, nu_b, nr_b, tid, mydof);
+  const RunWords rt = use_runs ? batch_dofs_issue<true, EPT, 256>(ud, rn, M, tid, mydof)
+                               : batch_dofs_issue<false, EPT, 256>(ud, rn, M, tid, mydof);
   uint16_t sl[EPT];
   T w[EPT];
 #pragma unroll
@@ -140,7 +140,9 @@ __global__ void __launch_bounds__(256)
       w[r] = detJ[base + ic] * entity_constants[ent0 + e];
     }
   }
-  batch_dofs_resolve<EPT, 256, true>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(sy), mydof);
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = use_runs ? plan_runs_of<true>(packed) : 0;
+  if (use_runs) batch_dofs_resolve<true, EPT, 256, true>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(sy), mydof);
   T xv[EPT];
 #pragma unroll
   for (int r = 0; r < EPT; ++r) xv[r] = x[mydof[r]];

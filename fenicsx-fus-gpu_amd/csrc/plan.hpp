@@ -38,10 +38,9 @@
 #include <hip/hip_runtime.h>
 
 #include <mutex>
+#include <type_traits>
 #include <vector>
 #include <stdint.h>
-
-#include <type_traits>
 
 #include "stiffness.hpp"
 
@@ -178,251 +177,86 @@ inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
   return plan_view_generic(workspace, n * n * n, cpb, ncell);
 }
 
-// One workgroup per batch: LDS bitonic sort of (dof << 16 | position) keys, unique flags,
-// block scan, write slots + distinct dofs.  M = epb * N entries per batch, M <= M2 (power of 2).
-template <int M2>
-__global__ void __launch_bounds__(256)
-    plan_build_kernel(const int32_t* __restrict__ dofmap, int64_t nent, int N, int epb, int32_t* __restrict__ nu,
-                      int32_t* __restrict__ udofs, int32_t* __restrict__ runs, uint16_t* __restrict__ slot,
-                      int allow_runs, const int32_t* __restrict__ order) {
-  constexpr int CH = M2 / 256;  // elements per thread in the scan phase
-  __shared__ uint64_t keys[M2];
-  __shared__ int cnt[256];
-
-  const int tid = threadIdx.x;
-  const int M = epb * N;
-  const int64_t batch = blockIdx.x;
-  const int64_t ent0 = batch * epb;
-  const int64_t left = nent - ent0;
-  const int valid = (int)((left < epb ? left : epb) * N);
-  const int32_t* dm = dofmap + ent0 * N;
-
-  for (int i = tid; i < M2; i += 256) {
-    uint64_t k = ~0ull;
-    if (i < valid) {
-      int32_t d;
-      if (order) {  // entity at batch position e = i / N is order[ent0 + e]
-        const int e = i / N;
-        d = dofmap[(int64_t)order[ent0 + e] * N + (i - e * N)];
-      } else {
-        d = dm[i];
-      }
-      k = ((uint64_t)(uint32_t)d << 16) | (uint64_t)i;
-    }
-    keys[i] = k;
-  }
-  __syncthreads();
-
-  for (int k = 2; k <= M2; k <<= 1) {
-    for (int j = k >> 1; j > 0; j >>= 1) {
-      for (int i = tid; i < M2; i += 256) {
-        const int l = i ^ j;
-        if (l > i) {
-          const uint64_t a = keys[i], b = keys[l];
-          const bool up = (i & k) == 0;
-          if ((a > b) == up) {
-            keys[i] = b;
-            keys[l] = a;
-          }
-        }
-      }
-      __syncthreads();
-    }
-  }
-
-  // unique / run-start flags over this thread's contiguous chunk [tid*CH, tid*CH+CH); a run is a
-  // maximal stretch of consecutive dof numbers among the distinct dofs
-  const int i0 = tid * CH;
-  int local = 0;  // distinct dofs | (run starts << 16)
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int i = i0 + c;
-    if (i < valid) {
-      const uint32_t d = (uint32_t)(keys[i] >> 16);
-      const uint32_t dp = (i == 0) ? 0u : (uint32_t)(keys[i - 1] >> 16);
-      const bool first = (i == 0) || (d != dp);
-      const bool rstart = first && ((i == 0) || (d != dp + 1u));
-      local += (first ? 1 : 0) + (rstart ? 0x10000 : 0);
-    }
-  }
-  cnt[tid] = local;
-  __syncthreads();
-  for (int off = 1; off < 256; off <<= 1) {  // inclusive Hillis-Steele scan (both counts at once)
-    const int v = (tid >= off) ? cnt[tid - off] : 0;
-    __syncthreads();
-    cnt[tid] += v;
-    __syncthreads();
-  }
-  const int total = cnt[255];
-  const int nu_b = total & 0xffff, nr_b = total >> 16;
-  const bool use_runs = allow_runs && (nr_b <= kPlanMaxRuns) && (2 * nr_b < nu_b);
-  const int excl = cnt[tid] - local;
-  int s = excl & 0xffff;  // slot of the first new dof in this chunk
-  int r = excl >> 16;     // index of the first new run in this chunk
-  if (tid == 255) nu[batch] = nu_b | ((use_runs ? nr_b : 0) << 16);
-  int32_t* ud = udofs + batch * (int64_t)M;
-  int32_t* rn = runs + batch * (int64_t)(2 * kPlanMaxRuns);
-  uint16_t* sl = slot + batch * (int64_t)M;
-#pragma unroll
-  for (int c = 0; c < CH; ++c) {
-    const int i = i0 + c;
-    if (i < valid) {
-      const uint64_t key = keys[i];
-      const uint32_t d = (uint32_t)(key >> 16);
-      const uint32_t dp = (i == 0) ? 0u : (uint32_t)(keys[i - 1] >> 16);
-      const bool first = (i == 0) || (d != dp);
-      const bool rstart = first && ((i == 0) || (d != dp + 1u));
-      if (first) {
-        ud[s] = (int32_t)d;
-        if (use_runs && rstart) {
-          rn[2 * r] = (int32_t)d;
-          rn[2 * r + 1] = s;
-          ++r;
-        }
-        ++s;
-      }
-      sl[key & 0xffffu] = (uint16_t)(s - 1);
-    }
-  }
-  // pad [nu, M) with the batch's first dof, so the apply kernels can issue their per-slot loads
-  // without first waiting for nu (entries beyond nu are loaded but never used)
-  if (valid > 0) {
-    const int32_t d0 = (int32_t)(uint32_t)(keys[0] >> 16);
-    for (int i = nu_b + tid; i < M; i += 256) ud[i] = d0;
-  }
-}
-
 constexpr int kPlanMaxEntries = 4096;  // per batch; slot ids are 16-bit, keys live in LDS
 
-inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int epb, int64_t nent, void* workspace,
-                                            hipStream_t stream, int allow_runs = 1,
-                                            const int32_t* cell_order = nullptr) {
-  if (nent <= 0) return hipSuccess;
-  const int M = epb * N;
-  if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
-  PlanView v = plan_view_generic(workspace, N, epb, nent);
-  if (v.nbatch > 0x7fffffffLL) return hipErrorInvalidValue;
-  int64_t hdr[7] = {kPlanMagic, N, epb, nent, v.nbatch, v.entries, cell_order ? 1 : 0};
-  hipError_t e = hipMemcpyAsync(workspace, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream);
-  if (e != hipSuccess) return e;
-  const int32_t* order = nullptr;
-  if (cell_order) {  // keep a copy inside the workspace: the plan is self-contained
-    e = hipMemcpyAsync(v.order, cell_order, nent * sizeof(int32_t), hipMemcpyDeviceToDevice, stream);
-    if (e != hipSuccess) return e;
-    order = v.order;
-  }
-  const dim3 grid((unsigned)v.nbatch), block(256);
-  if (M <= 256)
-    hipLaunchKernelGGL((plan_build_kernel<256>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
-                       allow_runs, order);
-  else if (M <= 512)
-    hipLaunchKernelGGL((plan_build_kernel<512>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
-                       allow_runs, order);
-  else if (M <= 1024)
-    hipLaunchKernelGGL((plan_build_kernel<1024>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
-                       allow_runs, order);
-  else if (M <= 2048)
-    hipLaunchKernelGGL((plan_build_kernel<2048>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
-                       allow_runs, order);
-  else
-    hipLaunchKernelGGL((plan_build_kernel<4096>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
-                       allow_runs, order);
-  return hipGetLastError();
-}
+// ---- the preamble every planned kernel shares ------------------------------------------------------------------------
+// A workgroup lives ~9 us, and a global load under load costs ~1.3 us: the preamble must be TWO round trips deep (the plan's
+// lists and per-cell data; then what they point to: x and, with in-kernel geometry, the vertex coordinates), not one per
+// array.  The compiler keeps program order across exec-masked blocks and waits (vmcnt counts in order: for EVERY older load)
+// at the first USE of a loaded register, so the rules are: (1) no load whose value is used inside the conditional block it
+// was issued in (an LDS store of a table, the sign extension of an index); tables are loaded with clamped indices into
+// registers and stored later; (2) nothing in the issue phase depends on nu[batch]; (3) what is uniform over the LAUNCH -- the
+// plan carries a cell order (ORDERED), the launch reads the run tables (RUNS) -- is a template parameter, not a pointer test:
+// a runtime select would make every launch wait for the order load, and the two list encodings would share one wait
+// (profiles/r05p_ablate_geom_phases.log: 8 serial round trips -> 2, in-kernel-geometry kernel -3.6 %).
 
-template <int P>
-inline hipError_t launch_plan_build(const int32_t* dofmap, int64_t ncell, void* workspace, hipStream_t stream,
-                                    int allow_runs = 1) {
-  constexpr int n = P + 1;
-  return launch_plan_build_generic(dofmap, n * n * n, plan_cells_per_batch<P>(), ncell, workspace, stream, allow_runs);
+// Row of the per-cell arrays of the cell at position ``pos`` of the plan's order.  Issue: unsigned, so that widening it later is
+// no use of the loaded register (a sign extension would be hoisted to the load and wait for it).
+template <bool ORDERED>
+__device__ __forceinline__ uint32_t plan_row_issue(const int32_t* __restrict__ order, int64_t pos, bool active) {
+  if constexpr (ORDERED) return (uint32_t)order[active ? pos : 0];
+  return 0u;
 }
-
-// ---- exclusive-dof marks (optional second pass over a built plan) ------------------------------------------------------
-// use[dof] += 1 for every (batch, distinct dof) of the plan.  ``use`` comes in holding what ELSE touches each dof (0 for a
-// launch that runs alone): dofs with use == 1 afterwards belong to exactly one batch and to nothing else.
-__global__ void __launch_bounds__(256)
-    plan_count_uses_kernel(const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs, int64_t entries, int32_t* use,
-                           int64_t ndofs) {
-  const int64_t batch = blockIdx.x;
-  const int nu_b = nu[batch] & 0xffff;
-  const int32_t* ud = udofs + batch * entries;
-  for (int s = threadIdx.x; s < nu_b; s += 256) {
-    const int32_t d = ud[s];
-    if (d >= 0 && d < ndofs) atomicAdd(&use[d], 1);
-  }
-}
-__global__ void __launch_bounds__(256)
-    plan_mark_exclusive_kernel(const int32_t* __restrict__ nu, const int32_t* __restrict__ udofs, int64_t entries,
-                               const int32_t* __restrict__ use, int64_t ndofs, uint32_t* __restrict__ excl, int64_t words) {
-  const int64_t batch = blockIdx.x;
-  const int nu_b = nu[batch] & 0xffff;
-  const int32_t* ud = udofs + batch * entries;
-  uint32_t* ex = excl + batch * words;
-  for (int64_t w = threadIdx.x; w < words; w += 256) {
-    uint32_t bits = 0;
-    for (int b = 0; b < 32; ++b) {
-      const int64_t s = w * 32 + b;
-      if (s < nu_b) {
-        const int32_t d = ud[s];
-        if (d >= 0 && d < ndofs && use[d] == 1) bits |= 1u << b;
-      }
-    }
-    ex[w] = bits;
-  }
-}
-inline hipError_t launch_plan_mark_exclusive(void* workspace, int N, int epb, int64_t nent, int32_t* use, int64_t ndofs,
-                                             hipStream_t stream) {
-  if (nent <= 0) return hipSuccess;
-  PlanView v = plan_view_generic(workspace, N, epb, nent);
-  hipLaunchKernelGGL(plan_count_uses_kernel, dim3((unsigned)v.nbatch), dim3(256), 0, stream, v.nu, v.udofs, v.entries, use, ndofs);
-  hipError_t e = hipGetLastError();
-  if (e != hipSuccess) return e;
-  hipLaunchKernelGGL(plan_mark_exclusive_kernel, dim3((unsigned)v.nbatch), dim3(256), 0, stream, v.nu, v.udofs, v.entries, use, ndofs,
-                     v.excl, v.excl_words);
-  return hipGetLastError();
+template <bool ORDERED>
+__device__ __forceinline__ int64_t plan_row(uint32_t row, int64_t pos) {
+  if constexpr (ORDERED) return (int64_t)row;
+  return pos;
 }
 
 // Distinct dofs owned by this thread (slots tid, tid + BLOCK, ...), for both plan encodings.
-// Phase 1 (issue the global loads; call BEFORE the other HBM loads of the batch so that the x
-// gather, which depends on them, can be issued while those are still in flight).  Raw list: one
-// dof per slot.  Run-length list: thread t < nr holds run t = (first dof, first slot, end slot).
+// Phase 1 (issue the global loads; call BEFORE the other HBM loads of the batch so that the x gather, which depends on
+// them, can be issued while those are still in flight).  Raw list (!RUNS): one dof per slot, slots clamped (the builder
+// padded [nu, M) with a valid dof).  Run-length list (RUNS): thread t holds run t = (first dof, first slot, first slot of
+// the next run), read SPECULATIVELY for all kPlanMaxRuns entries of the batch's table -- entries beyond the batch's runs
+// hold whatever the allocation held and are never used (phase 2 masks them with nu[batch], which has arrived by then).
 struct RunWords {
   int32_t d0, s0, s1;
 };
-// ``rn`` = the batch's run table, or nullptr when this launch reads the lists; ``nr_b`` is then forced to 0
-// by the caller (plan_runs_of) so that both phases take the list path.
-__device__ __forceinline__ int plan_runs_of(int packed, const int32_t* runs) { return runs != nullptr ? (packed >> 16) : 0; }
-
-template <int SPT, int BLOCK>
-__device__ __forceinline__ RunWords batch_dofs_issue(const int32_t* __restrict__ ud, const int32_t* __restrict__ rn,
-                                                     int M, int nu_b, int nr_b, int tid, int32_t (&mydof)[SPT]) {
+template <bool RUNS, int SPT, int BLOCK>
+__device__ __forceinline__ RunWords batch_dofs_issue(const int32_t* __restrict__ ud, const int32_t* __restrict__ rn, int M, int tid,
+                                                     int32_t (&mydof)[SPT]) {
   RunWords rw = {0, 0, 0};
-  if (nr_b == 0) {  // the list; the builder padded [nu, M) with a valid dof
+  if constexpr (RUNS) {
+    constexpr int last = 2 * kPlanMaxRuns - 1;
+    const int i0 = 2 * tid, i1 = 2 * tid + 1, i3 = 2 * tid + 3;
+    rw.d0 = rn[i0 < last ? i0 : last];
+    rw.s0 = rn[i1 < last ? i1 : last];
+    rw.s1 = rn[i3 < last ? i3 : last];
+  } else {
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const int s = tid + r * BLOCK;
       mydof[r] = ud[s < M ? s : 0];
     }
-  } else if (tid < nr_b) {
-    rw.d0 = rn[2 * tid];
-    rw.s0 = rn[2 * tid + 1];
-    rw.s1 = (tid + 1 < nr_b) ? rn[2 * tid + 3] : nu_b;
   }
   return rw;
 }
-// Phase 2 (run-length plans only): the owners of the runs expand them into ``s_dofs`` (an LDS region
-// of >= 4 * nu_b bytes that nothing else uses until the next barrier of the caller -- every kernel
-// passes a cube that is written only after its gather), one barrier, every thread reads its slots.
-// A run is <= a few dozen consecutive dofs, so the serial expansion by <= 128 threads is a fraction of
-// a microsecond; what it buys is 8 bytes per RUN instead of 4 per DOF in HBM (P = 4: 4.1 kB -> 0.2 kB
-// per batch).
-// TRAIL: end with a barrier (for callers that overwrite the region before their next barrier).
-template <int SPT, int BLOCK, bool TRAIL = false>
-__device__ __forceinline__ void batch_dofs_resolve(const RunWords& rw, int nu_b, int nr_b, int tid,
-                                                   int32_t* __restrict__ s_dofs, int32_t (&mydof)[SPT]) {
-  if (nr_b == 0) return;  // block-uniform
+// nu[batch]: distinct dofs (low half) and, in a run-coded launch, runs (high half; 0 = this batch's list did not compress)
+template <bool RUNS>
+__device__ __forceinline__ int plan_runs_of(int packed) {
+  return RUNS ? (packed >> 16) : 0;
+}
+// Phase 2 (RUNS only): the owners of the runs expand them into ``s_dofs`` (an LDS region of >= 4 * nu_b bytes that nothing
+// else uses until the next barrier of the caller -- every kernel passes a cube that is written only after its gather), one
+// barrier, every thread reads its slots.  A run is <= a few dozen consecutive dofs, so the serial expansion by <= 128
+// threads is a fraction of a microsecond; what it buys is 8 bytes per RUN instead of 4 per DOF in HBM (P = 4: 4.1 kB ->
+// 0.2 kB per batch).  A batch whose list did not compress (nr_b == 0, block-uniform) reads the raw list here, one round
+// trip late.  TRAIL: end with a barrier (for callers that overwrite the region before their next barrier).
+template <bool RUNS, int SPT, int BLOCK, bool TRAIL = false>
+__device__ __forceinline__ void batch_dofs_resolve(const RunWords& rw, const int32_t* __restrict__ ud, int M, int nu_b, int nr_b,
+                                                   int tid, int32_t* __restrict__ s_dofs, int32_t (&mydof)[SPT]) {
+  if constexpr (!RUNS) return;
+  if (nr_b == 0) {
+#pragma unroll
+    for (int r = 0; r < SPT; ++r) {
+      const int s = tid + r * BLOCK;
+      mydof[r] = ud[s < M ? s : 0];
+    }
+    return;
+  }
   if (tid < nr_b) {
-    for (int s = rw.s0; s < rw.s1; ++s) s_dofs[s] = rw.d0 + (s - rw.s0);
+    const int s1 = (tid + 1 < nr_b) ? rw.s1 : nu_b;
+    for (int s = rw.s0; s < s1; ++s) s_dofs[s] = rw.d0 + (s - rw.s0);
   }
   __syncthreads();
 #pragma unroll
@@ -431,6 +265,18 @@ __device__ __forceinline__ void batch_dofs_resolve(const RunWords& rw, int nu_b,
     mydof[r] = s_dofs[s < nu_b ? s : 0];
   }
   if constexpr (TRAIL) __syncthreads();
+}
+
+// Launch a planned kernel compiled for (ORDERED, RUNS): K is a generic lambda taking two std::bool_constant tags.
+template <typename K>
+inline void plan_dispatch(bool ordered, bool runs, K&& k) {
+  if (ordered) {
+    if (runs) k(std::true_type{}, std::true_type{});
+    else k(std::true_type{}, std::false_type{});
+  } else {
+    if (runs) k(std::false_type{}, std::true_type{});
+    else k(std::false_type{}, std::false_type{});
+  }
 }
 
 template <typename T>

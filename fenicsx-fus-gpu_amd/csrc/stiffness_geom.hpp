@@ -101,27 +101,47 @@ __device__ __forceinline__ T column_absdet_at(T ex, const T (&J0)[3], const T (&
   return det < T(0) ? -det : det;
 }
 
-// Stage the 24 vertex coordinates of each cell of the batch in LDS (sX[cell in batch][vertex][axis]):
-// issue the vertex-id loads ...
-template <int VPT, int BLOCK, int CPB>
+// Stage the 24 vertex coordinates of each cell of the batch in LDS (sX[cell in batch][vertex][axis]), entry e = tid + r * BLOCK
+// = (cell in batch) * 24 + vertex * 3 + axis.  Three steps, so that the loads travel with the other loads of the preamble
+// (plan.hpp): (A) with the plan's lists: the vertex id itself, or, for an ORDERED plan, the row of the cell; (B) ORDERED only:
+// row -> vertex id; (C) with the x gather: the coordinate (stage_vertex_coords_issue), stored after the gather was issued.
+template <bool ORDERED, int VPT, int BLOCK, int CPB>
 __device__ __forceinline__ void stage_vertex_ids(const int32_t* __restrict__ x_dofs, const int32_t* __restrict__ order,
                                                  int64_t cell0, int64_t ncell, int tid, int32_t (&vid)[VPT]) {
 #pragma unroll
   for (int r = 0; r < VPT; ++r) {
-    const int e = tid + r * BLOCK;  // entry e = (cell in batch) * 24 + vertex * 3 + axis
+    const int e = tid + r * BLOCK;
     const int c = e / 24, v = (e - c * 24) / 3;
     const bool ok = (e < CPB * 24) && (cell0 + c < ncell);
-    vid[r] = ok ? x_dofs[(order != nullptr ? (int64_t)order[cell0 + c] : cell0 + c) * 8 + v] : 0;
+    const int64_t pc = ok ? cell0 + c : 0;
+    vid[r] = ORDERED ? order[pc] : x_dofs[pc * 8 + (ok ? v : 0)];
   }
 }
-// ... and, once they have arrived, the coordinates themselves.
+template <bool ORDERED, int VPT, int BLOCK, int CPB>
+__device__ __forceinline__ void stage_vertex_ids_of_rows(const int32_t* __restrict__ x_dofs, int tid, int32_t (&vid)[VPT]) {
+  if constexpr (ORDERED) {
+#pragma unroll
+    for (int r = 0; r < VPT; ++r) {
+      const int e = tid + r * BLOCK;
+      const int c = e / 24, v = (e - c * 24) / 3;
+      vid[r] = x_dofs[(int64_t)(uint32_t)vid[r] * 8 + (e < CPB * 24 ? v : 0)];
+    }
+  }
+}
 template <typename T, int VPT, int BLOCK, int CPB>
-__device__ __forceinline__ void stage_vertex_coords(const T* __restrict__ x_g, const int32_t (&vid)[VPT], int tid,
-                                                    T* __restrict__ sX) {
+__device__ __forceinline__ void stage_vertex_coords_issue(const T* __restrict__ x_g, const int32_t (&vid)[VPT], int tid, T (&cv)[VPT]) {
 #pragma unroll
   for (int r = 0; r < VPT; ++r) {
     const int e = tid + r * BLOCK;
-    if (e < CPB * 24) sX[e] = x_g[(int64_t)vid[r] * 3 + e % 3];
+    cv[r] = x_g[(int64_t)vid[r] * 3 + (e < CPB * 24 ? e % 3 : 0)];
+  }
+}
+template <typename T, int VPT, int BLOCK, int CPB>
+__device__ __forceinline__ void stage_vertex_coords_store(const T (&cv)[VPT], int tid, T* __restrict__ sX) {
+#pragma unroll
+  for (int r = 0; r < VPT; ++r) {
+    const int e = tid + r * BLOCK;
+    if (e < CPB * 24) sX[e] = cv[r];
   }
 }
 
@@ -130,7 +150,7 @@ __device__ __forceinline__ void stage_vertex_coords(const T* __restrict__ x_g, c
 // profile of the general kernel (P = 4 fp64: 4 workgroups per CU) and the geometry arithmetic runs in
 // the shadow of the gather.  Without it the factors are formed plane by plane inside the loop (fewest
 // registers: the build for P >= 6).
-template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, bool PREG>
+template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, bool PREG, bool ORDERED, bool RUNS>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_geom_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                                const T* __restrict__ x_g, const int32_t* __restrict__ x_dofs,
@@ -161,43 +181,51 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int64_t cell0 = (int64_t)batch * CPB;
   const int64_t pos = cell0 + lc;  // position in the plan's cell order
   const bool active = (lc < CPB) && (pos < ncell);
-  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
-  const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
-  const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
+  const int32_t* rn = runs + (int64_t)batch * (2 * kPlanMaxRuns);  // read only when RUNS
 
-  if (tid < n2) sD[tid] = dphi[tid];
-  if (tid < n) {
-    sP[tid] = pts[tid];
-    sW[tid] = wts[tid];
-  }
-
+  // ---- round trip 1: everything that depends on the kernel arguments alone (the rules: plan.hpp, "the preamble every planned
+  // kernel shares")
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const T dval = dphi[tid < n2 ? tid : 0];
+  const T pval = pts[tid < n ? tid : 0];
+  const T wval = wts[tid < n ? tid : 0];
   int32_t mydof[SPT];
-  const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<RUNS, SPT, BLOCK>(ud, rn, M, tid, mydof);
   int32_t vid[VPT];
-  stage_vertex_ids<VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
+  stage_vertex_ids<ORDERED, VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
   uint16_t sl[n];
-  T coeff = T(0);
   if (active) {
     const uint16_t* sp = slot + pos * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
-    coeff = cell_constants[cell];
   }
-  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
-  stage_vertex_coords<T, VPT, BLOCK, CPB>(x_g, vid, tid, sX);
+  // ---- round trip 2: what those point to -- (ORDERED: vertex ids and the cell's constant;) x and the vertex coordinates
+  stage_vertex_ids_of_rows<ORDERED, VPT, BLOCK, CPB>(x_dofs, tid, vid);
+  T coeff = T(0);
+  if (active) coeff = cell_constants[plan_row<ORDERED>(row, pos)];
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
+  if (tid < n2) sD[tid] = dval;
+  if (tid < n) {
+    sP[tid] = pval;
+    sW[tid] = wval;
+  }
+  batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
 
   // ---- gather x (as plan_gather_x) with the column geometry formed between its two barriers
   {
     T xv[SPT];
 #pragma unroll
     for (int r = 0; r < SPT; ++r) xv[r] = x[mydof[r]];
+    T cv[VPT];
+    stage_vertex_coords_issue<T, VPT, BLOCK, CPB>(x_g, vid, tid, cv);
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const int s = tid + r * BLOCK;
       if (s < nu_b) sx[s] = xv[r];
     }
+    stage_vertex_coords_store<T, VPT, BLOCK, CPB>(cv, tid, sX);
   }
   __syncthreads();  // x values and vertex coordinates are in LDS
 
@@ -268,9 +296,11 @@ inline hipError_t launch_stiffness_plan_geom(const T* x, const T* cc, T* y, cons
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   const LaunchSignal sig = take_launch_signal(stream);
-  hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG>), dim3((unsigned)v.nbatch),
-                     dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot, dphi, ncell,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig);
+  plan_dispatch(ordered, use_runs, [&](auto o, auto r) {
+    hipLaunchKernelGGL((stiffness_plan_geom_kernel<T, P, CPB, ALIAS, PADLDS, MINW, PREG, decltype(o)::value, decltype(r)::value>),
+                       dim3((unsigned)v.nbatch), dim3(threads), 0, stream, x, cc, y, x_g, x_dofs, pts, wts, v.nu, v.udofs, v.slot,
+                       dphi, ncell, v.order, v.runs, sig);
+  });
   return settle_launch_signal(stream, sig, hipGetLastError());
 }
 

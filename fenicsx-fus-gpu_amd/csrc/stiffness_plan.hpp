@@ -158,7 +158,7 @@ struct PlanOwnAcc {
 // LDS: three cubes per cell (u, f_y, f_z) + the batch's distinct-dof values.  Lifetimes:
 //   x values [load, B2)   u cube [B1, B3)   f_y/f_z [B2, B4)   y partial sums [B3, end)
 // ALIAS: x values live in the f_y region and the y sums in the u region (one more barrier).
-template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, int GPRE>
+template <typename T, int P, int CPB, bool ALIAS, bool PADLDS, int MINW, int GPRE, bool ORDERED, bool RUNS>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     stiffness_plan_kernel(const T* __restrict__ x, const T* __restrict__ cell_constants, T* __restrict__ y,
                           const T* __restrict__ G, const int32_t* __restrict__ nu,
@@ -185,20 +185,18 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int ty = t / n, tz = t - ty * n;
   const int64_t pos = (int64_t)batch * CPB + lc;  // position in the plan's cell order
   const bool active = (lc < CPB) && (pos < ncell);
-  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
-  const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
-  const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
+  const int32_t* rn = runs + (int64_t)batch * (2 * kPlanMaxRuns);  // read only when RUNS
 
-  if (tid < n2) sD[tid] = dphi[tid];
-
-  // ---- issue every HBM load of the batch up front ---------------------------------------------
+  // ---- issue every HBM load of the batch up front (the rules: plan.hpp, "the preamble every planned kernel shares")
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const T dval = dphi[tid < n2 ? tid : 0];
   int32_t mydof[SPT];
-  const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<RUNS, SPT, BLOCK>(ud, rn, M, tid, mydof);
   uint16_t sl[n];
   T g[GPRE][6];
   T coeff = T(0);
+  const int64_t cell = plan_row<ORDERED>(row, pos);  // row of the per-cell arrays
   const T* Gc = G + (cell * Nd + t) * 6;
   if (active) {
     const uint16_t* sp = slot + pos * Nd + t;
@@ -208,7 +206,10 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int ix = 0; ix < GPRE; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
     coeff = cell_constants[cell];
   }
-  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
+  if (tid < n2) sD[tid] = dval;
+  batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
 
   T u[n];
   plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sl, sx, su + lc * S + t, u);
@@ -259,9 +260,11 @@ inline hipError_t launch_stiffness_plan(const T* x, const T* cc, T* y, const T* 
   PlanView v = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   const LaunchSignal sig = take_launch_signal(stream);
-  hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GPRE>), dim3((unsigned)v.nbatch),
-                     dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell, xcd_remap,
-                     ordered ? v.order : nullptr, use_runs ? v.runs : nullptr, sig);
+  plan_dispatch(ordered, use_runs, [&](auto o, auto r) {
+    hipLaunchKernelGGL((stiffness_plan_kernel<T, P, CPB, ALIAS, PADLDS, MINW, GPRE, decltype(o)::value, decltype(r)::value>),
+                       dim3((unsigned)v.nbatch), dim3(threads), 0, stream, x, cc, y, G, v.nu, v.udofs, v.slot, dphi, ncell,
+                       xcd_remap, v.order, v.runs, sig);
+  });
   return settle_launch_signal(stream, sig, hipGetLastError());
 }
 

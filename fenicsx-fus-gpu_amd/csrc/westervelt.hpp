@@ -31,7 +31,7 @@ namespace fus {
 // collocation the mass operator is diagonal, M(c) x = diag(M(c) 1) x, so a driver can precompute the two
 // diagonals once and apply the mass terms pointwise in its vector kernel (fus_rk4_stage_nl2_*): no
 // detJ stream, no second atomic flush and no extra barriers in the cell pass.
-template <typename T, int P, int CPB, int MINW, int GPRE, bool MASS = true>
+template <typename T, int P, int CPB, int MINW, int GPRE, bool MASS, bool ORDERED, bool RUNS>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     westervelt_cell_kernel(const T* __restrict__ u_in, const T* __restrict__ v_in, const T* __restrict__ c2,
                            const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
@@ -70,20 +70,19 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int ty = t / n, tz = t - ty * n;
   const int64_t pos = (int64_t)batch * CPB + lc;  // position in the plan's cell order
   const bool active = (lc < CPB) && (pos < ncell);
-  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;  // row of the per-cell arrays
-  const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
-  const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
+  const int32_t* rn = runs + (int64_t)batch * (2 * kPlanMaxRuns);  // read only when RUNS
 
-  if (tid < n2) sD[tid] = dphi[tid];
-
+  // ---- issue every HBM load of the batch up front (the rules: plan.hpp, "the preamble every planned kernel shares")
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const T dval = dphi[tid < n2 ? tid : 0];
   int32_t mydof[SPT];
-  const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<RUNS, SPT, BLOCK>(ud, rn, M, tid, mydof);
   uint16_t sl[n];
   T g[GPRE][6];
   T dj[n];
   T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
+  const int64_t cell = plan_row<ORDERED>(row, pos);  // row of the per-cell arrays
   const T* Gc = G + (cell * Nd + t) * 6;
   if (active) {
     const uint16_t* sp = slot + pos * Nd + t;
@@ -101,7 +100,10 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     k3 = c3[cell];
     k4 = c4[cell];
   }
-  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
+  if (tid < n2) sD[tid] = dval;
+  batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
   {
     T xu[SPT], xv[SPT];
 #pragma unroll
@@ -223,9 +225,11 @@ inline hipError_t launch_westervelt_cell(const T* u, const T* v, const T* c2, co
   // stiffness-only: the ring sizes of the stiffness kernel (its register profile + one more gather)
   constexpr int RING = MASS ? westervelt_g_ring<P>() : (P >= 6 ? plan_g_ring<P>() : P + 1);
   const LaunchSignal sig = take_launch_signal(stream);
-  hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, RING, MASS>), dim3((unsigned)pv.nbatch),
-                     dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs, pv.slot, dphi, ncell,
-                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr, sig);
+  plan_dispatch(ordered, use_runs, [&](auto o, auto r) {
+    hipLaunchKernelGGL((westervelt_cell_kernel<T, P, CPB, MINW, RING, MASS, decltype(o)::value, decltype(r)::value>),
+                       dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, G, detJ, pv.nu, pv.udofs,
+                       pv.slot, dphi, ncell, pv.order, pv.runs, sig);
+  });
   return settle_launch_signal(stream, sig, hipGetLastError());
 }
 

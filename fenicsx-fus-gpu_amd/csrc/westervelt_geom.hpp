@@ -10,7 +10,7 @@
 
 namespace fus {
 
-template <typename T, int P, int CPB, int MINW, bool MASS = true>
+template <typename T, int P, int CPB, int MINW, bool MASS, bool ORDERED, bool RUNS>
 __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     westervelt_cell_geom_kernel(const T* __restrict__ u_in, const T* __restrict__ v_in, const T* __restrict__ c2,
                                 const T* __restrict__ c3, const T* __restrict__ c4, const T* __restrict__ c5,
@@ -52,28 +52,30 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int64_t cell0 = (int64_t)batch * CPB;
   const int64_t pos = cell0 + lc;
   const bool active = (lc < CPB) && (pos < ncell);
-  const int64_t cell = (order != nullptr && active) ? (int64_t)order[pos] : pos;
-  const int packed = nu[batch];
-  const int nu_b = packed & 0xffff, nr_b = plan_runs_of(packed, runs);
   const int32_t* ud = udofs + (int64_t)batch * M;
-  const int32_t* rn = runs != nullptr ? runs + (int64_t)batch * (2 * kPlanMaxRuns) : nullptr;
+  const int32_t* rn = runs + (int64_t)batch * (2 * kPlanMaxRuns);  // read only when RUNS
 
-  if (tid < n2) sD[tid] = dphi[tid];
-  if (tid < n) {
-    sP[tid] = pts[tid];
-    sW[tid] = wts[tid];
-  }
-
+  // ---- round trip 1: everything that depends on the kernel arguments alone (the rules: plan.hpp, "the preamble every planned
+  // kernel shares")
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const T dval = dphi[tid < n2 ? tid : 0];
+  const T pval = pts[tid < n ? tid : 0];
+  const T wval = wts[tid < n ? tid : 0];
   int32_t mydof[SPT];
-  const RunWords rt = batch_dofs_issue<SPT, BLOCK>(ud, rn, M, nu_b, nr_b, tid, mydof);
+  const RunWords rt = batch_dofs_issue<RUNS, SPT, BLOCK>(ud, rn, M, tid, mydof);
   int32_t vid[VPT];
-  stage_vertex_ids<VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
+  stage_vertex_ids<ORDERED, VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
   uint16_t sl[n];
-  T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
   if (active) {
     const uint16_t* sp = slot + pos * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+  }
+  // ---- round trip 2: what those point to -- (ORDERED: vertex ids and the cell's constants;) u, v and the vertex coordinates
+  stage_vertex_ids_of_rows<ORDERED, VPT, BLOCK, CPB>(x_dofs, tid, vid);
+  T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
+  if (active) {
+    const int64_t cell = plan_row<ORDERED>(row, pos);
     if constexpr (MASS) {
       k2 = c2[cell];
       k5 = c5[cell];
@@ -81,8 +83,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     k3 = c3[cell];
     k4 = c4[cell];
   }
-  batch_dofs_resolve<SPT, BLOCK>(rt, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
-  stage_vertex_coords<T, VPT, BLOCK, CPB>(x_g, vid, tid, sX);
+  const int packed = nu[batch];
+  const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
+  if (tid < n2) sD[tid] = dval;
+  if (tid < n) {
+    sP[tid] = pval;
+    sW[tid] = wval;
+  }
+  batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
   {
     T xu[SPT], xv[SPT];
 #pragma unroll
@@ -90,6 +98,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       xu[r] = u_in[mydof[r]];
       xv[r] = v_in[mydof[r]];
     }
+    T cv[VPT];
+    stage_vertex_coords_issue<T, VPT, BLOCK, CPB>(x_g, vid, tid, cv);
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const int s = tid + r * BLOCK;
@@ -98,6 +108,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
         sxv[s] = xv[r];
       }
     }
+    stage_vertex_coords_store<T, VPT, BLOCK, CPB>(cv, tid, sX);
   }
   __syncthreads();  // B1: u / v values and vertex coordinates are in LDS
 
@@ -198,9 +209,11 @@ inline hipError_t launch_westervelt_cell_geom(const T* u, const T* v, const T* c
   PlanView pv = plan_view(const_cast<void*>(workspace), P, CPB, ncell);
   constexpr int threads = col_block_threads<P, CPB>();
   const LaunchSignal sig = take_launch_signal(stream);
-  hipLaunchKernelGGL((westervelt_cell_geom_kernel<T, P, CPB, 1, MASS>), dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u,
-                     v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, pv.nu, pv.udofs, pv.slot, dphi, ncell,
-                     ordered ? pv.order : nullptr, use_runs ? pv.runs : nullptr, sig);
+  plan_dispatch(ordered, use_runs, [&](auto o, auto r) {
+    hipLaunchKernelGGL((westervelt_cell_geom_kernel<T, P, CPB, 1, MASS, decltype(o)::value, decltype(r)::value>),
+                       dim3((unsigned)pv.nbatch), dim3(threads), 0, stream, u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, pv.nu,
+                       pv.udofs, pv.slot, dphi, ncell, pv.order, pv.runs, sig);
+  });
   return settle_launch_signal(stream, sig, hipGetLastError());
 }
 

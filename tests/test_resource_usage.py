@@ -1,6 +1,6 @@
 """Pins the register allocation of the shipped kernel builds (an edit next to
 the product template silently cost the default P = 4 build one workgroup per CU).  hipcc
-cross-compiles gfx950 without a GPU; one device-only compile of csrc/fus_gpu.hip (~45 s, cached
+cross-compiles gfx950 without a GPU; one device-only compile of the library's translation units (in parallel, ~1 min, cached
 under csrc/_asm while the sources are unchanged) yields every kernel's VGPR / scratch / occupancy.
 
 The bounds are the allocation steps of gfx950 (512 registers per SIMD lane, granule 8:
@@ -33,34 +33,36 @@ def _find(table, pattern):
     return hits[0][1]
 
 
-# (kernel regex, max VGPRs, min waves per SIMD) of the builds the auto dispatch of csrc/fus_gpu.hip picks
+# (kernel regex, max VGPRs, min waves per SIMD) of the builds the auto dispatch of the library picks (csrc/dispatch_*.hip, fus_gpu.hip).
+# The last two template arguments of the planned cell kernels are (ORDERED, RUNS) (csrc/plan.hpp): pinned here for an un-ordered plan
+# and the list encoding the auto dispatch reads (run tables: fp64 always, fp32 up to P = 4); test_ordered_and_list_variants has the rest
 SHIPPED = [
     # general-G planned stiffness: P <= 3 build 0, P = 4 / 5 build 1 (LDS-aliased), P >= 6 build 2 (G ring)
-    (r"stiffness_plan_kernel<double, 2, 28, false, true, 1, 3>", 128, 4),
-    (r"stiffness_plan_kernel<double, 4, 10, true, true, 1, 5>", 128, 4),   # the headline kernel
-    (r"stiffness_plan_kernel<double, 6, 5, true, true, 1, 4>", 168, 3),
-    (r"stiffness_plan_kernel<float, 2, 28, false, true, 5, 3>", 96, 5),
-    (r"stiffness_plan_kernel<float, 4, 10, false, true, 5, 5>", 96, 5),
-    (r"stiffness_plan_kernel<float, 6, 5, true, true, 1, 4>", 96, 4),   # 4 by LDS: fp32 sums are kept in double
+    (r"stiffness_plan_kernel<double, 2, 28, false, true, 1, 3, false, true>", 128, 4),
+    (r"stiffness_plan_kernel<double, 4, 10, true, true, 1, 5, false, true>", 128, 4),   # the headline kernel
+    (r"stiffness_plan_kernel<double, 6, 5, true, true, 1, 4, false, true>", 168, 3),
+    (r"stiffness_plan_kernel<float, 2, 28, false, true, 5, 3, false, true>", 96, 5),
+    (r"stiffness_plan_kernel<float, 4, 10, false, true, 5, 5, false, true>", 96, 5),
+    (r"stiffness_plan_kernel<float, 6, 5, true, true, 1, 4, false, false>", 96, 4),   # 4 by LDS: fp32 sums are kept in double
     # high degrees: the ring of G slabs keeps P = 9 at three waves per SIMD (ring of 1: 165 VGPRs); P = 10 is bound by its LDS (66 kB per
     # workgroup of two cells: 2 workgroups per CU whatever the registers do), see test_high_degree_builds
-    (r"stiffness_plan_kernel<double, 8, 3, true, false, 1, 2>", 168, 3),
-    (r"stiffness_plan_kernel<double, 9, 2, true, true, 1, 1>", 168, 3),
-    (r"westervelt_cell_kernel<double, 9, 2, 1, 1, false>", 168, 3),
+    (r"stiffness_plan_kernel<double, 8, 3, true, false, 1, 2, false, true>", 168, 3),
+    (r"stiffness_plan_kernel<double, 9, 2, true, true, 1, 1, false, true>", 168, 3),
+    (r"westervelt_cell_kernel<double, 9, 2, 1, 1, false, false, true>", 168, 3),
     # in-kernel geometry
-    (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true>", 128, 4),
-    (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, 1, false>", 168, 3),
-    (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, 1, true>", 96, 5),
-    (r"westervelt_cell_geom_kernel<double, 6, 5, 1, false>", 168, 3),
+    (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true, false, true>", 128, 4),
+    (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, 1, false, false, true>", 168, 3),
+    (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, 1, true, false, true>", 96, 5),
+    (r"westervelt_cell_geom_kernel<double, 6, 5, 1, false, false, true>", 168, 3),
     # affine fast path
-    (r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>", 96, 5),
-    (r"stiffness_plan_affine_kernel<double, 6, 5, true, true, 1>", 168, 3),
+    (r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5, false, true>", 96, 5),
+    (r"stiffness_plan_affine_kernel<double, 6, 5, true, true, 1, false, true>", 168, 3),
     # fused Westervelt cell pass
-    (r"westervelt_cell_kernel<double, 4, 10, 1, 3, true>", 128, 4),
-    (r"westervelt_cell_kernel<double, 6, 5, 1, 4, true>", 168, 3),
-    (r"westervelt_cell_kernel<double, 6, 5, 1, 4, false>", 168, 3),   # BASELINE config 5: what the solver runs
-    (r"westervelt_cell_kernel<double, 4, 10, 1, 5, false>", 128, 4),
-    (r"westervelt_cell_kernel<float, 4, 10, 1, 3, true>", 96, 4),
+    (r"westervelt_cell_kernel<double, 4, 10, 1, 3, true, false, true>", 128, 4),
+    (r"westervelt_cell_kernel<double, 6, 5, 1, 4, true, false, true>", 168, 3),
+    (r"westervelt_cell_kernel<double, 6, 5, 1, 4, false, false, true>", 168, 3),   # BASELINE config 5: what the solver runs
+    (r"westervelt_cell_kernel<double, 4, 10, 1, 5, false, false, true>", 128, 4),
+    (r"westervelt_cell_kernel<float, 4, 10, 1, 3, true, false, true>", 96, 4),
     # atomic-free mass apply (transposed dofmap): latency-bound unless eight waves per SIMD are resident
     (r"mass_gather_kernel<double, 1, true, 2, false>", 64, 8),
     (r"mass_gather_kernel<float, 1, true, 4, false>", 64, 8),
@@ -87,10 +89,24 @@ def test_shipped_build_occupancy(table, pattern, max_vgpr, min_occ):
     assert d["occupancy"] >= min_occ, f"{pattern}: {d['occupancy']} waves/SIMD < {min_occ}"
 
 
+def test_ordered_and_list_variants(table):
+    """Every (ORDERED, RUNS) shape of the fp64 P = 4 kernels keeps the occupancy of the pinned one -- except the list encoding of the
+    general-G kernel, which fp64 launches read only under the FUS_TUNE_PLAN_RUNS = 0 A/B knob (its five list words stay live across the
+    G loads: 129 VGPRs)."""
+    for o in ("false", "true"):
+        for r in ("false", "true"):
+            for pat, lim, occ in ((rf"stiffness_plan_kernel<double, 4, 10, true, true, 1, 5, {o}, {r}>", 128 if r == "true" else 136, 4 if r == "true" else 3),
+                                  (rf"stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true, {o}, {r}>", 128, 4),
+                                  (rf"westervelt_cell_kernel<double, 4, 10, 1, 3, true, {o}, {r}>", 128, 4),
+                                  (rf"westervelt_cell_kernel<double, 4, 10, 1, 5, false, {o}, {r}>", 128, 4)):
+                d = _find(table, pat)
+                assert d["vgpr"] <= lim and d["occupancy"] >= occ and d["scratch"] == 0, (pat, d)
+
+
 def test_no_scratch(table):
     """No shipped kernel spills, except the one measured build that trades a 20-byte spill for a fifth
     wave per SIMD (affine P = 4 fp64: +8 %, profiles/r01f_affine_fast_path.log)."""
-    allowed = {r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5>": 32}
+    allowed = {r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5, (true|false), (true|false)>": 32}
     bad = []
     for name, d in table.items():
         if "rocprim::" in name:  # the radix sort / scan of the gather plan's one-off build (hipCUB, set-up path): not ours to tune
@@ -105,14 +121,14 @@ def test_high_degree_builds(table):
     """VERDICT r4 item 6 (second half): P = 9 runs at three waves per SIMD (165 VGPRs with a ring of ONE G slab); what limits P = 10
     is LDS, not registers: three cubes of two 11^3 cells are 66 kB, so a CU holds 2 workgroups = 2 waves per SIMD even at 168 VGPRs
     (one cell per workgroup would be 33 kB and 4 workgroups of 2 waves: the same 8 waves per CU)."""
-    p9 = _find(table, r"stiffness_plan_kernel<double, 9, 2, true, true, 1, 1>")
+    p9 = _find(table, r"stiffness_plan_kernel<double, 9, 2, true, true, 1, 1, false, true>")
     assert p9["vgpr"] <= 168 and p9["occupancy"] >= 3 and 3 * p9["lds"] <= 160 * 1024
-    p10 = _find(table, r"stiffness_plan_kernel<double, 10, 2, true, true, 1, 6>")
+    p10 = _find(table, r"stiffness_plan_kernel<double, 10, 2, true, true, 1, 6, false, true>")
     assert p10["scratch"] == 0 and 2 * p10["lds"] <= 160 * 1024 < 3 * p10["lds"]  # LDS admits two workgroups per CU, not three
     assert p10["occupancy"] >= 2
 
 
 def test_headline_kernel_lds_allows_four_workgroups(table):
-    d = _find(table, r"stiffness_plan_kernel<double, 4, 10, true, true, 1, 5>")
+    d = _find(table, r"stiffness_plan_kernel<double, 4, 10, true, true, 1, 5, false, true>")
     assert 4 * d["lds"] <= 160 * 1024
     assert d["sgpr"] <= 80  # 8 blocks/CU admission limit of the SGPR file is not the binding one

@@ -43,14 +43,27 @@ def parse(text):
     return dict(zip(demangle(names), vals))
 
 
-def compile_remarks(source="fus_gpu.hip", extra=()):
-    """Device-only compile of ``source`` with resource-usage remarks; returns the remark text."""
-    cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffp-contract=fast",
-           "-fno-slp-vectorize", "--cuda-device-only", "-c", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", *extra, source]
-    r = subprocess.run(cmd, cwd=CSRC, capture_output=True, text=True)
-    if r.returncode != 0:
-        raise RuntimeError(f"hipcc failed:\n{r.stderr[-4000:]}")
-    return r.stderr
+# the translation units of libfusgpu.so (csrc/Makefile): (source, defines)
+UNITS = [("fus_gpu.hip", ())] + [(f"{d}.hip", (f"-DFUS_INST_T={t}",)) for d in ("dispatch_stiffness_plan", "dispatch_geometry", "dispatch_westervelt")
+                                   for t in ("double", "float")]
+
+
+def compile_remarks(source=None, extra=()):
+    """Device-only compile with resource-usage remarks of ``source`` (default: every translation unit of the library, in parallel);
+    returns the remark text."""
+    units = UNITS if source is None else [(source, ())]
+    procs = []
+    for src, defs in units:
+        cmd = [HIPCC, "-O3", "-std=c++17", "--offload-arch=gfx950", "-munsafe-fp-atomics", "-ffp-contract=fast", "-fno-slp-vectorize",
+               "--cuda-device-only", "-c", "-o", "/dev/null", "-Rpass-analysis=kernel-resource-usage", *defs, *extra, src]
+        procs.append((cmd, subprocess.Popen(cmd, cwd=CSRC, stdout=subprocess.PIPE, stderr=subprocess.PIPE, text=True)))
+    text = ""
+    for cmd, p in procs:
+        _, err = p.communicate()
+        if p.returncode != 0:
+            raise RuntimeError(f"{' '.join(cmd)} failed:\n{err[-4000:]}")
+        text += err
+    return text
 
 
 def cached_remarks():
