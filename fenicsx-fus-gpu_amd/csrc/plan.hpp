@@ -180,27 +180,62 @@ inline PlanView plan_view(void* workspace, int P, int cpb, int64_t ncell) {
 constexpr int kPlanMaxEntries = 4096;  // per batch; slot ids are 16-bit, keys live in LDS
 
 // ---- the preamble every planned kernel shares ------------------------------------------------------------------------
-// A workgroup lives ~9 us, and a global load under load costs ~1.3 us: the preamble must be TWO round trips deep (the plan's
-// lists and per-cell data; then what they point to: x and, with in-kernel geometry, the vertex coordinates), not one per
-// array.  The compiler keeps program order across exec-masked blocks and waits (vmcnt counts in order: for EVERY older load)
-// at the first USE of a loaded register, so the rules are: (1) no load whose value is used inside the conditional block it
-// was issued in (an LDS store of a table, the sign extension of an index); tables are loaded with clamped indices into
-// registers and stored later; (2) nothing in the issue phase depends on nu[batch]; (3) what is uniform over the LAUNCH -- the
-// plan carries a cell order (ORDERED), the launch reads the run tables (RUNS) -- is a template parameter, not a pointer test:
-// a runtime select would make every launch wait for the order load, and the two list encodings would share one wait
-// (profiles/r05p_ablate_geom_phases.log: 8 serial round trips -> 2, in-kernel-geometry kernel -3.6 %).
-
+// A workgroup lives ~9 us and a global load under load costs ~1.3 us: the preamble must be TWO round trips deep (the plan's lists and
+// per-cell data; then what they point to: x and, with in-kernel geometry, the vertex coordinates), not one per array -- and nothing
+// may wait for the G slab before the x gather is on its way.  The compiler waits at the first USE of a loaded register, vmcnt counts in
+// order (a wait for one load is a wait for EVERY older one), and after an exec-masked block its counts are the minimum over both paths
+// (a later wait for an OLD load then waits for nearly every younger one as well).  Hence the rules (phase clocks of the kernel before:
+// profiles/r05p_ablate_geom_phases.log, 54 % of a workgroup's life before its first barrier; A/B: profiles/r05q_*, r05s_*, r05t_*):
+//  (1) no load whose value is used inside the conditional block it was issued in (an LDS store of a table, the sign extension of an
+//      index): tables are loaded with clamped indices into registers and stored later, by every thread (plan_table_store);
+//  (2) nothing in the issue phase depends on nu[batch] (the run words are read speculatively, batch_dofs_issue);
+//  (3) what is uniform over the LAUNCH -- the plan carries a cell order (ORDERED), the launch reads the run tables (RUNS) -- is a
+//      template parameter, not a pointer test: a runtime select would make every launch wait for the order load, and the two list
+//      encodings would share one wait (the library is several objects compiled in parallel for it: Makefile);
+//  (4) every thread issues the preamble's loads, no exec-masked block around them.  A thread without a column of its own (the spare
+//      threads of the block; the ragged last batch) loads what the last valid cell of the batch loads anyway (plan_load_pos): the same
+//      lines, no HBM traffic of its own;
+//  (5) the 16-bit slots are loaded as 32-bit words and narrowed (their first use) after the x gather has been issued (PlanSlotWord);
+//  (6) where the compiler would sink a load into the conditional block of its only use, an empty asm pins it (batch_dofs_resolve).
+// (4)-(5) hold up to degree 6.  From degree 7 on the loads stay under ``active`` and the slots are narrowed where they are loaded: the
+// G slab is a ring of one or two planes there (little in flight to wait for), and the unconditional forms cost registers the P = 9
+// kernels do not have (169 VGPRs, +46 spilled SGPRs: their third wave per SIMD).
+template <int n>
+__host__ __device__ constexpr bool plan_loads_by_all() {
+  return n <= 7;
+}
+template <int CPB>
+__device__ __forceinline__ int64_t plan_load_pos(int64_t cell0, int lc, int64_t ncell) {
+  const int64_t p = cell0 + (lc < CPB ? lc : CPB - 1);
+  return p < ncell ? p : ncell - 1;
+}
 // Row of the per-cell arrays of the cell at position ``pos`` of the plan's order.  Issue: unsigned, so that widening it later is
 // no use of the loaded register (a sign extension would be hoisted to the load and wait for it).
 template <bool ORDERED>
-__device__ __forceinline__ uint32_t plan_row_issue(const int32_t* __restrict__ order, int64_t pos, bool active) {
-  if constexpr (ORDERED) return (uint32_t)order[active ? pos : 0];
+__device__ __forceinline__ uint32_t plan_row_issue(const int32_t* __restrict__ order, int64_t pos) {
+  if constexpr (ORDERED) return (uint32_t)order[pos];
   return 0u;
 }
 template <bool ORDERED>
 __device__ __forceinline__ int64_t plan_row(uint32_t row, int64_t pos) {
   if constexpr (ORDERED) return (int64_t)row;
   return pos;
+}
+
+// Rule (5): the word a slot is loaded into.
+template <int n>
+using PlanSlotWord = std::conditional_t<plan_loads_by_all<n>(), uint32_t, uint16_t>;
+
+// Rule (1): store of a small table (dphi, the GLL points / weights) whose entries the first COUNT threads loaded in the preamble, by
+// EVERY thread (the others into the spare entry table[COUNT]): under a condition the compiler sinks the load into the block with the
+// store, behind every load issued since and a full wait.
+template <int n, int COUNT, typename T>
+__device__ __forceinline__ void plan_table_store(T* __restrict__ table, int tid, T v) {
+  if constexpr (plan_loads_by_all<n>()) {
+    table[tid < COUNT ? tid : COUNT] = v;
+  } else {
+    if (tid < COUNT) table[tid] = v;
+  }
 }
 
 // Distinct dofs owned by this thread (slots tid, tid + BLOCK, ...), for both plan encodings.
@@ -240,21 +275,23 @@ __device__ __forceinline__ int plan_runs_of(int packed) {
 // else uses until the next barrier of the caller -- every kernel passes a cube that is written only after its gather), one
 // barrier, every thread reads its slots.  A run is <= a few dozen consecutive dofs, so the serial expansion by <= 128
 // threads is a fraction of a microsecond; what it buys is 8 bytes per RUN instead of 4 per DOF in HBM (P = 4: 4.1 kB ->
-// 0.2 kB per batch).  A batch whose list did not compress (nr_b == 0, block-uniform) reads the raw list here, one round
-// trip late.  TRAIL: end with a barrier (for callers that overwrite the region before their next barrier).
+// 0.2 kB per batch).  TRAIL: end with a barrier (for callers that overwrite the region before their next barrier).
 template <bool RUNS, int SPT, int BLOCK, bool TRAIL = false>
-__device__ __forceinline__ void batch_dofs_resolve(const RunWords& rw, const int32_t* __restrict__ ud, int M, int nu_b, int nr_b,
-                                                   int tid, int32_t* __restrict__ s_dofs, int32_t (&mydof)[SPT]) {
+__device__ __forceinline__ void batch_dofs_resolve(RunWords rw, const int32_t* __restrict__ ud, int M, int nu_b, int nr_b, int tid,
+                                                   int32_t* __restrict__ s_dofs, int32_t (&mydof)[SPT]) {
   if constexpr (!RUNS) return;
+  // rule (6): an unconditional (empty) use of the run words; without it the compiler sinks their loads into the ``tid < nr_b`` block
+  // below, i.e. behind every load the kernel has issued since, with a full wait
+  asm volatile("" : "+v"(rw.d0), "+v"(rw.s0), "+v"(rw.s1));
   if (nr_b == 0) {
+    // a batch whose list did not compress: its raw list goes through the same LDS region, one round trip late (were it loaded straight
+    // into ``mydof``, the x gather of EVERY batch would wait on the merged state of both paths: for all its outstanding loads)
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const int s = tid + r * BLOCK;
-      mydof[r] = ud[s < M ? s : 0];
+      if (s < nu_b) s_dofs[s] = ud[s];
     }
-    return;
-  }
-  if (tid < nr_b) {
+  } else if (tid < nr_b) {
     const int s1 = (tid + 1 < nr_b) ? rw.s1 : nu_b;
     for (int s = rw.s0; s < s1; ++s) s_dofs[s] = rw.d0 + (s - rw.s0);
   }

@@ -20,7 +20,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   constexpr int n = Sh::n, n2 = Sh::n2, Nd = Sh::Nd, S = Sh::S, BLOCK = Sh::BLOCK, M = Sh::M, SPT = Sh::SPT;
   launch_signal_publish(sig);
 
-  __shared__ T sD[n2];
+  __shared__ T sD[n2 + 1];  // + 1: plan_table_store
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
@@ -39,19 +39,21 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int32_t* rn = runs + (int64_t)batch * (2 * kPlanMaxRuns);  // read only when RUNS
 
   // ---- issue every HBM load of the batch up front (the rules: plan.hpp, "the preamble every planned kernel shares")
-  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const int64_t pos_ld = plan_load_pos<CPB>((int64_t)batch * CPB, lc, ncell);
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos_ld);
   const T dval = dphi[tid < n2 ? tid : 0];
   int32_t mydof[SPT];
   const RunWords rt = batch_dofs_issue<RUNS, SPT, BLOCK>(ud, rn, M, tid, mydof);
   uint16_t sl[n];
   T g0[6];
   T wr[n];
+  const int64_t cell = plan_row<ORDERED>(row, pos_ld);  // row of the per-cell arrays
+  PlanSlotWord<n> sraw[n];  // narrowed once the gather is on its way (plan.hpp, PlanSlotWord)
   T coeff = T(0);
-  const int64_t cell = plan_row<ORDERED>(row, pos);  // row of the per-cell arrays
-  if (active) {
-    const uint16_t* sp = slot + pos * Nd + t;
+  if (plan_loads_by_all<n>() || active) {
+    const uint16_t* sp = slot + pos_ld * Nd + t;
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+    for (int ix = 0; ix < n; ++ix) sraw[ix] = sp[ix * n2];
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) wr[ix] = wratio[ix * n2 + t];
     load_g6<T>(G + cell * Nd * 6, g0);
@@ -59,11 +61,11 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   }
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
-  if (tid < n2) sD[tid] = dval;
+  plan_table_store<n, n2>(sD, tid, dval);
   batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
 
   T u[n];
-  plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sl, sx, su + lc * S + t, u);
+  plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sraw, sl, sx, su + lc * S + t, u);
   if constexpr (!ALIAS) plan_zero<T, SPT, BLOCK>(sy, nu_b, tid);
 
   T fx[n];

@@ -163,8 +163,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   launch_signal_publish(sig);
   constexpr int VPT = (CPB * 24 + BLOCK - 1) / BLOCK;  // vertex coordinates staged per thread (1 for P >= 4)
 
-  __shared__ T sD[n2];
-  __shared__ T sP[n], sW[n];
+  __shared__ T sD[n2 + 1];  // + 1: plan_table_store
+  __shared__ T sP[n + 1], sW[n + 1];
   __shared__ T sX[CPB * 24];
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
@@ -186,7 +186,8 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 
   // ---- round trip 1: everything that depends on the kernel arguments alone (the rules: plan.hpp, "the preamble every planned
   // kernel shares")
-  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const int64_t pos_ld = plan_load_pos<CPB>(cell0, lc, ncell);
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos_ld);
   const T dval = dphi[tid < n2 ? tid : 0];
   const T pval = pts[tid < n ? tid : 0];
   const T wval = wts[tid < n ? tid : 0];
@@ -195,22 +196,20 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   int32_t vid[VPT];
   stage_vertex_ids<ORDERED, VPT, BLOCK, CPB>(x_dofs, order, cell0, ncell, tid, vid);
   uint16_t sl[n];
-  if (active) {
-    const uint16_t* sp = slot + pos * Nd + t;
+  if (plan_loads_by_all<n>() || active) {
+    const uint16_t* sp = slot + pos_ld * Nd + t;
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
   }
   // ---- round trip 2: what those point to -- (ORDERED: vertex ids and the cell's constant;) x and the vertex coordinates
   stage_vertex_ids_of_rows<ORDERED, VPT, BLOCK, CPB>(x_dofs, tid, vid);
   T coeff = T(0);
-  if (active) coeff = cell_constants[plan_row<ORDERED>(row, pos)];
+  if (plan_loads_by_all<n>() || active) coeff = cell_constants[plan_row<ORDERED>(row, pos_ld)];
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
-  if (tid < n2) sD[tid] = dval;
-  if (tid < n) {
-    sP[tid] = pval;
-    sW[tid] = wval;
-  }
+  plan_table_store<n, n2>(sD, tid, dval);
+  plan_table_store<n, n>(sP, tid, pval);
+  plan_table_store<n, n>(sW, tid, wval);
   batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
 
   // ---- gather x (as plan_gather_x) with the column geometry formed between its two barriers

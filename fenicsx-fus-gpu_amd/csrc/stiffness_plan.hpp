@@ -53,11 +53,16 @@ __host__ __device__ constexpr int plan_ring_min_waves() {
 // them to the cell's u cube.  Two barriers; on return su is readable by the whole cell.
 template <typename T, int n, int n2, int SPT, int BLOCK>
 __device__ __forceinline__ void plan_gather_x(const T* __restrict__ x, const int32_t (&mydof)[SPT], int nu_b, int tid,
-                                              bool active, const uint16_t (&sl)[n], T* __restrict__ sx,
-                                              T* __restrict__ cu, T (&u)[n]) {
+                                              bool active, const PlanSlotWord<n> (&sraw)[n], uint16_t (&sl)[n], T* __restrict__ sx,
+                                              T* __restrict__ cu, T (&u)[n], T scale = T(1)) {
   T xv[SPT];
 #pragma unroll
   for (int r = 0; r < SPT; ++r) xv[r] = x[mydof[r]];
+  // the slots were loaded as 32-bit words; narrowing them is their first use, and a wait covers every OLDER load as well (the whole G
+  // slab of the general kernel): it must come AFTER the gather is on its way (unpinned, the scheduler hoists it: it frees two registers)
+  __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+  for (int ix = 0; ix < n; ++ix) sl[ix] = (uint16_t)sraw[ix];
 #pragma unroll
   for (int r = 0; r < SPT; ++r) {
     const int s = tid + r * BLOCK;
@@ -67,7 +72,7 @@ __device__ __forceinline__ void plan_gather_x(const T* __restrict__ x, const int
   if (active) {
 #pragma unroll
     for (int ix = 0; ix < n; ++ix) {
-      u[ix] = sx[sl[ix]];
+      u[ix] = scale * sx[sl[ix]];
       cu[ix * n2] = u[ix];
     }
   }
@@ -170,7 +175,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   static_assert(GPRE >= 1 && GPRE <= n, "GPRE: slabs of G held in registers");
   launch_signal_publish(sig);
 
-  __shared__ T sD[n2];
+  __shared__ T sD[n2 + 1];  // + 1: plan_table_store
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
@@ -189,30 +194,31 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int32_t* rn = runs + (int64_t)batch * (2 * kPlanMaxRuns);  // read only when RUNS
 
   // ---- issue every HBM load of the batch up front (the rules: plan.hpp, "the preamble every planned kernel shares")
-  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const int64_t pos_ld = plan_load_pos<CPB>((int64_t)batch * CPB, lc, ncell);
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos_ld);
   const T dval = dphi[tid < n2 ? tid : 0];
   int32_t mydof[SPT];
   const RunWords rt = batch_dofs_issue<RUNS, SPT, BLOCK>(ud, rn, M, tid, mydof);
   uint16_t sl[n];
   T g[GPRE][6];
-  T coeff = T(0);
-  const int64_t cell = plan_row<ORDERED>(row, pos);  // row of the per-cell arrays
+  const int64_t cell = plan_row<ORDERED>(row, pos_ld);  // row of the per-cell arrays
   const T* Gc = G + (cell * Nd + t) * 6;
-  if (active) {
-    const uint16_t* sp = slot + pos * Nd + t;
+  PlanSlotWord<n> sraw[n];  // narrowed once the gather is on its way (plan.hpp, PlanSlotWord)
+  if (plan_loads_by_all<n>() || active) {
+    const uint16_t* sp = slot + pos_ld * Nd + t;
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+    for (int ix = 0; ix < n; ++ix) sraw[ix] = sp[ix * n2];
 #pragma unroll
     for (int ix = 0; ix < GPRE; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
-    coeff = cell_constants[cell];
   }
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
-  if (tid < n2) sD[tid] = dval;
+  plan_table_store<n, n2>(sD, tid, dval);
   batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
 
+  const T coeff = cell_constants[cell];  // with the gather: it scales u there (c K u = K (c u)), so the main loop holds no constant
   T u[n];
-  plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sl, sx, su + lc * S + t, u);
+  plan_gather_x<T, n, n2, SPT, BLOCK>(x, mydof, nu_b, tid, active, sraw, sl, sx, su + lc * S + t, u, coeff);
 
   if constexpr (!ALIAS) plan_zero<T, SPT, BLOCK>(sy, nu_b, tid);  // x values are dead: the buffer becomes the y accumulator
 
@@ -233,9 +239,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       T vx, vy, vz;
       plan_grad_at<T, n, n2>(qx, dphi, u, dy, dz, cu_y, cu_z, vx, vy, vz);
       const T* gq = g[qx % GPRE];
-      fx[qx] = coeff * (gq[0] * vx + gq[1] * vy + gq[2] * vz);
-      cfy[qx * n2] = coeff * (gq[1] * vx + gq[3] * vy + gq[4] * vz);
-      cfz[qx * n2] = coeff * (gq[2] * vx + gq[4] * vy + gq[5] * vz);
+      fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
+      cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
+      cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
       if constexpr (GPRE < n) {
         if (qx + GPRE < n) load_g6<T>(Gc + (int64_t)(qx + GPRE) * n2 * 6, g[qx % GPRE]);
       }

@@ -49,7 +49,7 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
 
   // regions: su (combined input cube, later the b accumulator), sfy (u values, then the m
   // accumulator, later flux y), sfz (v values, later flux z)
-  __shared__ T sD[n2];
+  __shared__ T sD[n2 + 1];  // + 1: plan_table_store
   __shared__ T su[CPB * S];
   __shared__ T sfy[CPB * S];
   __shared__ T sfz[CPB * S];
@@ -74,20 +74,23 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
   const int32_t* rn = runs + (int64_t)batch * (2 * kPlanMaxRuns);  // read only when RUNS
 
   // ---- issue every HBM load of the batch up front (the rules: plan.hpp, "the preamble every planned kernel shares")
-  const uint32_t row = plan_row_issue<ORDERED>(order, pos, active);
+  const int64_t pos_ld = plan_load_pos<CPB>((int64_t)batch * CPB, lc, ncell);
+  const uint32_t row = plan_row_issue<ORDERED>(order, pos_ld);
   const T dval = dphi[tid < n2 ? tid : 0];
   int32_t mydof[SPT];
   const RunWords rt = batch_dofs_issue<RUNS, SPT, BLOCK>(ud, rn, M, tid, mydof);
   uint16_t sl[n];
   T g[GPRE][6];
   T dj[n];
-  T k2 = T(0), k3 = T(0), k4 = T(0), k5 = T(0);
-  const int64_t cell = plan_row<ORDERED>(row, pos);  // row of the per-cell arrays
+  T k2 = T(0), k5 = T(0);
+  const int64_t cell = plan_row<ORDERED>(row, pos_ld);  // row of the per-cell arrays
   const T* Gc = G + (cell * Nd + t) * 6;
-  if (active) {
-    const uint16_t* sp = slot + pos * Nd + t;
+  PlanSlotWord<n> sraw[n];  // narrowed once the gather is on its way (plan.hpp, PlanSlotWord)
+  T k3 = T(0), k4 = T(0);
+  if (plan_loads_by_all<n>() || active) {
+    const uint16_t* sp = slot + pos_ld * Nd + t;
 #pragma unroll
-    for (int ix = 0; ix < n; ++ix) sl[ix] = sp[ix * n2];
+    for (int ix = 0; ix < n; ++ix) sraw[ix] = sp[ix * n2];
     if constexpr (MASS) {
       const T* dc = detJ + cell * Nd + t;
 #pragma unroll
@@ -95,14 +98,14 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       k2 = c2[cell];
       k5 = c5[cell];
     }
-#pragma unroll
-    for (int ix = 0; ix < GPRE; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
     k3 = c3[cell];
     k4 = c4[cell];
+#pragma unroll
+    for (int ix = 0; ix < GPRE; ++ix) load_g6<T>(Gc + (int64_t)ix * n2 * 6, g[ix]);
   }
   const int packed = nu[batch];
   const int nu_b = packed & 0xffff, nr_b = plan_runs_of<RUNS>(packed);
-  if (tid < n2) sD[tid] = dval;
+  plan_table_store<n, n2>(sD, tid, dval);
   batch_dofs_resolve<RUNS, SPT, BLOCK>(rt, ud, M, nu_b, nr_b, tid, reinterpret_cast<int32_t*>(su), mydof);
   {
     T xu[SPT], xv[SPT];
@@ -111,6 +114,9 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
       xu[r] = u_in[mydof[r]];
       xv[r] = v_in[mydof[r]];
     }
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int ix = 0; ix < n; ++ix) sl[ix] = (uint16_t)sraw[ix];
 #pragma unroll
     for (int r = 0; r < SPT; ++r) {
       const int s = tid + r * BLOCK;
