@@ -29,9 +29,10 @@ inline int plan_allow_runs(int ndof_per_entity) {
 template <typename T>
 inline bool plan_use_runs(int ndof_per_entity) {
   const int mode = g_plan_runs.load(std::memory_order_relaxed);
-  // auto: fp64 always (+2..7 % at every degree); fp32 up to P = 4 (+6.5 % at P = 2 and 4, -12 % at P = 6,
-  // where the kernel is not bandwidth-bound): profiles/r02o_ab_run_tables.log, r02y_ab_fp32.log
-  return mode == 2 || (mode == 1 && (sizeof(T) == 8 || ndof_per_entity <= 125));
+  // auto: fp64 always (+4..6 % at every degree); fp32 up to P = 6 (+7..12 % at P = 2, 4, 5, 6; P = 7 equal, P = 8 -6 %).  Before the
+  // run words were read speculatively (plan.hpp, the preamble) the fp32 limit was P = 4 (-12 % at P = 6 then):
+  // profiles/r05x_ab_run_tables.log; r02o_ab_run_tables.log, r02y_ab_fp32.log for the earlier kernels
+  return mode == 2 || (mode == 1 && (sizeof(T) == 8 || ndof_per_entity <= 343));
 }
 inline std::atomic<int> g_plan_variant{-1};  // -1 = auto
 

@@ -35,7 +35,7 @@ def _find(table, pattern):
 
 # (kernel regex, max VGPRs, min waves per SIMD) of the builds the auto dispatch of the library picks (csrc/dispatch_*.hip, fus_gpu.hip).
 # The last two template arguments of the planned cell kernels are (ORDERED, RUNS) (csrc/plan.hpp): pinned here for an un-ordered plan
-# and the list encoding the auto dispatch reads (run tables: fp64 always, fp32 up to P = 4); test_ordered_and_list_variants has the rest
+# and the list encoding the auto dispatch reads (run tables: fp64 always, fp32 up to P = 6); test_ordered_and_list_variants has the rest
 SHIPPED = [
     # general-G planned stiffness: P <= 3 build 0, P = 4 / 5 build 1 (LDS-aliased), P >= 6 build 2 (G ring)
     (r"stiffness_plan_kernel<double, 2, 28, false, true, 1, 3, false, true>", 128, 4),
@@ -43,7 +43,7 @@ SHIPPED = [
     (r"stiffness_plan_kernel<double, 6, 5, true, true, 1, 4, false, true>", 168, 3),
     (r"stiffness_plan_kernel<float, 2, 28, false, true, 5, 3, false, true>", 96, 5),
     (r"stiffness_plan_kernel<float, 4, 10, false, true, 5, 5, false, true>", 96, 5),
-    (r"stiffness_plan_kernel<float, 6, 5, true, true, 1, 4, false, false>", 128, 4),   # 4 by LDS (fp32 sums are kept in double): 98 VGPRs cost nothing
+    (r"stiffness_plan_kernel<float, 6, 5, true, true, 1, 4, false, true>", 128, 4),   # 4 by LDS (fp32 sums are kept in double): 98 VGPRs cost nothing
     # high degrees: the ring of G slabs keeps P = 9 at three waves per SIMD (ring of 1: 165 VGPRs); P = 10 is bound by its LDS (66 kB per
     # workgroup of two cells: 2 workgroups per CU whatever the registers do), see test_high_degree_builds
     (r"stiffness_plan_kernel<double, 8, 3, true, false, 1, 2, false, true>", 168, 3),
