@@ -35,6 +35,7 @@ def _signatures():
         "fus_plan_build": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_plan_build_ordered": [_vp, _vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_plan_release": [_vp],
+        "fus_plan_encoding": [_vp, C.POINTER(_i64), C.POINTER(_i64), C.POINTER(_int), C.POINTER(_int)],
         "fus_plan_mark_exclusive": [_vp, _int, _int, _i64, _vp, _i64, _vp],
         "fus_mass_gather_plan_bytes": [_int, _i64, _i64],
         "fus_mass_gather_plan_build": [_vp, _int, _i64, _i64, _vp, _i64, _vp],

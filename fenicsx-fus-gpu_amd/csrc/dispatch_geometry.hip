@@ -18,8 +18,8 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   if (ncell == 0) return FUS_OK;
   if (!x || !cc || !y || !G || !wratio || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
+  bool ord = false, rp = true;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
   // P <= 4: unpadded LDS + 5 waves per SIMD (+8 %, profiles/r01f_affine_fast_path.log); above, registers do
@@ -27,7 +27,7 @@ int stiffness_apply_planned_affine(const T* x, const T* cc, T* y, const T* G, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
+    e = fus::launch_stiffness_plan_affine<T, PP, true, (PP > 4), (PP <= 4 ? 5 : 1)>(x, cc, y, G, wratio, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -44,14 +44,14 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   if (ncell == 0) return FUS_OK;
   if (!x || !cc || !y || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
+  bool ord = false, rp = true;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) {
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) {
 #ifdef FUS_EXPERIMENT_GEOM_CPB20
     // EXPERIMENT (tools/exp_geom_tiles.py): a generic plan with 20 cells per batch (2 x 2 x 5 tiles:
     // 85 instead of 103 distinct dofs per cell) takes a 512-thread build of the kernel -- 65 kB of LDS, 2 workgroups per CU
     if constexpr (std::is_same<T, double>::value) {
-      if (P == 4 && plan_check(ws, 125, 20, ncell, &ord))
+      if (P == 4 && plan_check(ws, 125, 20, ncell, &ord, nullptr, &rp))
         return hip_rc(fus::launch_stiffness_plan_geom<T, 4, true, false, 1, true, 20>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, true));
     }
 #endif
@@ -61,7 +61,7 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)

@@ -27,8 +27,8 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
   if (ncell == 0) return FUS_OK;
   if (!x || !cc || !y || !G || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
+  bool ord = false, rp = true;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   const int remap = g_xcd_remap.load(std::memory_order_relaxed);
   hipError_t e = hipErrorInvalidValue;
@@ -53,10 +53,10 @@ int stiffness_apply_planned(const T* x, const T* cc, T* y, const T* G, const voi
 #define FUS_CASE(PP)                                                                                      \
   case PP:                                                                                                \
     switch (pv) {                                                                                         \
-      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break;   \
-      case 2: e = fus::launch_stiffness_plan<T, PP, true, (PP != 8), fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
-      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
-      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); break; \
+      case 1: e = fus::launch_stiffness_plan<T, PP, true, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); break;   \
+      case 2: e = fus::launch_stiffness_plan<T, PP, true, (PP != 8), fus::plan_ring_min_waves<PP>(), fus::plan_g_ring<PP>()>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); break; \
+      case 30: e = launch_plan_f32_5w<T, PP>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); break; \
+      default: e = fus::launch_stiffness_plan<T, PP, false, true, 1>(x, cc, y, G, ws, dphi, ncell, remap, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); break; \
     }                                                                                                     \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)

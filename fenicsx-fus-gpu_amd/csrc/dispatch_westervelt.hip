@@ -20,15 +20,15 @@ int westervelt_cell(const T* u, const T* v, const T* c2, const T* c3, const T* c
   if (!u || !v || !c3 || !c4 || !b || !G || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (mass && (!c2 || !c5 || !m || !detJ)) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(G, 2 * sizeof(T)) || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
+  bool ord = false, rp = true;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))) \
-             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
+    e = mass ? fus::launch_westervelt_cell<T, PP, true>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)) \
+             : fus::launch_westervelt_cell<T, PP, false>(u, v, c2, c3, c4, c5, b, m, G, detJ, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)
@@ -48,15 +48,15 @@ int westervelt_cell_geom(const T* u, const T* v, const T* c2, const T* c3, const
   if (!u || !v || !c3 || !c4 || !b || !x_g || !x_dofs || !pts || !wts || !ws || !dphi) return FUS_ERR_INVALID_ARGUMENT;
   if (mass && (!c2 || !c5 || !m)) return FUS_ERR_INVALID_ARGUMENT;
   if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
-  bool ord = false;
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord)) return FUS_ERR_PLAN_MISMATCH;
+  bool ord = false, rp = true;
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) return FUS_ERR_PLAN_MISMATCH;
   hipStream_t s = static_cast<hipStream_t>(stream);
   hipError_t e = hipErrorInvalidValue;
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))) \
-             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1))); \
+    e = mass ? fus::launch_westervelt_cell_geom<T, PP, true>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)) \
+             : fus::launch_westervelt_cell_geom<T, PP, false>(u, v, c2, c3, c4, c5, b, m, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)

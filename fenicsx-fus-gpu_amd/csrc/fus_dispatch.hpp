@@ -25,10 +25,13 @@ inline int plan_allow_runs(int ndof_per_entity) {
   (void)ndof_per_entity;
   return g_plan_runs.load(std::memory_order_relaxed) != 0;
 }
-// which encoding of the dof lists a launch reads (the plan holds both)
+// which encoding of the dof lists a launch reads (the plan holds both).  ``runs_pay``: at least half of the plan's batches carry a
+// run table -- a numbering whose lists do not compress (Morton, a graph reordering) makes a run-coded launch read every list one round
+// trip late, behind a wasted speculative read of the table (+2..3 %, profiles/r05y_numbering.log)
 template <typename T>
-inline bool plan_use_runs(int ndof_per_entity) {
+inline bool plan_use_runs(int ndof_per_entity, bool runs_pay = true) {
   const int mode = g_plan_runs.load(std::memory_order_relaxed);
+  if (mode == 1 && !runs_pay) return false;
   // auto: fp64 always (+4..6 % at every degree); fp32 up to P = 6 (+7..12 % at P = 2, 4, 5, 6; P = 7 equal, P = 8 -6 %).  Before the
   // run words were read speculatively (plan.hpp, the preamble) the fp32 limit was P = 4 (-12 % at P = 6 then):
   // profiles/r05x_ab_run_tables.log; r02o_ab_run_tables.log, r02y_ab_fp32.log for the earlier kernels
@@ -45,16 +48,18 @@ struct PlanInfo {
   int64_t nent = 0;
   bool ordered = false;
   bool exclusive = false;  // fus_plan_mark_exclusive has run: the plan carries exclusive-dof marks
+  bool runs_pay = true;    // at least half of the batches carry a run table (plan_use_runs)
+  int64_t nbatch = 0, with_runs = 0;
 };
 inline std::mutex g_plans_mu;
 inline std::unordered_map<const void*, PlanInfo> g_plans;
 
-inline void plan_register(const void* ws, int N, int epb, int64_t nent, bool ordered) {
+inline void plan_register(const void* ws, int N, int epb, int64_t nent, bool ordered, int64_t nbatch = 0, int64_t with_runs = 0) {
   std::lock_guard<std::mutex> lk(g_plans_mu);
-  g_plans[ws] = PlanInfo{N, epb, nent, ordered, false};
+  g_plans[ws] = PlanInfo{N, epb, nent, ordered, false, 2 * with_runs >= nbatch, nbatch, with_runs};
 }
 // true if ``ws`` holds a plan for exactly this shape; ``ordered`` out
-inline bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, bool* exclusive = nullptr) {
+inline bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* ordered, bool* exclusive = nullptr, bool* runs_pay = nullptr) {
   std::lock_guard<std::mutex> lk(g_plans_mu);
   auto it = g_plans.find(ws);
   if (it == g_plans.end()) return false;
@@ -62,6 +67,7 @@ inline bool plan_check(const void* ws, int N, int epb, int64_t nent, bool* order
   if (p.N != N || p.epb != epb || p.nent != nent) return false;
   *ordered = p.ordered;
   if (exclusive) *exclusive = p.exclusive;
+  if (runs_pay) *runs_pay = p.runs_pay;
   return true;
 }
 

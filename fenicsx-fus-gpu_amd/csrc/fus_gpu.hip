@@ -100,8 +100,9 @@ int mass_apply_planned(const T* x, const T* consts, T* y, const T* detJ, const v
   if (nent == 0) return FUS_OK;
   if (!x || !consts || !y || !detJ || !ws || misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   bool ord = false, excl = false;
-  if (!plan_check(ws, N, epb, nent, &ord, &excl)) return FUS_ERR_PLAN_MISMATCH;
-  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>(N), excl));
+  bool rp = true;
+  if (!plan_check(ws, N, epb, nent, &ord, &excl, &rp)) return FUS_ERR_PLAN_MISMATCH;
+  return hip_rc(fus::launch_mass_plan<T>(x, consts, y, detJ, ws, N, epb, nent, static_cast<hipStream_t>(stream), ord, plan_use_runs<T>(N, rp), excl));
 }
 
 template <typename T>
@@ -389,7 +390,28 @@ int fus_plan_build_ordered(const int32_t* dofmap, const int32_t* entity_order, i
                                                         static_cast<hipStream_t>(stream), plan_allow_runs(N), entity_order);
     if (e != hipSuccess) return hip_rc(e);
   }
-  plan_register(workspace, N, entities_per_batch, nent, entity_order != nullptr);
+  int64_t nbatch = 0, with_runs = 0;
+  if (nent > 0) {
+    const hipError_t e = fus::plan_run_batches(workspace, static_cast<hipStream_t>(stream), &with_runs);
+    if (e != hipSuccess) return hip_rc(e);
+    nbatch = (nent + entities_per_batch - 1) / entities_per_batch;
+  }
+  plan_register(workspace, N, entities_per_batch, nent, entity_order != nullptr, nbatch, with_runs);
+  return FUS_OK;
+}
+
+int fus_plan_encoding(const void* workspace, int64_t* batches, int64_t* batches_with_runs, int* reads_runs_f64, int* reads_runs_f32) {
+  PlanInfo p;
+  {
+    std::lock_guard<std::mutex> lk(g_plans_mu);
+    auto it = g_plans.find(workspace);
+    if (it == g_plans.end()) return FUS_ERR_PLAN_MISMATCH;
+    p = it->second;
+  }
+  if (batches) *batches = p.nbatch;
+  if (batches_with_runs) *batches_with_runs = p.with_runs;
+  if (reads_runs_f64) *reads_runs_f64 = plan_use_runs<double>(p.N, p.runs_pay) ? 1 : 0;
+  if (reads_runs_f32) *reads_runs_f32 = plan_use_runs<float>(p.N, p.runs_pay) ? 1 : 0;
   return FUS_OK;
 }
 

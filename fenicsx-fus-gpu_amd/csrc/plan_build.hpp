@@ -120,6 +120,14 @@ __global__ void __launch_bounds__(256)
   }
 }
 
+constexpr int kPlanHeaderRunBatches = 56;  // byte offset in the plan header (8th int64 word)
+__global__ void __launch_bounds__(256) plan_count_runs_kernel(const int32_t* __restrict__ nu, int64_t nbatch, unsigned long long* out) {
+  unsigned long long mine = 0;
+  for (int64_t b = (int64_t)blockIdx.x * 256 + threadIdx.x; b < nbatch; b += (int64_t)gridDim.x * 256) mine += (nu[b] >> 16) != 0;
+  for (int o = 32; o > 0; o >>= 1) mine += __shfl_down(mine, o, 64);
+  if ((threadIdx.x & 63) == 0 && mine) atomicAdd(out, mine);
+}
+
 inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int epb, int64_t nent, void* workspace,
                                             hipStream_t stream, int allow_runs = 1,
                                             const int32_t* cell_order = nullptr) {
@@ -128,7 +136,7 @@ inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int ep
   if (M < 1 || M > kPlanMaxEntries) return hipErrorInvalidValue;
   PlanView v = plan_view_generic(workspace, N, epb, nent);
   if (v.nbatch > 0x7fffffffLL) return hipErrorInvalidValue;
-  int64_t hdr[7] = {kPlanMagic, N, epb, nent, v.nbatch, v.entries, cell_order ? 1 : 0};
+  int64_t hdr[8] = {kPlanMagic, N, epb, nent, v.nbatch, v.entries, cell_order ? 1 : 0, 0 /* batches with a run table: plan_count_runs */};
   hipError_t e = hipMemcpyAsync(workspace, hdr, sizeof(hdr), hipMemcpyHostToDevice, stream);
   if (e != hipSuccess) return e;
   const int32_t* order = nullptr;
@@ -153,7 +161,23 @@ inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int ep
   else
     hipLaunchKernelGGL((plan_build_kernel<4096>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,
                        allow_runs, order);
+  e = hipGetLastError();
+  if (e != hipSuccess) return e;
+  hipLaunchKernelGGL(plan_count_runs_kernel, dim3((unsigned)((v.nbatch + 255) / 256 < 1024 ? (v.nbatch + 255) / 256 : 1024)), block, 0, stream,
+                     v.nu, v.nbatch, reinterpret_cast<unsigned long long*>(static_cast<char*>(workspace) + kPlanHeaderRunBatches));
   return hipGetLastError();
+}
+
+// How many batches of a built plan carry a run table (the others kept their raw list: too many runs, or no gain).  Waits for the
+// build on ``stream``; the apply entry points launch the run-coded form of their kernels only for plans where that pays
+// (fus_dispatch.hpp: plan_register).
+inline hipError_t plan_run_batches(const void* workspace, hipStream_t stream, int64_t* out) {
+  unsigned long long c = 0;
+  hipError_t e = hipMemcpyAsync(&c, static_cast<const char*>(workspace) + kPlanHeaderRunBatches, sizeof(c), hipMemcpyDeviceToHost, stream);
+  if (e != hipSuccess) return e;
+  e = hipStreamSynchronize(stream);
+  *out = (int64_t)c;
+  return e;
 }
 
 template <int P>

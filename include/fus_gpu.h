@@ -218,6 +218,12 @@ int fus_plan_mark_exclusive(void* workspace, int ndof_per_entity, int entities_p
                             int32_t* dof_use_count, int64_t ndofs, void* stream);
 /* Forget a workspace (before freeing it): drops its entry of the registry the planned applies check. */
 int fus_plan_release(const void* workspace);
+/* What a built plan holds: its number of batches, how many of them carry a run-length table of their distinct dofs (the
+ * others kept the raw list: more than 128 runs, or no gain), and whether the planned applies will read the run tables
+ * (FUS_TUNE_PLAN_RUNS auto: only for plans where at least half of the batches carry one -- a numbering whose lists do not
+ * compress is read through the lists).  FUS_ERR_PLAN_MISMATCH for a workspace fus_plan_build* has not seen.  No reference
+ * counterpart (its kernels read the dofmap itself, cuda/operators.py:108-125). */
+int fus_plan_encoding(const void* workspace, int64_t* batches, int64_t* batches_with_runs, int* reads_runs_f64, int* reads_runs_f32);
 int fus_mass_apply_planned_f64(const double* x, const double* entity_constants, double* y, const double* entity_detJ,
                                const void* workspace, int ndof_per_entity, int entities_per_batch, int64_t nent,
                                void* stream);

@@ -799,6 +799,49 @@ def test_lists_and_run_tables_of_one_plan(gpu, oracle_c, P, dtype):
         ops._PLANS.clear()
 
 
+def test_plan_encoding_follows_the_numbering(gpu, oracle_c):
+    """``fus_plan_encoding``: a lexicographic numbering compresses into run tables (every batch carries one, fp64 launches read them); a
+    random renumbering of the dofs does not (no batch does), and the auto choice then reads the raw lists -- a run-coded launch would read
+    every list one round trip late.  Same result as the oracle either way, and with the choice forced the other way."""
+    import ctypes
+
+    dev, ops = gpu
+    lib = pkg("_lib")
+    P = 4
+    pb = build_problem(P, (6, 5, 7), perturb=0.16, seed=21)
+    mesh = pb["mesh"]
+    perm = np.random.default_rng(3).permutation(mesh.ndofs).astype(mesh.dofmap.dtype)
+    clib = lib.load()
+    for name, dofmap, xs in (("lexicographic", mesh.dofmap, pb["x"]), ("random", perm[mesh.dofmap], None)):
+        if xs is None:  # x in the new numbering: x_new[perm[d]] = x[d]
+            xs = np.empty_like(pb["x"])
+            xs[perm] = pb["x"]
+        y_ref = np.zeros(mesh.ndofs)
+        oracle_c.stiffness_apply(P, pb["D"], xs, pb["cc"], y_ref, pb["G"], dofmap)
+        x, cc, G, dm = (dev.to_device(a) for a in (xs, pb["cc"], pb["G"], np.ascontiguousarray(dofmap)))
+        op = ops.stiffness_operator(P, pb["D"].flatten(), np.float64)
+        ops._PLANS.clear()
+        try:
+            for mode in (1, 0, 2, 1):
+                lib.set_tuning(lib.TUNE_PLAN_RUNS, mode)
+                y = dev.to_device(np.zeros(mesh.ndofs))
+                op(x, cc, y, G, dm)
+                _check(y.copy_to_host(), y_ref, np.float64, f"{name} numbering, run-table mode {mode}")
+                if mode == 1:
+                    (ws, *_), = [v for k, v in ops._PLANS._plans.items() if k[-1] != "strips"]
+                    nb, nr, r64, r32 = ctypes.c_int64(), ctypes.c_int64(), ctypes.c_int(), ctypes.c_int()
+                    assert clib.fus_plan_encoding(ws.data_ptr(), ctypes.byref(nb), ctypes.byref(nr), ctypes.byref(r64), ctypes.byref(r32)) == 0
+                    assert nb.value == -(-mesh.ncells // 10)
+                    if name == "lexicographic":
+                        assert nr.value == nb.value and r64.value == 1 and r32.value == 1
+                    else:
+                        assert nr.value == 0 and r64.value == 0 and r32.value == 0
+        finally:
+            lib.set_tuning(lib.TUNE_PLAN_RUNS, 1)
+            ops._PLANS.clear()
+    assert clib.fus_plan_encoding(0, None, None, None, None) != 0  # a workspace no plan was built in
+
+
 def test_strip_ordered_plan_opt_in(gpu, oracle_c):
     """``use_strip_order(True)`` (opt-in, measured negative at config 3: docs/history.md section 11): the in-kernel-geometry operator's plan
     takes the two-row strip order when it lowers the distinct dofs per batch -- a second cached plan next to the row-ordered one, cell
