@@ -614,14 +614,15 @@ def test_in_kernel_geometry_full_size_properties(gpu):
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
-@pytest.mark.parametrize("P", [1, 2, 4, 6])
+@pytest.mark.parametrize("P", [1, 2, 3, 4, 5, 6, 8])
 def test_random_cell_order_uses_locality_plan(gpu, oracle_c, P, dtype):
     """A dofmap whose rows are in random order: the plan cache builds the batches in min-dof order (an
     index indirection inside the plan -- G, detJ and the constants are NOT permuted) for every planned
     kernel: stiffness, in-kernel geometry, affine, cell mass, fused Westervelt pass."""
     dev, ops = gpu
     gll = pkg("gll")
-    shape = {1: (8, 6, 5), 2: (5, 4, 5), 4: (4, 3, 5), 6: (3, 2, 3)}[P]  # more than two batches of cells
+    # more than two batches of cells, the last one ragged for P != 4 (its spare threads / missing cells load the last valid cell's lines)
+    shape = {1: (8, 6, 5), 2: (5, 4, 5), 3: (5, 3, 5), 4: (4, 3, 5), 5: (3, 3, 4), 6: (3, 2, 3), 8: (7, 1, 2)}[P]
     pb = build_problem(P, shape, dtype=dtype, perturb=0.2, seed=21)
     mesh = pb["mesh"]
     perm = np.random.default_rng(3).permutation(mesh.ncells)
@@ -663,6 +664,12 @@ def test_random_cell_order_uses_locality_plan(gpu, oracle_c, P, dtype):
                                                               dev.to_device(c4), dev.to_device(c5), b, m, G_d, dJ_d, dm_d)
     _check(b.copy_to_host(), b_ref, dtype, "Westervelt b, ordered plan")
     _check(m.copy_to_host(), m_ref, dtype, "Westervelt m, ordered plan")
+    # ... and with the geometry formed in the kernel (vertex ids through the plan's order: row -> vertex id -> coordinate)
+    b, m = dev.to_device(np.zeros(mesh.ndofs, dtype=dtype)), dev.to_device(np.zeros(mesh.ndofs, dtype=dtype))
+    ops.westervelt_cell_operator(P, pb["D"].flatten(), dtype, geometry=(mesh.x_g, pb["pts"], pb["wts"]))(
+        x_d, dev.to_device(v), dev.to_device(c2), dev.to_device(c3), dev.to_device(c4), dev.to_device(c5), b, m, dev.to_device(xd), dm_d)
+    _check(b.copy_to_host(), b_ref, dtype, "Westervelt b, in-kernel geometry, ordered plan")
+    _check(m.copy_to_host(), m_ref, dtype, "Westervelt m, in-kernel geometry, ordered plan")
     ops._PLANS.clear()
 
 
