@@ -5,7 +5,8 @@ config 5's shape (P = 6, 36^3): distinct dofs per cell and kernel time for
   rows          CPB consecutive cells of a row (the general-G kernels' plan)
   strips        two adjacent rows interleaved (plan_tiles.two_row_strip_order: 2 x 5 pieces at P = 4) -- through the operator
   2x2x5         P = 4 only, 20 cells per batch, 512-thread workgroups, 65 kB of LDS (2 workgroups per CU): needs a library built
-                with -DFUS_EXPERIMENT_GEOM_CPB20 (FUS_LIB_PATH=tools/_bin/libfusgpu_cpb20.so); skipped otherwise
+                with -DFUS_EXPERIMENT_GEOM_CPB20 (a copy of csrc/: ``make -B libfusgpu.so EXTRA_CXXFLAGS=-DFUS_EXPERIMENT_GEOM_CPB20``,
+                then FUS_LIB_PATH=tools/_bin/libfusgpu_cpb20.so); skipped otherwise
 
 Alternating rounds, medians."""
 import argparse
