@@ -89,11 +89,14 @@ __global__ void __launch_bounds__(kGatherThreads)
   int64_t d[R];
   bool live[R];
   T xv[R], acc[R];
+  // the row lengths with a clamped INDEX instead of a predicated load, and selected after x and y have been issued: the compiler
+  // waits inside the block of ``live ? p[r] : 0`` when the value is used there, one round trip per row of the thread
+  uint8_t lraw[R];
 #pragma unroll
   for (int k = 0; k < R; ++k) {
     const int64_t r = r0 + k * kGatherThreads;
     live[k] = r < v.nrows;
-    len[k] = live[k] ? (int)v.len[r] : 0;
+    lraw[k] = v.len[live[k] ? r : v.nrows - 1];
     d[k] = DENSE ? r : (live[k] ? (int64_t)v.rows[r] : 0);
   }
 #pragma unroll
@@ -101,6 +104,8 @@ __global__ void __launch_bounds__(kGatherThreads)
     xv[k] = live[k] ? ld_stream<NT>(x + d[k]) : T(0);
     acc[k] = live[k] ? ld_stream<NT>(y + d[k]) : T(0);
   }
+#pragma unroll
+  for (int k = 0; k < R; ++k) len[k] = live[k] ? (int)lraw[k] : 0;
   // exclusive prefix of len over the workgroup's R * 256 rows (row order: k, wave, lane)
 #pragma unroll
   for (int k = 0; k < R; ++k) incl[k] = len[k];
@@ -213,16 +218,27 @@ __global__ void gather_rows_kernel(const int32_t* keys, const int32_t* flag, con
 __global__ void gather_len_kernel(const int32_t* start, const int32_t* rows, uint8_t* len, int32_t* base, int64_t nrows,
                                   int64_t total, int64_t nblocks, int32_t* stats) {
   const int64_t r = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  int32_t mx = 0;
+  bool sparse = false;
   if (r < nrows) {
     const int64_t nxt = r + 1 < nrows ? start[r + 1] : total;
     const int64_t l = nxt - start[r];
     len[r] = (uint8_t)(l > 255 ? 255 : l);
-    if (l > 255) atomicMax(stats + 0, 1 << 30);
-    atomicMax(stats + 0, (int32_t)(l > 255 ? 255 : l));
-    if (rows[r] != (int32_t)r) atomicMax(stats + 1, 1);
+    mx = l > 255 ? (1 << 30) : (int32_t)l;
+    sparse = rows[r] != (int32_t)r;
     if (r % kGatherThreads == 0) base[r / kGatherThreads] = start[r];
   }
   if (r == 0) base[nblocks] = (int32_t)total;
+  // one atomic per wave (10 M same-address atomics took 1.8 ms of set-up at config 3)
+  for (int o = 32; o > 0; o >>= 1) {
+    const int32_t other = __shfl_down(mx, o, 64);
+    mx = other > mx ? other : mx;
+  }
+  const bool any_sparse = __any(sparse);
+  if ((threadIdx.x & 63) == 0) {
+    if (mx > 0) atomicMax(stats + 0, mx);
+    if (any_sparse) atomicMax(stats + 1, 1);
+  }
 }
 
 // keys of a ROW SUBSET: dofs whose mark is not ``want`` get the sentinel key ``ndofs`` (sorted behind every real dof and dropped);
