@@ -148,6 +148,15 @@ __global__ void __launch_bounds__(kGatherThreads)
 #pragma unroll
     for (int k = 0; k < R; ++k) ebase[k] = gs.ent_base[b * R + k];  // row r0 + k * 256 lies in 256-row block b * R + k
   }
+  // An (empty) unconditional use of the entry ids between their loads and the loads they address: every id is loaded in a predicated
+  // block of its own, and without a wait that ALL paths see the compiler waits again after the first dependent block -- for the first
+  // detJ / constant pair, one round trip before the others are issued.
+  auto pin_entries = [](auto& e) {
+#pragma unroll
+    for (auto& row : e)
+#pragma unroll
+      for (auto& v : row) asm volatile("" : "+v"(v));
+  };
   auto batch = [&](auto bc, int j0) {
     constexpr int B = decltype(bc)::value;
     uint32_t e[R][B];
@@ -162,6 +171,7 @@ __global__ void __launch_bounds__(kGatherThreads)
           e[k][q] = on ? (uint32_t)gs.ent16[beg[k] + j0 + q] : 0u;
           dv[k][q] = on ? ds[beg[k] + j0 + q] : T(0);
         }
+      pin_entries(e);
 #pragma unroll
       for (int k = 0; k < R; ++k)
 #pragma unroll
@@ -171,6 +181,7 @@ __global__ void __launch_bounds__(kGatherThreads)
     for (int k = 0; k < R; ++k)
 #pragma unroll
       for (int q = 0; q < B; ++q) e[k][q] = j0 + q < len[k] ? (uint32_t)v.entries[beg[k] + j0 + q] : 0u;
+    pin_entries(e);
 #pragma unroll
     for (int k = 0; k < R; ++k)
 #pragma unroll
