@@ -207,6 +207,13 @@ __device__ inline float ipc_load_elem<float>(const float* p) {
   return __uint_as_float(u);
 }
 
+// an empty, unconditional use of loaded values (keeps their loads where they were issued)
+template <typename V, int N>
+__device__ __forceinline__ void ipc_pin(V (&a)[N]) {
+#pragma unroll
+  for (int k = 0; k < N; ++k) asm volatile("" : "+v"(a[k]));
+}
+
 // GATHER: element i of the message is vec[index[i] + offset]; otherwise vec[offset + i] (ghosts numbered owner by owner)
 template <typename T, bool GATHER>
 __global__ void __launch_bounds__(kIpcMaxThreads)
@@ -223,19 +230,27 @@ __global__ void __launch_bounds__(kIpcMaxThreads)
   __syncthreads();
   if (ok) {
     T* dst = reinterpret_cast<T*>(p.data) + (c.start - p.seg_off);
+    // Two round trips for the whole chunk -- every index, then every value -- not two per element: the loads are issued by every
+    // thread with a clamped element (a thread beyond the chunk re-reads its first element) instead of under ``e < count``, where the
+    // compiler waits for each index inside its own block (16 serial round trips for 8 elements per thread; the same rule as the
+    // preamble of the planned kernels, plan.hpp)
+    int64_t src[kIpcEpt];
     T v[kIpcEpt];
+    if (c.count > 0) {  // block-uniform
 #pragma unroll
-    for (int k = 0; k < kIpcEpt; ++k) {
-      const int e = (int)threadIdx.x + k * (int)blockDim.x;
-      if (e < c.count) {
-        const int64_t i = c.start + e;
-        v[k] = vec[(GATHER ? index[i] : i) + offset];
+      for (int k = 0; k < kIpcEpt; ++k) {
+        const int e = (int)threadIdx.x + k * (int)blockDim.x;
+        const int64_t i = c.start + (e < c.count ? e : 0);
+        src[k] = GATHER ? index[i] : i;
       }
-    }
 #pragma unroll
-    for (int k = 0; k < kIpcEpt; ++k) {
-      const int e = (int)threadIdx.x + k * (int)blockDim.x;
-      if (e < c.count) ipc_store_elem<T>(dst + e, v[k]);
+      for (int k = 0; k < kIpcEpt; ++k) v[k] = vec[src[k] + offset];
+      ipc_pin(v);  // (an empty use: the compiler would sink each load into the block of its store again)
+#pragma unroll
+      for (int k = 0; k < kIpcEpt; ++k) {
+        const int e = (int)threadIdx.x + k * (int)blockDim.x;
+        if (e < c.count) ipc_store_elem<T>(dst + e, v[k]);
+      }
     }
   }
   ipc_stores_done();  // my stores have reached the neighbour's memory before the flag can
@@ -258,23 +273,24 @@ __global__ void __launch_bounds__(kIpcMaxThreads)
     const T* src = reinterpret_cast<const T*>(p.data);
     T v[kIpcEpt];
     int64_t j[kIpcEpt];
+    if (c.count > 0) {  // block-uniform; loads by every thread with a clamped element: one round trip for the chunk (see ipc_send_kernel)
 #pragma unroll
-    for (int k = 0; k < kIpcEpt; ++k) {
-      const int e = (int)threadIdx.x + k * (int)blockDim.x;
-      if (e < c.count) {
-        const int64_t i = c.start + e;
+      for (int k = 0; k < kIpcEpt; ++k) {
+        const int e = (int)threadIdx.x + k * (int)blockDim.x;
+        const int64_t i = c.start + (e < c.count ? e : 0);
         v[k] = ipc_load_elem<T>(src + i);
-        j[k] = (GATHER ? index[i] : i) + offset;
+        j[k] = GATHER ? index[i] : i;
       }
-    }
+      ipc_pin(j);
 #pragma unroll
-    for (int k = 0; k < kIpcEpt; ++k) {
-      const int e = (int)threadIdx.x + k * (int)blockDim.x;
-      if (e < c.count) {
-        if constexpr (MODE == UNPACK_SET)
-          vec[j[k]] = v[k];
-        else
-          unsafeAtomicAdd(vec + j[k], v[k]);
+      for (int k = 0; k < kIpcEpt; ++k) {
+        const int e = (int)threadIdx.x + k * (int)blockDim.x;
+        if (e < c.count) {
+          if constexpr (MODE == UNPACK_SET)
+            vec[j[k] + offset] = v[k];
+          else
+            unsafeAtomicAdd(vec + j[k] + offset, v[k]);
+        }
       }
     }
   }
