@@ -197,12 +197,13 @@ constexpr int kPlanMaxEntries = 4096;  // per batch; slot ids are 16-bit, keys l
 //      lines, no HBM traffic of its own;
 //  (5) the 16-bit slots are loaded as 32-bit words and narrowed (their first use) after the x gather has been issued (PlanSlotWord);
 //  (6) where the compiler would sink a load into the conditional block of its only use, an empty asm pins it (batch_dofs_resolve).
-// (4)-(5) hold up to degree 6.  From degree 7 on the loads stay under ``active`` and the slots are narrowed where they are loaded: the
-// G slab is a ring of one or two planes there (little in flight to wait for), and the unconditional forms cost registers the P = 9
+// (4)-(5) hold up to degree 8 (P = 7, 8 keep their three waves per SIMD with them: 163-164 VGPRs; fp32 -6 %, fp64 0 ... -4 %,
+// profiles/r05y_sweep_ab_preamble_p78.log).  From degree 9 on the loads stay under ``active`` and the slots are narrowed where they are
+// loaded: the G slab is a ring of one plane there (little in flight to wait for), and the unconditional forms cost registers the P = 9
 // kernels do not have (169 VGPRs, +46 spilled SGPRs: their third wave per SIMD).
 template <int n>
 __host__ __device__ constexpr bool plan_loads_by_all() {
-  return n <= 7;
+  return n <= 9;
 }
 template <int CPB>
 __device__ __forceinline__ int64_t plan_load_pos(int64_t cell0, int lc, int64_t ncell) {
