@@ -32,10 +32,11 @@ template <typename T>
 inline bool plan_use_runs(int ndof_per_entity, bool runs_pay = true) {
   const int mode = g_plan_runs.load(std::memory_order_relaxed);
   if (mode == 1 && !runs_pay) return false;
-  // auto: fp64 always (+4..6 % at every degree); fp32 up to P = 6 (+7..12 % at P = 2, 4, 5, 6; P = 7 equal, P = 8 -6 %).  Before the
-  // run words were read speculatively (plan.hpp, the preamble) the fp32 limit was P = 4 (-12 % at P = 6 then):
-  // profiles/r05x_ab_run_tables.log; r02o_ab_run_tables.log, r02y_ab_fp32.log for the earlier kernels
-  return mode == 2 || (mode == 1 && (sizeof(T) == 8 || ndof_per_entity <= 343));
+  // auto: fp64 always (+4..6 % at every degree); fp32 up to P = 8, i.e. wherever the preamble reads the run words speculatively and
+  // issues its loads by every thread (plan.hpp: +7..12 % at P = 2, 4, 5, 6, +7 % at P = 7, +3 % at P = 8; P = 9, 10 keep the raw
+  // lists).  Before that the fp32 limit was P = 4 (-12 % at P = 6 then): profiles/r05x_ab_run_tables.log,
+  // r05x_ab_run_tables_fp32_p78.log; r02o_ab_run_tables.log, r02y_ab_fp32.log for the earlier kernels
+  return mode == 2 || (mode == 1 && (sizeof(T) == 8 || ndof_per_entity <= 729));
 }
 inline std::atomic<int> g_plan_variant{-1};  // -1 = auto
 

@@ -35,7 +35,7 @@ def _find(table, pattern):
 
 # (kernel regex, max VGPRs, min waves per SIMD) of the builds the auto dispatch of the library picks (csrc/dispatch_*.hip, fus_gpu.hip).
 # The last two template arguments of the planned cell kernels are (ORDERED, RUNS) (csrc/plan.hpp): pinned here for an un-ordered plan
-# and the list encoding the auto dispatch reads (run tables: fp64 always, fp32 up to P = 6); test_ordered_and_list_variants has the rest
+# and the list encoding the auto dispatch reads (run tables: fp64 always, fp32 up to P = 8); test_ordered_and_list_variants has the rest
 SHIPPED = [
     # general-G planned stiffness: P <= 3 build 0, P = 4 / 5 build 1 (LDS-aliased), P >= 6 build 2 (G ring)
     (r"stiffness_plan_kernel<double, 2, 28, false, true, 1, 3, false, true>", 128, 4),
