@@ -113,9 +113,11 @@ def solve(mesh, nsteps, dt, c0=1500.0, rho0=1000.0, f0=0.5e6, p0=60000.0, source
 
 
 def solve_westervelt(mesh, nsteps, dt, c0=1480.0, rho0=1000.0, f0=1.1e6, p0=None, beta=3.5, att_dB=0.2,
-                     source_time="tn", oracle_c=None, c_ref=None, rho_ref=None):
+                     source_time="tn", oracle_c=None, c_ref=None, rho_ref=None, threads=1, geometry=None):
     """cuda/demo_nonlinear_bowl.py:357-374,458-475,540-650 restated with the oracle's operators
-    (single rank; source on x = 0, absorbing on x = L)."""
+    (single rank; source on x = 0, absorbing on x = L).  ``oracle_c``: the C restatement of the operators (``threads`` > 1: its
+    OpenMP stiffness apply).  ``geometry = (G, detJ, detJ_f1, detJ_f2)``: geometry factors computed elsewhere (bench.py hands
+    over the ones the GPU stepped with) instead of the host precompute."""
     gll, pre = pkg("gll"), pkg("precompute")
     P, n = mesh.P, mesh.P + 1
     # c0, rho0, beta, att_dB: scalars or one value per cell; the source term and the default amplitude use scalars (c_ref, rho_ref)
@@ -131,14 +133,17 @@ def solve_westervelt(mesh, nsteps, dt, c0=1480.0, rho0=1000.0, f0=1.1e6, p0=None
     w3 = gll.tensor_weights_3d(wts)
     dg_ = pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))
     nc = mesh.ncells
-    G, detJ = np.zeros((nc, n**3, 6)), np.zeros((nc, n**3))
-    pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), nc, dg_, w3)
-    pre.compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), nc, dg_, w3)
     bd1, bd2 = mesh.boundary_facets([2]), mesh.boundary_facets([3])
-    w2, dpf = gll.tensor_weights_2d(wts), pre.tabulate_facet_gradients(pts)
-    dF1, dF2 = np.zeros((bd1.shape[0], n * n)), np.zeros((bd2.shape[0], n * n))
-    pre.compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dpf, w2)
-    pre.compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dpf, w2)
+    if geometry is not None:
+        G, detJ, dF1, dF2 = geometry
+    else:
+        G, detJ = np.zeros((nc, n**3, 6)), np.zeros((nc, n**3))
+        pre.compute_scaled_geometrical_factor(G, (mesh.x_dofs, mesh.x_g), nc, dg_, w3)
+        pre.compute_scaled_jacobian_determinant(detJ, (mesh.x_dofs, mesh.x_g), nc, dg_, w3)
+        w2, dpf = gll.tensor_weights_2d(wts), pre.tabulate_facet_gradients(pts)
+        dF1, dF2 = np.zeros((bd1.shape[0], n * n)), np.zeros((bd2.shape[0], n * n))
+        pre.compute_boundary_facets_scaled_jacobian_determinant(dF1, (mesh.x_dofs, mesh.x_g), bd1, dpf, w2)
+        pre.compute_boundary_facets_scaled_jacobian_determinant(dF2, (mesh.x_dofs, mesh.x_g), bd2, dpf, w2)
     fd1, fd2 = mesh.facet_dofmap(bd1), mesh.facet_dofmap(bd2)
     cc1 = 1 / rho0 / c0**2
     cc2 = -2 * beta / rho0**2 / c0**4
@@ -152,12 +157,14 @@ def solve_westervelt(mesh, nsteps, dt, c0=1480.0, rho0=1000.0, f0=1.1e6, p0=None
     nd = mesh.ndofs
     ones = np.ones(nd)
     m0 = np.zeros(nd)
+    # the mass applies: the numpy restatement, or (large meshes) the C one -- both pinned by tests/test_oracle_golden.py
+    mass_apply = oracle_c.mass_apply if (oracle_c is not None and geometry is not None) else oracle_np.mass_apply
     oracle_np.mass_apply(ones, cc1, m0, detJ, mesh.dofmap)
     oracle_np.mass_apply(ones, f12, m0, dF2, fd2)
 
     def stiff(x, cc, y):
         if oracle_c is not None:
-            oracle_c.stiffness_apply(P, D, x, cc, y, G, mesh.dofmap)
+            oracle_c.stiffness_apply(P, D, x, cc, y, G, mesh.dofmap, threads=threads)
         else:
             oracle_np.stiffness_apply(P, D.flatten(), x, cc, y, G, mesh.dofmap)
 
@@ -172,15 +179,15 @@ def solve_westervelt(mesh, nsteps, dt, c0=1480.0, rho0=1000.0, f0=1.1e6, p0=None
         g = np.full(nd, window * a * np.cos(w0 * t))
         dg = np.full(nd, dwindow * a * np.cos(w0 * t) - window * a * w0 * np.sin(w0 * t))
         m = np.zeros(nd)
-        oracle_np.mass_apply(un, cc2, m, detJ, mesh.dofmap)
+        mass_apply(np.ascontiguousarray(un), cc2, m, detJ, mesh.dofmap)
         m += m0
         b = np.zeros(nd)
-        stiff(un, cc3, b)
-        stiff(vn, cc4, b)
-        oracle_np.mass_apply(vn * vn, cc5, b, detJ, mesh.dofmap)
-        oracle_np.mass_apply(g, f11, b, dF1, fd1)
-        oracle_np.mass_apply(dg, f21, b, dF1, fd1)
-        oracle_np.mass_apply(vn, f22, b, dF2, fd2)
+        stiff(np.ascontiguousarray(un), cc3, b)
+        stiff(np.ascontiguousarray(vn), cc4, b)
+        mass_apply(vn * vn, cc5, b, detJ, mesh.dofmap)
+        mass_apply(g, f11, b, dF1, fd1)
+        mass_apply(dg, f21, b, dF1, fd1)
+        mass_apply(np.ascontiguousarray(vn), f22, b, dF2, fd2)
         return b / m
 
     u, v = np.zeros(nd), np.zeros(nd)

@@ -117,6 +117,9 @@ def main():
         return 100 * np.sin(2 * np.pi * xyz[:, 0]) * np.cos(3 * np.pi * xyz[:, 1]) * np.sin(4 * np.pi * xyz[:, 2])
 
     only = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "all"  # all | ops | scatter | plan | rk4 | rk4nl
+    # --match SUBSTRING: (re)write only the ops / rk4nl fixtures whose tag contains it (round 6 added P = 5, P = 8 and the P = 3 two-rank
+    # Westervelt case without touching the committed ones: ``--only ops --match ops_P5``, ``--only rk4nl --match P3``)
+    match = sys.argv[sys.argv.index("--match") + 1] if "--match" in sys.argv else ""
 
     # ---- operator + precompute fixtures --------------------------------------
     cases = []
@@ -127,7 +130,12 @@ def main():
                     if P == 6 and shape == (3, 2, 2):
                         continue  # keep the fixture set small
                     cases.append((P, shape, perturb, dt))
+    # the degrees between / above the reference's test set that its Q map serves (numba-cpu/time_operators.py:35-45): the generic-n path
+    # of the operators at an odd and at a high degree
+    cases += [(5, (2, 2, 2), 0.16, np.float64), (8, (2, 2, 2), 0.16, np.float64)]
     for P, shape, perturb, dt in (cases if only in ("all", "ops") else []):
+        if match and match not in f"ops_P{P}_{shape[0]}x{shape[1]}x{shape[2]}_{'pert' if perturb else 'affine'}_{np.dtype(dt).name}":
+            continue
         n = P + 1
         mesh = boxmesh.BoxMesh(P, shape, perturb=perturb, seed=7, dtype=dt)
         pts, wts, D = gll.tabulate_1d(P, dt)
@@ -416,7 +424,10 @@ def main():
         p0 = rho0 * c0 * 0.38557513826589934  # :56-62
         w0 = 2 * np.pi * f0
         delta0 = 2 * (att_dB / 20 * np.log(10)) * c0**3 / w0 / w0  # compute_diffusivity_of_sound, cuda/utils.py:157-162
-        for tag, P, shape, grid, nsteps in (("P2_2x2x2_bowl_1rank", 2, (2, 2, 2), (1, 1, 1), 10), ("P2_4x2x2_bowl_2ranks", 2, (4, 2, 2), (2, 1, 1), 8)):
+        for tag, P, shape, grid, nsteps in (("P2_2x2x2_bowl_1rank", 2, (2, 2, 2), (1, 1, 1), 10), ("P2_4x2x2_bowl_2ranks", 2, (4, 2, 2), (2, 1, 1), 8),
+                                            ("P3_4x2x2_bowl_2ranks", 3, (4, 2, 2), (2, 1, 1), 6)):  # P = 3: the solvers' default cell kernel forms G itself
+            if match and match not in f"rk4nl_{tag}":
+                continue
             n = P + 1
             R = int(np.prod(grid))
             L = 0.0015 * shape[0]

@@ -186,6 +186,23 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
         assert out["check"]["ok"] is True and out["check"]["rel_l2"] <= 1e-12  # every rank's owned dofs against the oracle, reverse-scattered
         fc = cfg["first_contact"]
         assert [r_["rank"] for r_ in fc["ranks"]] == list(range(n)) and len({r_["pid"] for r_ in fc["ranks"]}) == n and fc["rehearsal"] is True
+        if mode == "stiffness":
+            # the driver's fixed N > 1 command (no extra flags) harvests everything in ONE run -- the transports compared
+            # (on by default) and, on the same partition and communicator, the partitioned mass apply, both fused RK4 steps and the Westervelt
+            # P = 6 step (BASELINE config 5), each with ms, per-rank min / max, its exposed halo cost and its own halo check
+            hc = cfg["halo_compare"]
+            assert hc["chosen"] == "peer" and hc["transports"]["peer"]["ms_per_step_median"] > 0 and "rehearsal" in hc["not_compared"]["native"]
+            sec = out["roofline"]["secondary"]
+            for k in ("westervelt_geom", "rk4_geom", "mass", "rk4"):
+                v = sec[k]
+                assert v["ms"] > 0 and len(v["rank_ms"]) == 2 and 0 < v["rank_ms"][0] <= v["rank_ms"][1], (k, v)
+                assert v["halo_exposed_ms"] is not None and v["halo_ok"] is True, (k, v)
+            assert sec["mass"]["chk"][1] is True and sec["mass"]["chk"][0] <= 1e-12  # owned dofs of all ranks against the oracle
+            hv = out["harvest"]
+            assert hv["westervelt_geom"]["degree"] == 6 and hv["westervelt_geom"]["cells_per_gpu"] == 7**3 and "formed in the cell kernel" in hv["westervelt_geom"]["geometry"]
+            assert hv["rk4"]["geometry"] == "general per-quadrature-point G" and hv["mass"]["kernel"] == "fus::mass_gather_kernel"
+            assert hv["rk4_geom"]["halo_check"]["forward_wrong_ghosts"] == 0 and hv["rk4_geom"]["local_ms"] > 0 and hv["seconds"] < 150
+            assert "skipped" not in json.dumps(hv)
     else:  # the solver lines check the exchange they are about to use, too
         hc = out["config"]["halo_check"]
         assert hc["ok"] is True and hc["forward_wrong_ghosts"] == 0 and hc["reverse_sum"] == hc["global_ghosts"] > 0
@@ -253,8 +270,16 @@ def test_default_line_carries_the_aux_entries():
     # a result check bound to the timed region, the aux scalars inside a key the driver keeps, the halo proxy
     for ck in (out["check"], out["config"]["check"]):
         assert ck["ok"] is True and ck["rel_l2"] <= 1e-12 and ck["rel_max"] <= 1e-11 and abs(ck["sum_y"] - ck["sum_y_oracle"]) <= 1e-9 * ck["norm_y_oracle"]
+    # every line the driver stores carries a check of what ITS OWN timed launches computed, against the oracle
+    for k in ("mass", "mass_cached_diagonal", "stiffness_in_kernel_geometry"):
+        assert aux[k]["check"]["ok"] is True and aux[k]["check"]["rel_l2"] <= 1e-12, (k, aux[k]["check"])
+    assert aux["mass"]["check"]["static_detJ_rel_l2"] <= 1e-12 and aux["mass"]["check"]["atomic_rel_l2"] <= 1e-12
+    for k in ("rk4_step", "rk4_step_in_kernel_geometry", "westervelt_step", "westervelt_step_in_kernel_geometry", "westervelt_step_single_gather"):
+        assert aux[k]["check"]["ok"] is True and aux[k]["check"]["rel_l2"] <= 1e-11, (k, aux[k]["check"])
     sec = out["roofline"]["secondary"]
-    assert len(json.dumps(sec)) <= 1024, len(json.dumps(sec))
+    assert len(json.dumps(sec)) <= 1536, len(json.dumps(sec))
+    for k in ("mass", "geom", "rk4", "rk4_geom", "westervelt", "westervelt_geom"):
+        assert sec[k]["chk"][1] is True, (k, sec[k])
     for k in ("mass", "geom", "rk4", "rk4_geom", "westervelt", "westervelt_geom", "sustained", "halo_proxy", "check"):
         assert k in sec, k
     assert sec["check"]["ok"] is True and sec["mass"]["ms"] > 0 and 0 < sec["rk4"]["frac"] < 1

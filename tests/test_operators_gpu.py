@@ -499,6 +499,57 @@ def test_full_size_config3(gpu, oracle_c):
     _check(K(2.0 * x - 3.0 * v), 2.0 * Kx - 3.0 * Kv, np.float64, "linearity")
 
 
+def test_full_size_config5_operators(gpu, oracle_c):
+    """BASELINE config 5's operators at the size its step is quoted on (P = 6, 36^3 bowl-warped trilinear cells, 10 218 313 dofs),
+    each DIRECTLY against the oracle on all host cores: the general-G stiffness apply, the stiffness
+    apply with G formed in the kernel, and the Westervelt cell pass b += K(c3) u + K(c4) v in both forms.  The oracle reads the
+    reference's G array (numba-cpu/precompute.py:115-163 conventions, formed on the device: pinned to 1e-13 by
+    test_device_precompute_vs_reference)."""
+    import torch
+
+    dev, ops = gpu
+    boxmesh, gll, pre = pkg("boxmesh"), pkg("gll"), pkg("precompute")
+    P, N, L = 6, 36, 0.12
+
+    def bowl(xg):  # bench.py's config-5 warp (benchlib/steps.py)
+        out = xg.copy()
+        yy, zz = xg[:, 1] / L - 0.5, xg[:, 2] / L - 0.5
+        out[:, 0] = xg[:, 0] + 0.15 * (L / N) * 4 * (yy * yy + zz * zz) * (1.0 - xg[:, 0] / L)
+        return out
+
+    mesh = boxmesh.BoxMesh(P, N, length=(L, L, L), warp=bowl)
+    assert mesh.ndofs == 10218313 and mesh.ncells == 46656
+    pts, wts, D = gll.tabulate_1d(P)
+    d = torch.device("cuda", 0)
+    dm, xd, xg = (torch.from_numpy(a).to(d) for a in (mesh.dofmap, mesh.x_dofs, mesh.x_g))
+    G = torch.empty((mesh.ncells, 343, 6), dtype=torch.float64, device=d)
+    pre.compute_scaled_geometrical_factor_device(
+        G, (xd, xg), mesh.ncells, torch.from_numpy(pre.tabulate_hex_p1_gradients(gll.tensor_points_3d(pts))).to(d),
+        torch.from_numpy(gll.tensor_weights_3d(wts)).to(d))
+    G_h = G.cpu().numpy()
+    rng = np.random.default_rng(6)
+    u, v = rng.standard_normal(mesh.ndofs), rng.standard_normal(mesh.ndofs)
+    c3, c4 = 0.5 + rng.random(mesh.ncells), 0.5 + rng.random(mesh.ncells)
+    threads = max(1, min(32, oracle_c.max_threads()))
+    Ku = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, D, u, c3, Ku, G_h, mesh.dofmap, threads=threads)
+    b_ref = Ku.copy()
+    oracle_c.stiffness_apply(P, D, v, c4, b_ref, G_h, mesh.dofmap, threads=threads)
+    u_d, v_d, c3_d, c4_d = (torch.from_numpy(a).to(d) for a in (u, v, c3, c4))
+    y = torch.zeros(mesh.ndofs, dtype=torch.float64, device=d)
+    ops.stiffness_operator(P, D.flatten(), np.float64)(u_d, c3_d, y, G, dm)
+    _check(y.cpu().numpy(), Ku, np.float64, "general-G stiffness, P = 6 36^3 bowl")
+    y.zero_()
+    ops.stiffness_operator(P, D.flatten(), np.float64, geometry=(xd, xg, pts, wts))(u_d, c3_d, y, None, dm)
+    _check(y.cpu().numpy(), Ku, np.float64, "in-kernel-geometry stiffness, P = 6 36^3 bowl")
+    y.zero_()
+    ops.westervelt_cell_operator(P, D.flatten(), np.float64).stiffness_only(u_d, v_d, c3_d, c4_d, y, G, dm)
+    _check(y.cpu().numpy(), b_ref, np.float64, "Westervelt cell pass (G array), P = 6 36^3 bowl")
+    y.zero_()
+    ops.westervelt_cell_operator(P, D.flatten(), np.float64, geometry=(mesh.x_g, pts, wts)).stiffness_only(u_d, v_d, c3_d, c4_d, y, xd, dm)
+    _check(y.cpu().numpy(), b_ref, np.float64, "Westervelt cell pass (in-kernel geometry), P = 6 36^3 bowl")
+
+
 def test_plan_cache_follows_dofmap_changes(gpu, oracle_c):
     """The cached batch plan is keyed on the dofmap array's identity AND version: an in-place
     change of the dofmap must be seen by the next apply."""
@@ -576,7 +627,7 @@ def test_in_kernel_geometry_all_degrees(gpu, oracle_c, P, dtype):
     _check(y.copy_to_host(), y_ref, dtype, f"in-kernel geometry P={P}")
 
 
-def test_in_kernel_geometry_full_size_properties(gpu):
+def test_in_kernel_geometry_full_size_properties(gpu, oracle_c):
     """BASELINE config 3 size (P = 4, 54^3 perturbed cells): size-independent properties of the
     in-kernel-geometry operator -- K 1 = 0, symmetry v.Ku = u.Kv, and agreement with the general-G
     kernel fed by the device precompute of the same vertices."""
@@ -611,6 +662,10 @@ def test_in_kernel_geometry_full_size_properties(gpu):
     ops.stiffness_operator(P, D.flatten(), np.float64)(u, cc, Ku2, G, dm)
     err = float((Ku - Ku2).norm() / Ku2.norm())
     assert err < 1e-12, err
+    # ... and DIRECTLY against the oracle at this size (round 6; until then only through the general-G GPU kernel above)
+    y_ref = np.zeros(mesh.ndofs)
+    oracle_c.stiffness_apply(P, D, u.cpu().numpy(), cc.cpu().numpy(), y_ref, G.cpu().numpy(), mesh.dofmap, threads=max(1, min(32, oracle_c.max_threads())))
+    _check(Ku.cpu().numpy(), y_ref, np.float64, "in-kernel geometry vs oracle, full config 3")
 
 
 @pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])

@@ -122,7 +122,7 @@ def _case_nl(name):
     return d, meshes, serial, kw
 
 
-@pytest.mark.parametrize("name", ["rk4nl_P2_2x2x2_bowl_1rank", "rk4nl_P2_4x2x2_bowl_2ranks"])
+@pytest.mark.parametrize("name", ["rk4nl_P2_2x2x2_bowl_1rank", "rk4nl_P2_4x2x2_bowl_2ranks", "rk4nl_P3_4x2x2_bowl_2ranks"])
 def test_oracle_westervelt_loop_reproduces_reference_driven_loop(name):
     """tests/golden/rk4nl_*.npz: the reference's own operators and scatter closures driven through the stage sequence of
     cuda/demo_nonlinear_bowl.py:458-475,533-650 (``generate_golden.py --only rk4nl``); ``rk4_oracle.solve_westervelt`` --
@@ -154,18 +154,21 @@ def test_gpu_westervelt_solver_reproduces_reference_driven_loop(variant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("transport", ["local", "peer"])
-def test_gpu_partitioned_westervelt_solver_reproduces_reference_driven_loop(transport):
+@pytest.mark.parametrize("transport,name", [("local", "rk4nl_P2_4x2x2_bowl_2ranks"), ("peer", "rk4nl_P2_4x2x2_bowl_2ranks"),
+                                            ("peer", "rk4nl_P3_4x2x2_bowl_2ranks")])
+def test_gpu_partitioned_westervelt_solver_reproduces_reference_driven_loop(transport, name):
+    """P = 3 (round 6): the fused stage's DEFAULT cell kernel from degree 3 on forms G in the kernel (westervelt_cell_geom_kernel) --
+    here against reference-held data on two ranks."""
     import torch
 
     from test_solver_gpu import _lockstep
 
     torch.cuda.set_device(0)
     nls, scat, utils = pkg("nonlinear_solver"), pkg("scatterer"), pkg("utils")
-    d, meshes, serial, kw = _case_nl("rk4nl_P2_4x2x2_bowl_2ranks")
+    d, meshes, serial, kw = _case_nl(name)
     R = len(meshes)
     od, gd = utils.compute_scatterer_data_all([m.index_map for m in meshes])
-    wid = 7400 + (transport == "peer")
+    wid = 7400 + (transport == "peer") + 2 * (int(d["P"]) == 3)
     comms = [scat.NativeComm(local=(wid, R, r), transport="peer" if transport == "peer" else "rccl") for r in range(R)]
     solvers = [nls.WesterveltSpectral3D(meshes[r], np.float64, speed_of_sound=kw["c0"], density=kw["rho0"], source_frequency=kw["f0"],
                                         source_amplitude=kw["p0"], nonlinear_coefficient=kw["beta"], attenuation_coefficient_dB=kw["att_dB"],
