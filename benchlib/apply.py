@@ -14,7 +14,7 @@ from .common import HBM_PEAK_GBS, coll_device, emit, host_cores, kernel_src_sha,
 from .cpu_legs import compare_with_oracle, cpu_baseline, cpu_baseline_mass, oracle_apply
 from .harvest import harvest, owned_dofs_check
 from .roofline import geom_bytes_per_cell, load_traffic, mass_bytes_per_cell, secondary_summary, stiffness_bytes_per_cell
-from .transports import TRANSPORT_TEXT, compare_transports, first_contact_report, gather_verdicts, make_comm, transport_candidates
+from .transports import apply_variant_env, compare_transports, first_contact_report, gather_verdicts, make_comm, transport_candidates, transport_text
 
 
 def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
@@ -127,15 +127,12 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
         scat = fusgpu_loader.submodule("scatterer")
         os.environ.setdefault("FUS_IPC_SPIN_SECONDS", "10")  # a transport that does not deliver fails its check in seconds
         first_contact = first_contact_report(rank, world, device)
-        ipc_memory_env = os.environ.get("FUS_IPC_MEMORY")
+        peer_failed_on_data = False
         for kind in transport_candidates(args):
-            base, _, arena_kind = kind.partition(":")
-            if arena_kind:
-                os.environ["FUS_IPC_MEMORY"] = arena_kind
-            elif ipc_memory_env is None:
-                os.environ.pop("FUS_IPC_MEMORY", None)
-            else:
-                os.environ["FUS_IPC_MEMORY"] = ipc_memory_env
+            base, _, variant = kind.partition(":")
+            if variant == "fenced" and not peer_failed_on_data:
+                continue  # the fenced rung answers a DATA failure of the fence-free protocol, nothing else
+            apply_variant_env(kind)
             comm, why = make_comm(base, scat, world, device)
             if comm is None:
                 tried.append({"transport": kind, "result": f"did not come up: {why}"})
@@ -153,7 +150,10 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
                 log(f"rank {rank}: halo transport {kind!r} failed during bring-up: {err}")
             arena = None
             try:
-                arena = halo.fwd.status().get("arena_memory") if (err is None and base == "peer" and hasattr(halo.fwd, "status")) else None
+                st_ = halo.fwd.status() if (err is None and base == "peer" and hasattr(halo.fwd, "status")) else {}
+                arena = st_.get("arena_memory")
+                if arena is not None and st_.get("fenced"):
+                    arena += ", fenced"
             except Exception:  # noqa: BLE001
                 pass
             bring_up = gather_verdicts(rank, world, {"error": err, "arena_memory": arena})
@@ -164,7 +164,8 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
                 verdict = check_halo()
                 per_rank = gather_verdicts(rank, world, {"forward_max_abs_err": verdict["forward_max_abs_err"], "device_wait_timeouts": int(halo.health())})
                 entry["check_failed_on_ranks"] = [v["rank"] for v in per_rank if v["forward_max_abs_err"] != 0.0 or v["device_wait_timeouts"] != 0]
-                if base in os.environ.get("FUS_BENCH_TEST_REJECT", "").split(","):  # test hook: exercise the fall-back path
+                rejects = os.environ.get("FUS_BENCH_TEST_REJECT", "").split(",")  # test hook: exercise the fall-back path ("=kind": that exact rung only)
+                if base in rejects or ("=" + kind) in rejects:
                     verdict = dict(verdict, ok=False, rejected_by="FUS_BENCH_TEST_REJECT")
             else:
                 entry["bring_up_errors"] = {v["rank"]: v["error"] for v in bring_up if v["error"] is not None}
@@ -174,6 +175,8 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
                 if rank == 0:
                     log(f"halo transport {kind!r}: came up on all {world} ranks, halo check passed ({verdict}); arena memory by rank: {entry['arena_memory_by_rank']}; CHOSEN")
                 break
+            if kind == "peer" and verdict is not None:
+                peer_failed_on_data = True  # it came up everywhere and its exchanges did not deliver: try the fenced form of the same protocol next
             tried.append(dict(entry, result=f"rejected: {verdict if verdict is not None else 'bring-up failed on rank(s) ' + str(failed_ranks)}"))
             if rank == 0:
                 log(f"halo transport {kind!r} rejected: {tried[-1]}; trying the next one")
@@ -255,7 +258,7 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
         sched_ms = timed_launches(lambda: halo.apply_no_exchange(x_d, cc_d, y_d, G_d, dm_d))
         if args.halo_compare:
             try:
-                halo_compare = compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, transport.partition(":")[0], halo, kern_ms)
+                halo_compare = compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, transport, halo, kern_ms)
             except Exception as e:  # noqa: BLE001
                 log(f"rank {rank}: --halo-compare failed: {e!r}")
                 halo_compare = {"error": repr(e)}
@@ -336,7 +339,7 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
             "halo_schedule": None if halo is None else halo.schedule_kind,
             "halo_lead_cells": None if halo is None else halo.lead_cells,
             "halo_check": halo_check,
-            "halo_transport": None if halo is None else TRANSPORT_TEXT[transport.partition(":")[0]] + (f" [arenas in {transport.partition(':')[2]} memory]" if ":" in transport else ""),
+            "halo_transport": None if halo is None else transport_text(transport),
             "halo_transports_tried": tried or None,
             "first_contact": first_contact,
             "halo_compare": halo_compare,

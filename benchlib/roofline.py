@@ -27,11 +27,14 @@ def geom_bytes_per_cell(P, T):
     return 4 * nd + 3 * T * P**3 + T + 32 + 3 * T
 
 
-def rk4_step_bytes(P, T, ncells, ndofs, nfacets_source, nfacets_absorbing, mode, affine, in_kernel_geometry, single_gather=False):
-    """Algorithmic HBM bytes of ONE fused RK4 step (4 stages), DESIGN.md section 6:
-    linear:      4 x [cell pass + facet terms] + 41 vector touches (csrc/rk4.hpp: FIRST 9 + MIDDLE 12 + MIDDLE 12 + LAST 8)
-    Westervelt:  4 x [cell pass: stiffness part, two gathers unless c4/c3 is uniform] + 4 x 15 vector touches
-                 (csrc/westervelt.hpp rk4_stage_nl2_kernel; + 1 per stage for w when the pass is single-gather)
+def rk4_step_bytes(P, T, ncells, ndofs, nfacets_source, nfacets_absorbing, mode, affine, in_kernel_geometry, single_gather=False, lean=True):
+    """Algorithmic HBM bytes of ONE fused RK4 step (4 stages), DESIGN.md 3.4 / 6:
+    linear:      4 x [cell pass + facet terms] + the vector passes: 34 touches with the LEAN stage kinds 4-7 of csrc/rk4.hpp (7 + 10 + 12 + 5;
+                 the default since round 6), 41 with kinds 2, 0, 0, 3 (9 + 12 + 12 + 8)
+    Westervelt:  4 x [cell pass: stiffness part, two gathers unless c4 / c3 is uniform] + the vector passes of csrc/westervelt.hpp
+                 rk4_stage_nl2_kernel, which also read un, ku, m0, w2, w5: 46 touches lean (9 + 13 + 15 + 9), 52 otherwise (11 + 15 + 15 + 11;
+                 rounds 2-5 priced this pass at 4 x 15 = 60: 8 touches too many, corrected in round 6); single-gather form: + 1 per pass for w
+                 (+ 1 for u0 in the lean last pass)
     cell pass per cell: G (or the 48-byte affine record, or vertex ids + coordinates) + dofmap + x once per gather +
     y read-modify-write + constants;  facet terms per facet: detJ + dofmap + y RMW (+ x for the absorbing set)."""
     n = P + 1
@@ -43,12 +46,12 @@ def rk4_step_bytes(P, T, ncells, ndofs, nfacets_source, nfacets_absorbing, mode,
             cell = geom_bytes_per_cell(P, T)
         else:
             cell = stiffness_bytes_per_cell(P, T)
-        touches = 41
+        touches = 34 if lean else 41
     else:
         gathers = 1 if single_gather else 2
         geo = (32 + 3 * T) if in_kernel_geometry else 6 * nd * T
         cell = geo + 4 * nd + gathers * T * P**3 + 2 * T * P**3 + gathers * T
-        touches = 4 * (15 + (1 if single_gather else 0))
+        touches = (46 if lean else 52) + ((5 if lean else 4) if single_gather else 0)
     facets = nfacets_source * n * n * (T + 4 + 2 * T) + nfacets_absorbing * n * n * (T + 4 + 3 * T)
     return {"cell_pass_bytes_per_cell": cell, "vector_touches_per_step": touches,
             "bytes_per_step": 4 * (ncells * cell + facets) + touches * T * ndofs}

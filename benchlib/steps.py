@@ -135,7 +135,7 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
                 solver.halo = h
     geo_kernel = bool(getattr(solver, "in_kernel_geometry", False))
     model = rk4_step_bytes(P, T, mesh.ncells, mesh.ndofs, int(solver.fdm1.shape[0]), int(solver.fdm2.shape[0]), mode,
-                           bool(solver.affine), geo_kernel, single_gather)
+                           bool(solver.affine), geo_kernel, single_gather, lean=bool(getattr(solver, "lean_stages", False)))
     achieved = model["bytes_per_step"] / (dev_ms * 1e-3) / 1e9
     if mode == "rk4" and perturbed and world == 1:
         traffic, traffic_source = rk4_step_traffic(P, mesh.ncells, args.dtype, geo_kernel)
@@ -181,7 +181,7 @@ def measure_rk4(args, rank, world, device, mode, perturbed, in_kernel_geometry, 
                    "lib_sha": lib_sha(), "lib_built_from_tree": lib_built_from_tree()},
         "roofline": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                      "traffic": traffic, "traffic_source": traffic_source,
-                     "kernel": "whole fused RK4 step: 4 x (cell pass + facet_terms_kernel + rk4_stage kernel)",
+                     "kernel": "whole fused RK4 step: 4 x (cell pass + facet_terms_kernel + rk4_stage kernel" + (", LEAN stage kinds 4-7)" if getattr(solver, "lean_stages", False) else ")"),
                      "kernel_ms": dev_ms, "kernel_ms_how": "one HIP-event pair around the K steps of the timed region / K",
                      "algorithmic_bytes_per_step": model["bytes_per_step"], "cell_pass_bytes_per_cell": model["cell_pass_bytes_per_cell"],
                      "vector_touches_per_step": model["vector_touches_per_step"], "cells_per_launch": mesh.ncells},

@@ -9,6 +9,35 @@ from .common import _free_port, coll_device, log, rehearsal
 from .launch import _StagedGlooComm
 
 
+_VARIANT_ENV = {"finegrained": ("FUS_IPC_MEMORY", "finegrained"), "fenced": ("FUS_IPC_FENCED", "1")}
+_ENV_AT_START = {}
+
+
+def apply_variant_env(kind):
+    """Point the environment at one variant of a transport (``"peer:fenced"``, ``"peer:finegrained"``; a plain kind restores what the
+    process started with): the PEER transport reads FUS_IPC_MEMORY / FUS_IPC_FENCED when a halo object is CREATED, so the variant
+    holds for every closure built until the next call -- the chosen transport's setting stays for the rest of the run (the harvest's
+    solvers build their closures on the same communicator)."""
+    for name in ("FUS_IPC_MEMORY", "FUS_IPC_FENCED"):
+        if name not in _ENV_AT_START:
+            _ENV_AT_START[name] = os.environ.get(name)
+        if _ENV_AT_START[name] is None:
+            os.environ.pop(name, None)
+        else:
+            os.environ[name] = _ENV_AT_START[name]
+    variant = kind.partition(":")[2]
+    if variant:
+        name, value = _VARIANT_ENV[variant]
+        os.environ[name] = value
+
+
+def transport_text(kind):
+    base, _, variant = kind.partition(":")
+    extra = {"": "", "finegrained": " [arenas in fine-grained memory]",
+             "fenced": " [FENCED: system-scope release before / acquire after every flag, one lane per workgroup]"}[variant]
+    return TRANSPORT_TEXT[base] + extra
+
+
 TRANSPORT_TEXT = {
     "peer": "libfusgpu.so PEER transport: peer-mapped arenas (HIP IPC), send / receive kernels with sequence flags, no RCCL kernel",
     "native": "libfusgpu.so: grouped ncclSend/ncclRecv on a library-owned stream",
@@ -22,7 +51,9 @@ def transport_candidates(args):
     # "peer:finegrained": the PEER transport once more with its receive arenas in fine-grained instead of uncached device memory
     # (FUS_IPC_MEMORY) -- export / open of UNCACHED memory between two different devices has never run on this pool (one GPU per box),
     # and falling straight back to RCCL would cost 22 % per apply where another memory kind might cost nothing
-    return {"peer": ["peer", "peer:finegrained", "native", "torch"], "native": ["native", "torch"], "torch": ["torch"]}[args.halo]
+    # "peer:fenced" (round 6): the same arenas and kernels, conservatively ordered (csrc/halo_ipc.hpp ipc_release_system) -- the middle rung,
+    # tried only after a PEER transport that CAME UP failed the halo check on data (a bring-up failure is not an ordering problem)
+    return {"peer": ["peer", "peer:fenced", "peer:finegrained", "native", "torch"], "native": ["native", "torch"], "torch": ["torch"]}[args.halo]
 
 
 def make_comm(kind, scat, world, device):
@@ -121,10 +152,14 @@ def compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d,
 
     ops_mod = __import__("fusgpu_loader").submodule("operators")
     halos, comms, notes = {chosen_kind: chosen_halo}, {}, {}
-    for kind in ("peer", "native"):
+    for kind in ("peer", "peer:fenced", "native"):  # the three rungs of the ladder: fence-free PEER, its fenced form, RCCL
         if kind in halos:
             continue
-        comm, why = make_comm(kind, scat, world, device)
+        if kind.startswith("peer") and chosen_kind.partition(":")[0] != "peer":
+            notes[kind] = "the run's own ladder rejected the PEER transport"
+            continue
+        apply_variant_env(kind)
+        comm, why = make_comm(kind.partition(":")[0], scat, world, device)
         if comm is None:
             notes[kind] = f"did not come up: {why}"
             continue
@@ -148,6 +183,7 @@ def compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d,
                 pass
             continue
         halos[kind], comms[kind] = h, comm
+    apply_variant_env(chosen_kind)  # what the rest of the run builds (harvest) is the chosen transport's variant again
     # one apply through each transport into a zeroed y: the extra transports against the chosen one
     ref, diffs = None, {}
     for kind, h in halos.items():
@@ -180,7 +216,7 @@ def compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d,
         med = float(np.median(times[kind]))
         late = torch.tensor([float(h.health())], dtype=torch.float64, device=coll_device(device))
         dist.all_reduce(late)
-        out["transports"][kind] = {"transport": TRANSPORT_TEXT[kind], "schedule": h.schedule_kind, "ms_per_step_median": med,
+        out["transports"][kind] = {"transport": transport_text(kind), "schedule": h.schedule_kind, "ms_per_step_median": med,
                                    "ms_per_step_rounds": times[kind], "exposed_ms": med - kern_ms, "exposed_frac": (med - kern_ms) / kern_ms,
                                    "failed_waits_all_ranks": int(late.item()), "max_rel_diff_vs_chosen": diffs.get(kind)}
     if rank == 0:
@@ -295,7 +331,7 @@ def measure_scatter(device, dtype_np, kinds=("peer", "native", "torch"), reps=10
     return out
 
 
-def measure_halo_proxy(op, mesh, cc_d, G_d, dm_d, y_d, device, dt_np, P, cells, kinds=("peer", "native"), rounds=5, reps=40):
+def measure_halo_proxy(op, mesh, cc_d, G_d, dm_d, y_d, device, dt_np, P, cells, kinds=("peer", "peer:fenced", "native"), rounds=5, reps=40):
     """north_star's "< 5 % halo-exchange overhead" on the only proxy a one-GPU box has (tools/overlap_probe.py --paired, the
     measurement DESIGN 4.3 quotes): ONE rank that is its own neighbour with the messages of a config-4 rank (3 faces + 3 edges
     + 1 corner of a 54^3-cell P = 4 block: 1.14 MB per direction; it sends AND receives every message -- the upper bound of what
@@ -340,7 +376,8 @@ def measure_halo_proxy(op, mesh, cc_d, G_d, dm_d, y_d, device, dt_np, P, cells, 
     for kind in kinds:
         comm = halo = None
         try:
-            comm = scat.NativeComm(transport="peer" if kind == "peer" else "rccl")
+            apply_variant_env(kind)
+            comm = scat.NativeComm(transport="peer" if kind.startswith("peer") else "rccl")
             halo = scat.HaloApply(m, op, comm, dt_np, plan=(od, gd))
             halo.prepare(xg, cc_d, G_d, dm_d)
             fns = (("single", lambda: op(xg, cc_d, y_d, G_d, dm_d)),
@@ -354,7 +391,7 @@ def measure_halo_proxy(op, mesh, cc_d, G_d, dm_d, y_d, device, dt_np, P, cells, 
             single = float(np.median(a["single"]))
             d_halo, d_split = float(np.median(a["halo"] - a["single"])), float(np.median(a["schedule"] - a["single"]))
             out["transports"][kind] = {
-                "transport": TRANSPORT_TEXT[kind], "schedule": halo.schedule_kind, "lead_cells": halo.lead_cells,
+                "transport": transport_text(kind), "schedule": halo.schedule_kind, "lead_cells": halo.lead_cells,
                 "single_launch_us": single, "schedule_without_exchange_us": float(np.median(a["schedule"])),
                 "with_both_exchanges_us": float(np.median(a["halo"])), "exposed_us": d_halo, "exposed_pct": 100.0 * d_halo / single,
                 "split_us": d_split, "exchanges_us": float(np.median(a["halo"] - a["schedule"])),
@@ -371,4 +408,5 @@ def measure_halo_proxy(op, mesh, cc_d, G_d, dm_d, y_d, device, dt_np, P, cells, 
                     comm.close()
             except Exception:  # noqa: BLE001
                 pass
+    apply_variant_env("peer")  # back to what the process started with
     return out

@@ -244,6 +244,17 @@ int main(int argc, char** argv) {
         CHECK_HIP(fetch_y());
         report("MassSpectral3D<double,4>::operator(), atomic-free kernel, detJ in row order", rel_l2(y, g["ref_y_mass"].f64()), tol);
         if (y != y_gather) throw std::runtime_error("static-detJ mass apply differs bitwise from the gather apply");
+        // a CALLER-OWNED detJ is never snapshotted by default (the caller may update it between applies: ADVICE r5) -- only on request;
+        // and a second enable_gather() replaces the plans of the first
+        fus_gpu::MassSpectral3D<double, 4> mass_c(d_dm, ncell, mass_s.detJ());
+        mass_c.enable_gather(d_dm, ndofs);
+        if (!mass_c.gather_enabled() || mass_c.static_detJ_enabled()) throw std::runtime_error("a caller-owned detJ was snapshotted without being asked");
+        mass_c.enable_gather(d_dm, ndofs, nullptr, fus_gpu::MassSpectral3D<double, 4>::kStaticAlways);
+        if (!mass_c.static_detJ_enabled()) throw std::runtime_error("kStaticAlways did not build the static companion");
+        CHECK_HIP(reset_y());
+        mass_c(d_x, d_cc, d_y);
+        CHECK_HIP(fetch_y());
+        if (y != y_gather) throw std::runtime_error("caller-owned detJ, kStaticAlways: differs bitwise from the gather apply");
       } catch (const std::exception& e) {
         std::fprintf(stderr, "functor twins: %s\n", e.what());
         ok = false;

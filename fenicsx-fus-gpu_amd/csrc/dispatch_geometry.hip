@@ -46,17 +46,7 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   if (misaligned(ws, 256)) return FUS_ERR_INVALID_ARGUMENT;
   bool ord = false, rp = true;
   hipStream_t s = static_cast<hipStream_t>(stream);
-  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) {
-#ifdef FUS_EXPERIMENT_GEOM_CPB20
-    // EXPERIMENT (tools/exp_geom_tiles.py): a generic plan with 20 cells per batch (2 x 2 x 5 tiles:
-    // 85 instead of 103 distinct dofs per cell) takes a 512-thread build of the kernel -- 65 kB of LDS, 2 workgroups per CU
-    if constexpr (std::is_same<T, double>::value) {
-      if (P == 4 && plan_check(ws, 125, 20, ncell, &ord, nullptr, &rp))
-        return hip_rc(fus::launch_stiffness_plan_geom<T, 4, true, false, 1, true, 20>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, true));
-    }
-#endif
-    return FUS_ERR_PLAN_MISMATCH;
-  }
+  if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) return FUS_ERR_PLAN_MISMATCH;
   hipError_t e = hipErrorInvalidValue;
   switch (P) {
 #define FUS_CASE(PP) \

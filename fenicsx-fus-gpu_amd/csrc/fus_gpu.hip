@@ -571,6 +571,7 @@ FUS_WEST(float, f32)
     if (nlocal < 0 || ntotal < nlocal) return FUS_ERR_INVALID_ARGUMENT;                                            \
     if (ntotal == 0) return FUS_OK;                                                                                \
     if (!m0 || !w2 || !w5 || !b || !u || !v || !u0 || !v0 || !ku || !un) return FUS_ERR_INVALID_ARGUMENT;          \
+    if (new_step < 0 || new_step > 7) return FUS_ERR_INVALID_ARGUMENT;                                             \
     return hip_rc(fus::launch_rk4_stage_nl2<T>(bw, aw, new_step, m0, w2, w5, b, u, v, u0, v0, ku, un, kappa, w,    \
                                                nlocal, ntotal, static_cast<hipStream_t>(s)));                      \
   }
@@ -595,6 +596,7 @@ FUS_WESTG(float, f32)
     if (nlocal < 0 || ntotal < nlocal) return FUS_ERR_INVALID_ARGUMENT;                                        \
     if (ntotal == 0) return FUS_OK;                                                                            \
     if (!minv || !b || !u || !v || !u0 || !v0 || !ku || !un) return FUS_ERR_INVALID_ARGUMENT;                  \
+    if (new_step < 0 || new_step > 7) return FUS_ERR_INVALID_ARGUMENT;                                         \
     return hip_rc(fus::launch_rk4_stage<T>(bw, aw, new_step, minv, b, u, v, u0, v0, ku, un, nlocal, ntotal,    \
                                            static_cast<hipStream_t>(s)));                                      \
   }

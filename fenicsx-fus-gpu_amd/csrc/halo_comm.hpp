@@ -555,6 +555,7 @@ inline hipError_t halo_ipc_create(Halo* h) {
   double seconds = 20.0;
   if (const char* v = std::getenv("FUS_IPC_SPIN_SECONDS")) seconds = std::atof(v) > 0 ? std::atof(v) : seconds;
   st.budget = (uint64_t)(seconds * 1e3 * khz);
+  if (const char* v = std::getenv("FUS_IPC_FENCED")) st.fenced = std::atoi(v) != 0 ? 1 : 0;
   if (e == hipSuccess) e = hipDeviceSynchronize();  // arena zeroed before its handle can reach a peer
   return e;
 }
@@ -754,13 +755,13 @@ inline hipError_t halo_ipc_post_recv(Halo* h, char* vecp, int dir, uint64_t seq,
   if (rr.nchunks > 0) {
     if (dir == 1)
       hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_ADD, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, rs, vec, h->ghosts.idx_d,
-                         (int64_t)0, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
+                         (int64_t)0, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join, st.fenced);
     else if (h->direct)
       hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, false>), dim3(rr.nchunks), dim3(ipc_threads()), 0, rs, vec, h->owners.idx_d,
-                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
+                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join, st.fenced);
     else
       hipLaunchKernelGGL((ipc_recv_kernel<T, UNPACK_SET, true>), dim3(rr.nchunks), dim3(ipc_threads()), 0, rs, vec, h->owners.idx_d,
-                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join);
+                         h->nlocal, rr.chunks, rr.peers, rr.counters, st.status, seq, st.budget, join, st.fenced);
     const hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -791,13 +792,13 @@ inline hipError_t halo_ipc_post(Halo* h, char* vecp, int dir, bool on_stream, bo
   if (sr.nchunks > 0) {
     if (dir == 0)  // owned entries listed in ghosts.idx -> the ghosting ranks
       hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, ss, vec, h->ghosts.idx_d, (int64_t)0,
-                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate, st.fenced);
     else if (h->direct)  // ghost block, already grouped by owner -> the owners
       hipLaunchKernelGGL((ipc_send_kernel<T, false>), dim3(sr.nchunks), dim3(ipc_threads()), 0, ss, vec, h->owners.idx_d, h->nlocal,
-                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate, st.fenced);
     else
       hipLaunchKernelGGL((ipc_send_kernel<T, true>), dim3(sr.nchunks), dim3(ipc_threads()), 0, ss, vec, h->owners.idx_d, h->nlocal,
-                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate);
+                         sr.chunks, sr.peers, sr.counters, st.status, seq, st.budget, gate, st.fenced);
     hipError_t e = hipGetLastError();
     if (e != hipSuccess) return e;
   }
@@ -834,7 +835,7 @@ inline int halo_ipc_status(Halo* h, int64_t* out8) {
   out8[4] = (int64_t)w[ST_TIMEOUTS];
   out8[5] = (int64_t)w[ST_POISONED];
   out8[6] = (int64_t)w[ST_DEAD];
-  out8[7] = 0;
+  out8[7] = h->ipc.fenced;
   return 0;
 }
 

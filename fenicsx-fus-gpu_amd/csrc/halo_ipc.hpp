@@ -110,6 +110,22 @@ __device__ inline uint64_t ipc_load_flag(const uint64_t* f) {
 }
 __device__ inline void ipc_stores_done() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
 
+// FENCED variant of the same protocol (FUS_IPC_FENCED=1 when the halo object is created; bench.py's ladder tries it as "peer:fenced" after
+// a PEER transport that came up but failed the run's halo check ON DATA): the conservatively ordered form of the microarchitecture
+// guide's hand-off -- producer: every storing wave's s_waitcnt vmcnt(0), the workgroup barrier, then ONE lane's SYSTEM-scope release
+// (L2 write-back) + s_waitcnt vmcnt(0) before the relaxed flag store; consumer: ONE relaxed poll, then ONE lane's system-scope acquire
+// (cache invalidate) + s_waitcnt vmcnt(0) before the workgroup barrier that precedes the data loads.  The fence-free default rests on
+// every arena access being a write-through / cache-bypassing system-scope atomic on uncached memory; should that not hold between two
+// DIFFERENT devices (never run on this pool: one GPU per box), this rung costs two fences per workgroup instead of RCCL's 40 us per apply.
+__device__ inline void ipc_release_system() {
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // (the compiler may drop the wait behind buffer_wbl2 when it thinks the scoreboard empty)
+}
+__device__ inline void ipc_acquire_system() {
+  __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "");
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the invalidate completes asynchronously: hold the barrier until it has
+}
+
 // Wait until *flag >= want.  Bounded: gives up after ``budget`` wall-clock ticks, or at once if an earlier wait of this
 // halo has already failed.  A poisoned flag (the publisher's halo is dead) ends the wait at once, is counted and kills this
 // halo too.  Returns 1 only if the data behind the flag may be consumed.
@@ -219,7 +235,7 @@ template <typename T, bool GATHER>
 __global__ void __launch_bounds__(kIpcMaxThreads)
     ipc_send_kernel(const T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
                     const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
-                    uint64_t* status, uint64_t seq, uint64_t budget, IpcGate gate) {
+                    uint64_t* status, uint64_t seq, uint64_t budget, IpcGate gate, int fenced) {
   const IpcChunk c = chunks[blockIdx.x];
   const IpcPeer p = peers[c.nbr];
   __shared__ int ok;
@@ -255,7 +271,10 @@ __global__ void __launch_bounds__(kIpcMaxThreads)
   }
   ipc_stores_done();  // my stores have reached the neighbour's memory before the flag can
   __syncthreads();
-  if (threadIdx.x == 0) ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq, status);
+  if (threadIdx.x == 0) {
+    if (fenced) ipc_release_system();
+    ipc_segment_done(&counters[c.nbr], p.nchunks, p.flag_out, seq, status);
+  }
 }
 
 // MODE: UNPACK_SET (forward: ghosts overwritten) or UNPACK_ADD (reverse: partial sums added into the owners' entries)
@@ -263,11 +282,14 @@ template <typename T, int MODE, bool GATHER>
 __global__ void __launch_bounds__(kIpcMaxThreads)
     ipc_recv_kernel(T* __restrict__ vec, const int64_t* __restrict__ index, int64_t offset,
                     const IpcChunk* __restrict__ chunks, const IpcPeer* __restrict__ peers, unsigned* counters,
-                    uint64_t* status, uint64_t seq, uint64_t budget, IpcJoin join) {
+                    uint64_t* status, uint64_t seq, uint64_t budget, IpcJoin join, int fenced) {
   const IpcChunk c = chunks[blockIdx.x];
   const IpcPeer p = peers[c.nbr];
   __shared__ int ok;
-  if (threadIdx.x == 0) ok = ipc_wait(p.flag_in, seq, status, budget);  // the neighbour's message seq is complete
+  if (threadIdx.x == 0) {
+    ok = ipc_wait(p.flag_in, seq, status, budget);  // the neighbour's message seq is complete
+    if (fenced) ipc_acquire_system();
+  }
   __syncthreads();
   if (ok) {
     const T* src = reinterpret_cast<const T*>(p.data);
@@ -377,6 +399,7 @@ struct IpcState {
   bool sent_recorded = false, done_recorded = false;  // the events of the exchange in flight were recorded (caller not on the communicator's stream)
   unsigned* join_counter = nullptr;  // workgroups of a receive kernel that have finished (ipc_kernel_done)
   int memory_kind = 0;  // 0 fine-grained, 1 uncached, 2 ordinary
+  int fenced = 0;       // FUS_IPC_FENCED=1 at creation: system-scope release / acquire around the flags (ipc_release_system)
 };
 
 inline int64_t ipc_align(int64_t v, int64_t a) { return (v + a - 1) / a * a; }

@@ -101,8 +101,17 @@ inline LaunchSignal post_launch_signal(hipStream_t stream, uint64_t* flag, uint6
 // A launch that took a signal and then failed (hipGetLastError() != hipSuccess) has not published it: put it back, so that
 // the next planned launch of the stream -- or fus_comm_fork_flush / the next fork / join -- does.  Without this the
 // communicator's wait kernel (or gated send kernel) would spin for FUS_IPC_SPIN_SECONDS and poison the halo.
+// A signal another fork posted on the same stream between take and settle is handed back by post_launch_signal: it is published at
+// once by a one-thread kernel (as halo_comm.hpp's fork does with a displaced signal) -- dropped, its wait kernel would spin out.
+template <int = 0>
+__global__ void displaced_signal_kernel(uint64_t* flag, uint64_t seq) {
+  __hip_atomic_store(flag, seq, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
 inline hipError_t settle_launch_signal(hipStream_t stream, const LaunchSignal& sig, hipError_t e) {
-  if (e != hipSuccess && sig.flag != nullptr) (void)post_launch_signal(stream, sig.flag, sig.seq);
+  if (e != hipSuccess && sig.flag != nullptr) {
+    const LaunchSignal displaced = post_launch_signal(stream, sig.flag, sig.seq);
+    if (displaced.flag != nullptr) hipLaunchKernelGGL(displaced_signal_kernel<0>, dim3(1), dim3(1), 0, stream, displaced.flag, displaced.seq);
+  }
   return e;
 }
 // the signal still waiting to be carried for ``flag`` (no planned launch has come), with its stream; {nullptr} if none

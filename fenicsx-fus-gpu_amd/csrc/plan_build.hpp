@@ -145,6 +145,10 @@ inline hipError_t launch_plan_build_generic(const int32_t* dofmap, int N, int ep
     if (e != hipSuccess) return e;
     order = v.order;
   }
+  // the run tables are read SPECULATIVELY by the apply kernels (all kPlanMaxRuns words of a batch, whatever the builder wrote): clear
+  // them, so that no launch ever reads a word nobody wrote (the values are never used; initcheck-style tools would flag the reads)
+  e = hipMemsetAsync(v.runs, 0, (size_t)v.nbatch * (2 * kPlanMaxRuns) * sizeof(int32_t), stream);
+  if (e != hipSuccess) return e;
   const dim3 grid((unsigned)v.nbatch), block(256);
   if (M <= 256)
     hipLaunchKernelGGL((plan_build_kernel<256>), grid, block, 0, stream, dofmap, nent, N, epb, v.nu, v.udofs, v.runs, v.slot,

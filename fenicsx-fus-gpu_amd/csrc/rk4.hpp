@@ -35,6 +35,22 @@ namespace fus {
 //              reads b minv ku u v, writes u0 v0 b                                      (8 touches)
 // A step run as FIRST, MIDDLE, MIDDLE, LAST moves 41 vector touches instead of 48 with the same
 // arithmetic in the same order (bitwise the same u, v).
+//
+// LEAN kinds 4, 5, 6, 7 (round 6; one per stage of a step, used as a set; bw = b_runge[0] dt = dt / 6, aw = a_runge[1] dt = dt / 2, the
+// other coefficients are their exact doubles): 34 touches.  The floor argument: b must be complete before kv = b / m, so
+// every pass reads b, minv and re-zeroes b (3); passes 1-3 must write the next stage's (un, vn) (2) and need (u0, v0) for them (2);
+// passes 2-4 read vn of their own stage (1).  What is left is the traffic of the two accumulators, and it shrinks because
+//   * u's increments are the vn's, each KNOWN ONE PASS EARLY (vn_{i+1} is formed in pass i): pass 2 writes u0 + b1 v0 + b2 vn2 + b3 vn3,
+//     pass 3 adds b4 vn4 and writes the NEW u straight into u0 (u0 is dead once un4 has been formed) -- pass 4 does not touch u at all;
+//   * pass 1 writes neither accumulator: pass 2 reads u0, v0, vn2 anyway and re-derives u0 + b1 v0 and b1 kv1 = (vn2 - v0) b1 / a2 (a
+//     first-order difference scaled by b1 / a2 = 1 / 3: absolute error eps |v0| / 3, the size of v's own rounding).
+//   4 FIRST'   reads b minv u0 v0,            writes un ku b            (7)
+//   5 SECOND'  reads b minv u0 v0 ku,         writes u v un ku b        (10)   u = accumulator INCLUDING b3 vn3
+//   6 THIRD'   reads b minv u0 v0 ku u v,     writes u0 v un ku b       (12)   u0 = new u
+//   7 LAST'    reads b minv v,                writes v0 b               (5)    v0 = new v
+// u is formed with the reference's operations in the reference's order (bitwise the same); v differs from the sequence above in the
+// rounding of b1 kv1 only.  Deriving more (v's accumulator in pass 3 from un and u0) would divide a difference of u's by dt twice:
+// not done.
 // one dof of the stage (all operands in registers): the arithmetic of the table above
 template <typename T>
 struct Rk4In {
@@ -44,10 +60,53 @@ template <typename T>
 struct Rk4Out {
   T u, v, u0, v0, un, ku;
 };
+// which vectors a stage kind reads / writes (b and minv are always read, b is always re-zeroed)
+struct Rk4Access {
+  bool rd_u, rd_v, rd_0, rd_ku, wr_u, wr_v, wr_n, wr_u0, wr_v0;
+};
+__host__ __device__ __forceinline__ Rk4Access rk4_access(int kind) {
+  switch (kind) {
+    case 1: return {true, true, false, true, true, true, true, true, true};
+    case 2: return {false, false, true, false, true, true, true, false, false};
+    case 3: return {true, true, false, true, false, false, false, true, true};
+    case 4: return {false, false, true, false, false, false, true, false, false};
+    case 5: return {false, false, true, true, true, true, true, false, false};
+    case 6: return {true, true, true, true, false, true, true, true, false};
+    case 7: return {false, true, false, false, false, false, false, false, true};
+    default: return {true, true, true, true, true, true, true, false, false};  // 0 MIDDLE
+  }
+}
+// vector touches of one pass of kind ``kind`` (b read + zeroed, minv read, + the table above)
+__host__ __device__ constexpr int rk4_touches(int kind) {
+  constexpr int t[8] = {12, 12, 9, 8, 7, 10, 12, 5};
+  return t[kind & 7];
+}
 template <typename T>
 __device__ __forceinline__ Rk4Out<T> rk4_update(int kind, T bw, T aw, const Rk4In<T>& in) {
   Rk4Out<T> o{};
   const T kv = in.b * in.minv;
+  if (kind >= 4) {  // LEAN set: bw = dt / 6, aw = dt / 2
+    const T b2 = bw + bw, a4 = aw + aw;
+    if (kind == 4) {
+      o.un = in.u0 + aw * in.v0;
+      o.ku = in.v0 + aw * kv;
+    } else if (kind == 5) {
+      const T vn2 = in.ku, vn3 = in.v0 + aw * kv;
+      o.v = (in.v0 + (vn2 - in.v0) * (bw / aw)) + b2 * kv;
+      o.u = ((in.u0 + bw * in.v0) + b2 * vn2) + b2 * vn3;
+      o.un = in.u0 + aw * vn2;
+      o.ku = vn3;
+    } else if (kind == 6) {
+      const T vn3 = in.ku, vn4 = in.v0 + a4 * kv;
+      o.v = in.v + b2 * kv;
+      o.u0 = in.u + bw * vn4;
+      o.un = in.u0 + a4 * vn3;
+      o.ku = vn4;
+    } else {
+      o.v0 = in.v + bw * kv;
+    }
+    return o;
+  }
   if (kind == 2) {  // FIRST: u == u0, v == v0, ku == v0
     o.u = in.u0 + bw * in.v0;
     o.v = in.v0 + bw * kv;
@@ -91,16 +150,14 @@ __global__ void __launch_bounds__(256)
       };
       ld(b, rb, true);
       ld(minv, rm, true);
-      const bool rd_uv = kind != 2, rd_0 = kind == 0 || kind == 2, rd_ku = kind != 2;
-      if (rd_uv) {
-        ld(u, ru, true);
-        ld(v, rv, true);
-      }
-      if (rd_0) {
+      const Rk4Access a = rk4_access(kind);
+      if (a.rd_u) ld(u, ru, true);
+      if (a.rd_v) ld(v, rv, true);
+      if (a.rd_0) {
         ld(u0, ru0, true);
         ld(v0, rv0, true);
       }
-      if (rd_ku) ld(ku, rku, true);
+      if (a.rd_ku) ld(ku, rku, true);
       T ou[W], ov[W], ou0[W], ov0[W], oun[W], oku[W];
 #pragma unroll
       for (int k = 0; k < W; ++k) {
@@ -115,16 +172,14 @@ __global__ void __launch_bounds__(256)
         else
           *reinterpret_cast<V*>(p + i) = t;
       };
-      if (kind != 3) {
-        st(u, ou, true);
-        st(v, ov, true);
+      if (a.wr_u) st(u, ou, true);
+      if (a.wr_v) st(v, ov, true);
+      if (a.wr_n) {
         st(un, oun, true);
         st(ku, oku, true);
       }
-      if (kind == 1 || kind == 3) {
-        st(u0, ou0, true);
-        st(v0, ov0, true);
-      }
+      if (a.wr_u0) st(u0, ou0, true);
+      if (a.wr_v0) st(v0, ov0, true);
       T z[W];
 #pragma unroll
       for (int k = 0; k < W; ++k) z[k] = T(0);
@@ -132,11 +187,14 @@ __global__ void __launch_bounds__(256)
     } else {  // the last owned dofs (nlocal not a multiple of W) and the ghost block of b
       for (int64_t j = i; j < i + W && j < ntotal; ++j) {
         if (j < nlocal) {
-          const Rk4Out<T> o = rk4_update<T>(kind, bw, aw, Rk4In<T>{b[j], minv[j], kind != 2 ? u[j] : T(0), kind != 2 ? v[j] : T(0),
-                                                                     (kind == 0 || kind == 2) ? u0[j] : T(0), (kind == 0 || kind == 2) ? v0[j] : T(0),
-                                                                     kind != 2 ? ku[j] : T(0)});
-          if (kind != 3) u[j] = o.u, v[j] = o.v, un[j] = o.un, ku[j] = o.ku;
-          if (kind == 1 || kind == 3) u0[j] = o.u0, v0[j] = o.v0;
+          const Rk4Access a = rk4_access(kind);
+          const Rk4Out<T> o = rk4_update<T>(kind, bw, aw, Rk4In<T>{b[j], minv[j], a.rd_u ? u[j] : T(0), a.rd_v ? v[j] : T(0),
+                                                                     a.rd_0 ? u0[j] : T(0), a.rd_0 ? v0[j] : T(0), a.rd_ku ? ku[j] : T(0)});
+          if (a.wr_u) u[j] = o.u;
+          if (a.wr_v) v[j] = o.v;
+          if (a.wr_n) un[j] = o.un, ku[j] = o.ku;
+          if (a.wr_u0) u0[j] = o.u0;
+          if (a.wr_v0) v0[j] = o.v0;
         }
         b[j] = T(0);
       }

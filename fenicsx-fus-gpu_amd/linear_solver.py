@@ -25,6 +25,8 @@ Two stage implementations with identical results up to round-off:
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -124,6 +126,7 @@ class LinearSpectral3D(StepGraphMixin):
         self.f0, self.p0 = float(source_frequency), float(source_amplitude)
         self.w0 = 2.0 * np.pi * self.f0
         self.fused, self.source_time = bool(fused), source_time
+        self.lean_stages = os.environ.get("FUS_RK4_LEAN", "1") != "0"  # the fused stage's vector pass: kinds 4-7 of csrc/rk4.hpp (_stage_args)
         if comm is not None:  # an MPI.Comm (the reference's comm = MPI.COMM_WORLD) becomes the bootstrap of a NativeComm
             from .scatterer import as_comm
 
@@ -298,6 +301,16 @@ class LinearSpectral3D(StepGraphMixin):
             yield from self.halo.apply_schedule(u_n, self.cell_coeff2, self.b, self.G, self.dofmap,
                                                 extra_forward=[(self.fwd_v, v_n)], boundary_terms=facets)
 
+    def _stage_args(self, i, dt):
+        """``(bw, aw, kind)`` of the vector pass after stage ``i`` (csrc/rk4.hpp).  Default: the LEAN set 4, 5, 6, 7 with bw = b_runge[0] dt,
+        aw = a_runge[1] dt in all four passes (u's accumulator runs one pass ahead, 34 instead of 41 vector touches per linear step, 46
+        instead of 52 per Westervelt step; v differs from the reference's sequence in the rounding of one term); ``lean_stages = False``
+        (FUS_RK4_LEAN=0): kinds 2, 0, 0, 3, the reference's arithmetic operation for operation."""
+        if self.lean_stages:
+            return B_RUNGE[0] * dt, A_RUNGE[1] * dt, 4 + i
+        last = i == 3
+        return B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if i == 0 else 0)
+
     def rk4(self, start_time, final_time, dt, max_steps=None):
         """Advance from ``start_time`` to ``final_time`` (cuda/demo_linear_box.py:487-566).
         Returns ``(t, steps)``."""
@@ -338,8 +351,7 @@ class LinearSpectral3D(StepGraphMixin):
                         yield from self._operator_fused(tn if self.source_time == "tn" else t, self.u0, self.v0)
                     else:
                         yield from self._operator_fused(tn if self.source_time == "tn" else t)
-                    last = i == 3
-                    self._rk4_stage_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if i == 0 else 0))
+                    self._rk4_stage_kernel(*self._stage_args(i, dt))
             else:
                 ops.copy(self.u, self.u0)
                 ops.copy(self.v, self.v0)
@@ -375,7 +387,7 @@ class LinearSpectral3D(StepGraphMixin):
             first, last = i == 0, i == 3
             for _ in self._operator_fused(None, self.u0 if first else None, self.v0 if first else None, scalars=self._scal[i]):
                 pass
-            self._rk4_stage_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if first else 0))
+            self._rk4_stage_kernel(*self._stage_args(i, dt))
 
     def u_sol(self, with_ghosts=False):
         """Owned part of the pressure field on the host; ``with_ghosts``: the whole local vector after a forward scatter

@@ -13,6 +13,8 @@ The stage follows the reference's launch sequence through the reference-compatib
 
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 
@@ -322,7 +324,17 @@ class WesterveltSpectral3D(StepGraphMixin):
             first, last = i == 0, i == 3
             for _ in self._operator_fused(None, self.u0 if first else None, self.v0 if first else None, scalars=self._scal[i]):
                 pass
-            self._stage_vector_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if first else 0))
+            self._stage_vector_kernel(*self._stage_args(i, dt))
+
+    def _stage_args(self, i, dt):
+        """``(bw, aw, kind)`` of the vector pass after stage ``i`` (csrc/rk4.hpp).  Default: the LEAN set 4, 5, 6, 7 with bw = b_runge[0] dt,
+        aw = a_runge[1] dt in all four passes (u's accumulator runs one pass ahead, 34 instead of 41 vector touches per linear step, 46
+        instead of 52 per Westervelt step; v differs from the reference's sequence in the rounding of one term); ``lean_stages = False``
+        (FUS_RK4_LEAN=0): kinds 2, 0, 0, 3, the reference's arithmetic operation for operation."""
+        if self.lean_stages:
+            return B_RUNGE[0] * dt, A_RUNGE[1] * dt, 4 + i
+        last = i == 3
+        return B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if i == 0 else 0)
 
     def rk4(self, start_time, final_time, dt, max_steps=None):
         gen = self.rk4_schedule(start_time, final_time, dt, max_steps)
@@ -357,8 +369,7 @@ class WesterveltSpectral3D(StepGraphMixin):
                         yield from self._operator_fused(tn if self.source_time == "tn" else t, self.u0, self.v0)
                     else:
                         yield from self._operator_fused(tn if self.source_time == "tn" else t)
-                    last = i == 3
-                    self._stage_vector_kernel(B_RUNGE[i] * dt, 0.0 if last else A_RUNGE[i + 1] * dt, 3 if last else (2 if i == 0 else 0))
+                    self._stage_vector_kernel(*self._stage_args(i, dt))
             else:
                 ops.copy(self.u, self.u0)
                 ops.copy(self.v, self.v0)

@@ -461,8 +461,10 @@ class _MassApply:
         return True
 
     def refresh(self):
-        """``static_detJ=True``: forget the row-ordered copies of detJ (after changing a detJ array IN PLACE through anything
-        but torch -- torch's own in-place operations are noticed by themselves)."""
+        """``static_detJ=True``: forget the row-ordered copies of detJ.  REQUIRED after changing a detJ array in place through
+        anything that writes through ``data_ptr()`` -- which includes THIS package's own vector ops (``fill`` / ``copy`` / ``axpy`` /
+        ``pointwise_divide``) and every other C-ABI kernel (``compute_scaled_jacobian_determinant_device`` into the same array):
+        they do not bump torch's version counter, the only change the cache notices by itself (torch's own in-place operations)."""
         _STATIC_DETJ.clear()
 
     def apply_rows(self, x, entity_constants, y, entity_detJ, entity_dofmap, row_set, which):
@@ -495,8 +497,9 @@ class _MassOperator(_Launchable):
         ``static_detJ=True`` (opt-in): the caller declares ``entity_detJ`` constant across applies -- it is what the reference's
         drivers do (one detJ array for the whole run, cuda/demo_nonlinear_bowl.py:603-632) -- and the operator keeps a copy of it
         in ROW order next to the transposed dofmap: the kernel streams detJ instead of gathering it through the entry ids
-        (bitwise the same result; ``op.refresh()`` after changing detJ in place behind torch's back).  The constants are read per
-        apply and may change."""
+        (bitwise the same result).  The copy is a SNAPSHOT: call ``op.refresh()`` after writing into detJ with anything but torch's
+        own in-place operations -- this package's vector ops and device precompute write through ``data_ptr()`` and are NOT noticed.
+        The constants are read per apply and may change."""
         return _MassApply(int(N), _lib.torch_dtype(float_type), exclusive, atomic, static_detJ)
 
     @staticmethod

@@ -476,7 +476,8 @@ class _NativeScatter:
         _lib.check(self._lib.fus_halo_ipc_status(self.handle, out), "fus_halo_ipc_status", self.comm.handle)
         return {"failures": int(out[0]), "timeouts": int(out[4]), "poisoned": int(out[5]), "dead": bool(out[6]),
                 "forward_posted": int(out[1]), "reverse_posted": int(out[2]),
-                "arena_memory": ("fine-grained", "uncached", "ordinary")[int(out[3])]}
+                "arena_memory": ("fine-grained", "uncached", "ordinary")[int(out[3])],
+                "fenced": bool(out[7])}  # FUS_IPC_FENCED=1 at creation: system-scope release / acquire around the flags
 
     def begin(self, buffer):
         _lib.require_device_tensor(buffer, self.dtype, "buffer")

@@ -183,6 +183,12 @@ int fus_stiffness_apply_planned_geom_f32(const float* x, const float* cell_const
  * apply.  fus_plan_entities_per_batch(N) returns the preferred batch size (for cells it equals
  * the stiffness plan's, so ONE workspace built from the cell dofmap serves both operators:
  * fus_stiffness_plan_build(dofmap, P, ...) == fus_plan_build(dofmap, n^3, fus_plan_entities_per_batch(n^3), ...)).
+ *
+ * SYNCHRONISATION: fus_plan_build / fus_plan_build_ordered / fus_stiffness_plan_build enqueue the build kernels on ``stream`` and then
+ * BLOCK THE HOST until they have run (one 8-byte device-to-host copy + hipStreamSynchronize: the number of batches that carry a run
+ * table decides which list encoding the applies read).  They are set-up calls: not stream-asynchronous, and NOT legal inside a hipGraph
+ * stream capture (they return a HIP error there) -- build every plan before capturing (the Python side's StepGraphMixin warms its
+ * plans first).
  */
 int fus_plan_entities_per_batch(int ndof_per_entity);
 int64_t fus_plan_bytes(int ndof_per_entity, int entities_per_batch, int64_t nent);
@@ -338,6 +344,12 @@ int fus_facet_jacobian_f32(const float* x_g, const int32_t* x_dofs, const int32_
  * 2 = first stage (u, v, ku are read from u0, v0, v0: u = u0 + bw v0; v = v0 + bw kv; un = u0 + aw v0;
  * ku = v0 + aw kv) and 3 = last stage (u0 = u + bw ku; v0 = v + bw kv; nothing else written): 41
  * instead of 48 vector touches per step, same arithmetic.
+ * LEAN set new_step = 4, 5, 6, 7 (added in round 6, additive: no ABI bump; the four stages of ONE step, used together, with bw = b_runge[0] dt = dt / 6 and
+ * aw = a_runge[1] dt = dt / 2 in all four calls): 34 vector touches per step -- u's accumulator runs one stage ahead (its
+ * increments are the vn's, known one pass early), the first pass writes no accumulator, the third writes the new u straight
+ * into u0, the fourth touches v only; between the calls ``u`` holds an intermediate that is NOT the reference's u.  After the
+ * fourth call the new solution is in (u0, v0), as with 2, 0, 0, 3.  u bitwise as the sequence above; v differs in the rounding
+ * of ONE term (csrc/rk4.hpp).  Any other value: FUS_ERR_INVALID_ARGUMENT.
  */
 int fus_rk4_stage_f64(double bw, double aw, int new_step, const double* minv, double* b, double* u, double* v,
                       double* u0, double* v0, double* ku, double* un, int64_t nlocal, int64_t ntotal, void* stream);
@@ -357,7 +369,7 @@ int fus_rk4_stage_f32(float bw, float aw, int new_step, const float* minv, float
  *   fus_westervelt_cell_apply_planned[_geom]_* with c2 = c5 = m = detJ = NULL computes the stiffness part
  *   alone, b += K(c3) u + K(c4) v  (no detJ stream, one atomic flush, no m array);
  *   fus_rk4_stage_nl2_*: kv = (b + w5 v_n^2) / (m0 + w2 u_n) with (u_n, v_n) the stage's inputs ((u0, v0)
- *   for new_step = 2, else (un, ku)), then the updates of fus_rk4_stage_*.  If w != NULL it also writes
+ *   for new_step = 2 or 4, else (un, ku)), then the updates of fus_rk4_stage_* (new_step 0 ... 7).  If w != NULL it also writes
  *   w = u_n' + kappa v_n' of the NEXT stage's inputs: where c4 = kappa c3 in every cell the next cell pass is
  *   then ONE plain stiffness apply K(c3) w (one gather).
  * Same result as the four reference launches up to summation order.

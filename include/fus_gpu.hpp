@@ -156,7 +156,16 @@ struct GatherPlan {
   GatherPlan() = default;
   GatherPlan(const GatherPlan&) = delete;
   GatherPlan& operator=(const GatherPlan&) = delete;
+  void release() {
+    if (ws) {
+      (void)fus_plan_release(ws);
+      (void)hipFree(ws);
+    }
+    ws = nullptr;
+    ok = false;
+  }
   void build(const int32_t* dofmap, int ndof_per_entity, int64_t n_entities, int64_t ndofs, hipStream_t stream) {
+    release();  // a second enable_gather() replaces the first plan instead of leaking it
     const int64_t bytes = fus_mass_gather_plan_bytes(ndof_per_entity, n_entities, ndofs);
     if (bytes < 0) return;  // 2^31 entries or more: atomic kernel
     check_hip(hipMalloc(&ws, (size_t)bytes), "hipMalloc(gather plan workspace)");
@@ -165,12 +174,7 @@ struct GatherPlan {
     check(rc, "fus_mass_gather_plan_build");
     ok = true;
   }
-  ~GatherPlan() {
-    if (ws) {
-      (void)fus_plan_release(ws);
-      (void)hipFree(ws);
-    }
-  }
+  ~GatherPlan() { release(); }
 };
 // the static companion of a transposed dofmap (fus_mass_gather_static_build): detJ in row order; ``ok`` stays false when the
 // library declines (a block of 256 dofs spanning more than 65 535 entities): the functor then gathers detJ as before
@@ -180,8 +184,17 @@ struct GatherStaticPlan {
   GatherStaticPlan() = default;
   GatherStaticPlan(const GatherStaticPlan&) = delete;
   GatherStaticPlan& operator=(const GatherStaticPlan&) = delete;
+  void release() {
+    if (ws) {
+      (void)fus_plan_release(ws);
+      (void)hipFree(ws);
+    }
+    ws = nullptr;
+    ok = false;
+  }
   template <typename T>
   void build(const void* gather_ws, const T* detJ, int ndof_per_entity, int64_t n_entities, hipStream_t stream) {
+    release();
     const int64_t bytes = fus_mass_gather_static_bytes(ndof_per_entity, n_entities, (int)sizeof(T));
     if (bytes < 0) return;
     check_hip(hipMalloc(&ws, (size_t)bytes), "hipMalloc(static companion of the gather plan)");
@@ -190,12 +203,7 @@ struct GatherStaticPlan {
     check(rc, "fus_mass_gather_static_build");
     ok = true;
   }
-  ~GatherStaticPlan() {
-    if (ws) {
-      (void)fus_plan_release(ws);
-      (void)hipFree(ws);
-    }
-  }
+  ~GatherStaticPlan() { release(); }
 };
 }  // namespace detail
 
@@ -224,15 +232,21 @@ public:
   MassSpectral3D(const MassSpectral3D&) = delete;
   MassSpectral3D& operator=(const MassSpectral3D&) = delete;
   /// Opt in to the atomic-free kernel (one thread per dof over the transposed dofmap: no float atomics, bitwise
-  /// reproducible, 0.100 against 0.133 ms at P = 4 / 10 M dofs): ``ndofs`` = length of the vectors the operator is applied to
+  /// reproducible, 0.091 against 0.133 ms at P = 4 / 10 M dofs): ``ndofs`` = length of the vectors the operator is applied to
   /// (every dofmap value < ndofs).  A launch then assumes that nothing else adds into y while it runs (other launches of the
   /// same stream are fine); ``apply_atomic`` stays safe next to concurrent writers (a halo receive, another stream).
-  /// ``static_detJ`` (default): the functor's detJ never changes in its life (the reference's constructor computes it once,
-  /// cpp/common/spectral_op.hpp:60-66), so it is also kept in ROW order and the kernel streams it instead of gathering it through the
-  /// transposed dofmap (0.083 against 0.101 ms; bitwise the same result).  Pass false if the caller-owned detJ may change.
-  void enable_gather(const int32_t* dofmap, int64_t ndofs, hipStream_t stream = nullptr, bool static_detJ = true) {
+  /// ``static_detJ``: detJ is ALSO kept in ROW order and the kernel streams that copy instead of gathering detJ through the
+  /// transposed dofmap (0.080 against 0.091 ms; bitwise the same result) -- a snapshot that is never re-read.  kStaticAuto
+  /// (default): only where the functor OWNS detJ (the constructor that computes it once, as the reference's does,
+  /// cpp/common/spectral_op.hpp:60-66: nobody else can change it); a caller-owned detJ is gathered live unless the caller
+  /// promises with kStaticAlways (or ``true``) that it stays constant; kStaticNever (or ``false``): never.  Calling
+  /// enable_gather() again rebuilds both plans (and re-takes the snapshot).
+  static constexpr int kStaticAuto = -1, kStaticNever = 0, kStaticAlways = 1;
+  void enable_gather(const int32_t* dofmap, int64_t ndofs, hipStream_t stream = nullptr, int static_detJ = kStaticAuto) {
+    static_.release();  // (belongs to the gather plan that is about to be replaced)
     gather_.build(dofmap, Nd, Nc, ndofs, stream);
-    if (gather_.ok && static_detJ) static_.template build<T>(gather_.ws, detJ_, Nd, Nc, stream);
+    const bool snapshot = static_detJ == kStaticAuto ? detJ_own_.p != nullptr : static_detJ != kStaticNever;
+    if (gather_.ok && snapshot) static_.template build<T>(gather_.ws, detJ_, Nd, Nc, stream);
   }
   bool gather_enabled() const { return gather_.ok; }
   bool static_detJ_enabled() const { return static_.ok; }

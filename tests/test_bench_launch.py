@@ -135,10 +135,22 @@ def test_transport_fallback_after_a_failed_halo_check():
         cfg = _one_json_line(r.stdout)["config"]
         assert used in cfg["halo_transport"] and cfg["halo_check"]["ok"] is True
         tried = cfg["halo_transports_tried"]
-        # (a rejected PEER transport is tried once more with its arenas in fine-grained memory before RCCL gets its turn)
-        assert [t["transport"] for t in tried] == ["peer", "peer:finegrained", "native", "torch"][: len(reject.split(",")) + 2]
-        assert tried[1]["arena_memory_by_rank"] == ["fine-grained"]
+        # (a PEER transport rejected ON DATA is tried once more in its fenced form, then with its arenas in fine-grained memory, before
+        # RCCL gets its turn)
+        assert [t["transport"] for t in tried] == ["peer", "peer:fenced", "peer:finegrained", "native", "torch"][: len(reject.split(",")) + 3]
+        assert tried[1]["arena_memory_by_rank"] == ["uncached, fenced"] and tried[2]["arena_memory_by_rank"] == ["fine-grained"]
         assert all("rejected" in t["result"] for t in tried[:-1]) and tried[-1]["result"] == "ok"
+    # the middle rung of the ladder: only the fence-free PEER protocol fails its check -> the SAME arenas and kernels
+    # with a system-scope release before / acquire after every flag are brought up, checked and used; RCCL is never started
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--cells", "12", "--no-cpu-baseline"],
+                       env=_env(FUS_BENCH_FORCE_DIST="1", FUS_BENCH_TEST_REJECT="=peer"), capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    out = _one_json_line(r.stdout)
+    cfg = out["config"]
+    assert "PEER" in cfg["halo_transport"] and "FENCED" in cfg["halo_transport"] and cfg["halo_check"]["ok"] is True and out["check"]["ok"] is True
+    assert [t["transport"] for t in cfg["halo_transports_tried"]] == ["peer", "peer:fenced"] and cfg["halo_transports_tried"][1]["result"] == "ok"
+    assert cfg["halo_transports_tried"][1]["arena_memory_by_rank"] == ["uncached, fenced"]
+    assert set(cfg["halo_compare"]["transports"]) == {"peer:fenced", "peer", "native"}  # all three rungs timed in the one run
     r = subprocess.run([sys.executable, BENCH, "--gpus", "1", "--steps", "3", "--warmup", "1", "--cells", "12", "--no-cpu-baseline"],
                        env=_env(FUS_BENCH_FORCE_DIST="1", FUS_BENCH_TEST_REJECT="peer,native,torch"), capture_output=True, text=True, timeout=900)
     assert r.returncode != 0 and "no halo transport passed" in (r.stdout + r.stderr)
@@ -192,6 +204,7 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
             # P = 6 step (BASELINE config 5), each with ms, per-rank min / max, its exposed halo cost and its own halo check
             hc = cfg["halo_compare"]
             assert hc["chosen"] == "peer" and hc["transports"]["peer"]["ms_per_step_median"] > 0 and "rehearsal" in hc["not_compared"]["native"]
+            assert hc["transports"]["peer:fenced"]["ms_per_step_median"] > 0 and hc["transports"]["peer:fenced"]["failed_waits_all_ranks"] == 0
             sec = out["roofline"]["secondary"]
             for k in ("westervelt_geom", "rk4_geom", "mass", "rk4"):
                 v = sec[k]
@@ -218,16 +231,17 @@ def test_halo_compare_one_run_times_every_transport():
                        env=_env(FUS_BENCH_FORCE_DIST="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     hc = _one_json_line(r.stdout)["config"]["halo_compare"]
-    assert hc["chosen"] == "peer" and set(hc["transports"]) == {"peer", "native"} and hc["rounds"] == 5
+    assert hc["chosen"] == "peer" and set(hc["transports"]) == {"peer", "peer:fenced", "native"} and hc["rounds"] == 5
     for k, v in hc["transports"].items():
         assert v["ms_per_step_median"] > 0 and len(v["ms_per_step_rounds"]) == 5 and v["failed_waits_all_ranks"] == 0
         assert abs(v["exposed_ms"] - (v["ms_per_step_median"] - hc["one_launch_ms"])) < 1e-12
     assert hc["transports"]["native"]["max_rel_diff_vs_chosen"] < 1e-12 and "halo compare: peer:" in r.stderr
+    assert hc["transports"]["peer:fenced"]["max_rel_diff_vs_chosen"] < 1e-12 and "FENCED" in hc["transports"]["peer:fenced"]["transport"]
     r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--cells", "8", "--no-cpu-baseline", "--halo-compare"],
                        env=_env(FUS_BENCH_REHEARSAL="1"), capture_output=True, text=True, timeout=900)
     assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
     hc = _one_json_line(r.stdout)["config"]["halo_compare"]
-    assert set(hc["transports"]) == {"peer"} and "rehearsal" in hc["not_compared"]["native"]
+    assert set(hc["transports"]) == {"peer", "peer:fenced"} and "rehearsal" in hc["not_compared"]["native"]
 
 
 @pytest.mark.gpu
@@ -286,6 +300,8 @@ def test_default_line_carries_the_aux_entries():
     hp = aux["halo_proxy"]["transports"]
     assert hp["peer"]["failed_waits"] == 0 and hp["peer"]["single_launch_us"] > 0 and "exposed_pct" in hp["peer"]
     assert sec["halo_proxy"]["peer"]["pct"] == round(hp["peer"]["exposed_pct"], 1)
+    # the three rungs of the transport ladder on the one-GPU proxy: fence-free PEER, its fenced form, RCCL
+    assert set(hp) == {"peer", "peer:fenced", "native"} and hp["peer:fenced"]["failed_waits"] == 0 and "pct" in sec["halo_proxy"]["peer:fenced"]
     assert aux["westervelt_step_in_kernel_geometry"]["value"] > 0
 
 

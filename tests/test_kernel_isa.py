@@ -23,7 +23,26 @@ ROOT = os.path.abspath(os.path.join(os.path.dirname(__file__), ".."))
 CSRC = os.path.join(ROOT, "fenicsx-fus-gpu_amd", "csrc")
 HIPCC = os.environ.get("HIPCC", "/opt/rocm/bin/hipcc")
 
-pytestmark = pytest.mark.skipif(shutil.which("hipcc") is None and not os.path.exists(HIPCC), reason="hipcc not available")
+# The pins were taken with this compiler (``hipcc --version``: HIP 7.2.26015, AMD clang 22.0.0git roc-7.2.0).  Scheduling is the
+# compiler's: another release may order the loads differently with no functional or performance regression, so on any other
+# version a failing pin is reported as an expected failure (xfail, non-strict) instead of breaking the CPU suite.
+PINNED_HIP_VERSION = "7.2.26015"
+
+
+def _hip_version():
+    try:
+        out = subprocess.run([HIPCC, "--version"], capture_output=True, text=True).stdout
+    except OSError:
+        return None
+    m = re.search(r"HIP version:\s*([0-9.]+)", out)
+    return m.group(1) if m else None
+
+
+_have_hipcc = shutil.which("hipcc") is not None or os.path.exists(HIPCC)
+_pinned = _have_hipcc and _hip_version() == PINNED_HIP_VERSION
+pytestmark = [pytest.mark.skipif(not _have_hipcc, reason="hipcc not available"),
+              pytest.mark.xfail(condition=not _pinned, strict=False,
+                                reason=f"ISA pins were taken with HIP {PINNED_HIP_VERSION}; this is {_hip_version()}: scheduling may differ")]
 
 SOURCE = r"""
 #include "stiffness_plan.hpp"
@@ -34,7 +53,7 @@ namespace fus {
 template __global__ void stiffness_plan_kernel<double, 4, 10, true, true, 1, 5, false, true>(const double*, const double*, double*, const double*, const int32_t*, const int32_t*, const uint16_t*, const double*, int64_t, int, const int32_t*, const int32_t*, LaunchSignal);
 template __global__ void stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true, false, true>(const double*, const double*, double*, const double*, const int32_t*, const double*, const double*, const int32_t*, const int32_t*, const uint16_t*, const double*, int64_t, const int32_t*, const int32_t*, LaunchSignal);
 template __global__ void mass_gather_kernel<double, 1, true, 2, false>(const double*, const double*, double*, const double*, GatherView, double, int, int64_t, GatherStatic);
-template __global__ void ipc_send_kernel<double, true>(const double*, const int64_t*, int64_t, const IpcChunk*, const IpcPeer*, unsigned*, uint64_t*, uint64_t, uint64_t, IpcGate);
+template __global__ void ipc_send_kernel<double, true>(const double*, const int64_t*, int64_t, const IpcChunk*, const IpcPeer*, unsigned*, uint64_t*, uint64_t, uint64_t, IpcGate, int);
 }
 """
 

@@ -6,7 +6,8 @@ config 5's shape (P = 6, 36^3): distinct dofs per cell and kernel time for
   strips        two adjacent rows interleaved (plan_tiles.two_row_strip_order: 2 x 5 pieces at P = 4) -- through the operator
   2x2x5         P = 4 only, 20 cells per batch, 512-thread workgroups, 65 kB of LDS (2 workgroups per CU): needs a library built
                 with -DFUS_EXPERIMENT_GEOM_CPB20 (a copy of csrc/: ``make -B libfusgpu.so EXTRA_CXXFLAGS=-DFUS_EXPERIMENT_GEOM_CPB20``,
-                then FUS_LIB_PATH=tools/_bin/libfusgpu_cpb20.so); skipped otherwise
+                then FUS_LIB_PATH=tools/_bin/libfusgpu_cpb20.so); skipped otherwise.  Round 6 took that experimental branch OUT of the shipped
+                dispatch (measured +12.7 %, profiles/r05f_*): it lives in the history at d4461de:fenicsx-fus-gpu_amd/csrc/dispatch_geometry.hip
 
 Alternating rounds, medians."""
 import argparse
