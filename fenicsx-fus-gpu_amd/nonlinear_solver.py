@@ -73,6 +73,7 @@ class WesterveltSpectral3D(StepGraphMixin):
         self.delta = float(delta_cells.mean())
         self.source_time = source_time
         self.fused = bool(fused)
+        self.lean_stages = os.environ.get("FUS_RK4_LEAN", "1") != "0"  # the fused stage's vector pass: kinds 4-7 of csrc/rk4.hpp (_stage_args)
         P, n = self.P, self.P + 1
         dev = torch.device("cuda", torch.cuda.current_device())
         self.dev = dev
