@@ -202,6 +202,10 @@ _USE_GATHER = os.environ.get("FUS_MASS_GATHER", "1") != "0"
 # mean entries per touched dof above which the gather loses to the atomic batch plan: at P = 2 (27 / 8 = 3.4 entries per dof,
 # one-element detJ segments) 0.262 against 0.200 ms, at P = 3 (2.4) 0.142 against 0.158 (profiles/r04t_ab_mass_gather.log)
 _GATHER_MAX_MEAN_ENTRIES = 2.6
+# ... the STATIC-detJ form of the gather (detJ streamed in row order instead of gathered through one-element segments) wins up to P = 2:
+# 0.135 against 0.176 ms fp64 (0.60 of the roofline instead of 0.46), 0.071 against 0.134 ms fp32, where the plain gather takes 0.242 / 0.139
+# (profiles/r06g_ab_mass_low_degree.log).  P = 1 (8 entries per dof) stays on the atomic plan.
+_GATHER_STATIC_MAX_MEAN_ENTRIES = 4.0
 
 
 def use_mass_gather(flag: bool):
@@ -216,11 +220,13 @@ class _GatherPlanCache:
 
     def __init__(self, capacity: int = 16):
         self._plans = {}
+        self._static_only = set()  # keys of plans kept for the static-detJ form alone (the plain gather would lose: P = 2)
         self.capacity = capacity
 
-    def get(self, dofmap: torch.Tensor, ndofs: int, rows=None):
+    def get(self, dofmap: torch.Tensor, ndofs: int, rows=None, static=False):
         """``rows = (row_set, which)``: the plan of the dofs d with ``row_set[d] == which`` only (device uint8[ndofs]; the
-        partitioned apply's split into rows next to the exchanges and rows between them)."""
+        partitioned apply's split into rows next to the exchanges and rows between them).  ``static``: the caller will apply the
+        static-detJ form, which pays up to a higher mean number of entries per dof than the plain gather."""
         lib = _lib.load()
         nent, N = dofmap.shape
         key = (dofmap.data_ptr(), nent, N, dofmap._version, dofmap.device.index, int(ndofs))
@@ -248,17 +254,23 @@ class _GatherPlanCache:
                     info = (C.c_int64 * 4)()
                     _lib.check(lib.fus_mass_gather_plan_info(ws.data_ptr(), info), "fus_mass_gather_plan_info")
                     # (a row subset is judged by the full plan: the caller asks for it only when the full plan was kept)
-                    if rows is not None or (info[0] > 0 and nent * N <= _GATHER_MAX_MEAN_ENTRIES * info[0]):
+                    if rows is not None or (info[0] > 0 and nent * N <= _GATHER_STATIC_MAX_MEAN_ENTRIES * info[0]):
                         hit = (ws, dofmap, tuple(int(v) for v in info)) + ((rows[0],) if rows is not None else ())
+                        if rows is None and nent * N > _GATHER_MAX_MEAN_ENTRIES * info[0]:
+                            self._static_only.add(key)
                     else:
                         lib.fus_plan_release(ws.data_ptr())
                 elif rc != _lib.ERR_UNSUPPORTED_ENTITY:
                     _lib.check(rc, "fus_mass_gather_plan_build")
             if len(self._plans) >= self.capacity:
-                old = self._plans.pop(next(iter(self._plans)))
+                oldest = next(iter(self._plans))
+                old = self._plans.pop(oldest)
+                self._static_only.discard(oldest)
                 if old is not None:
                     lib.fus_plan_release(old[0].data_ptr())
             self._plans[key] = hit
+        if hit is not None and not static and key in self._static_only:
+            return None  # the plain gather would lose on this dofmap: the caller takes the atomic batch plan
         if hit is not None and _PLANS._recording is not None:
             _PLANS._recording.append((hit[0], hit[1]))  # a captured graph keeps the workspace alive
         return hit
@@ -272,6 +284,7 @@ class _GatherPlanCache:
             if hit is not None:
                 lib.fus_plan_release(hit[0].data_ptr())
         self._plans.clear()
+        self._static_only.clear()
 
 
 _GATHER_PLANS = _GatherPlanCache()
@@ -449,7 +462,7 @@ class _MassApply:
             raise ValueError("dofs per entity / number of constants do not match the dofmap")
         if nent == 0 or not _mass_gather_usable(nent, n_per):
             return False
-        plan = _GATHER_PLANS.get(entity_dofmap, min(x.numel(), y.numel()))
+        plan = _GATHER_PLANS.get(entity_dofmap, min(x.numel(), y.numel()), static=True)
         if plan is None:
             return False
         st = _STATIC_DETJ.get(plan[0], entity_detJ, n_per, nent)

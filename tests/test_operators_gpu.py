@@ -1325,6 +1325,16 @@ def test_mass_gather_policy_and_errors(gpu, oracle_c):
     y_ref = np.zeros(mesh.ndofs)
     oracle_c.mass_apply(pb["x"], pb["cc"], y_ref, pb["detJ"], mesh.dofmap)
     _check(y.cpu().numpy(), y_ref, np.float64, "P = 2 cell mass (atomic plan by policy)")
+    # round 6: the STATIC-detJ form pays at P = 2 too (0.60 against 0.46 of the roofline at 10 M dofs, profiles/r06g_ab_mass_low_degree.log):
+    # static_detJ=True takes the transposed dofmap + the row-ordered detJ there, the default operator keeps the atomic plan
+    ys = torch.zeros_like(y)
+    ops.mass_operator(27, np.float64, static_detJ=True)(x_d, cc_d, ys, dj_d, dm)
+    _check(ys.cpu().numpy(), y_ref, np.float64, "P = 2 cell mass, static-detJ gather")
+    assert len([v for v in ops._STATIC_DETJ._entries.values() if v is not None]) >= 1, "static_detJ=True must take the static gather path at P = 2"
+    assert ops.mass_kernel_name(dm, mesh.ndofs) == "fus::mass_plan_kernel"  # (the plan kept for the static form does not change the default)
+    ys2 = torch.zeros_like(y)
+    ops.mass_operator(27, np.float64, static_detJ=True)(x_d, cc_d, ys2, dj_d, dm)
+    assert torch.equal(ys, ys2), "the atomic-free kernel is bitwise reproducible"
     # ... but the kernel itself is right there too (policy threshold lifted)
     old = ops._GATHER_MAX_MEAN_ENTRIES
     ops._GATHER_MAX_MEAN_ENTRIES = 100.0

@@ -72,7 +72,26 @@ def main():
     def gather(y):
         lib.check(fn_g(x.data_ptr(), cc.data_ptr(), y.data_ptr(), detJ.data_ptr(), ws.data_ptr(), N, nent, lib.stream_ptr()), "gather")
 
+    # the static-detJ form (round 5): detJ in row order next to the transposed dofmap, streamed instead of gathered
+    sbytes = L.fus_mass_gather_static_bytes(N, nent, T)
+    sws, fn_s = None, getattr(L, f"fus_mass_apply_gather_static_{a.dtype}")
+    if sbytes > 0:
+        sws = torch.empty(int(sbytes), dtype=torch.uint8, device=dev)
+        rc = getattr(L, f"fus_mass_gather_static_build_{a.dtype}")(ws.data_ptr(), detJ.data_ptr(), sws.data_ptr(), int(sbytes), lib.stream_ptr())
+        if rc != 0:
+            print(f"static companion declined (rc {rc})")
+            sws = None
+
+    def static(y):
+        lib.check(fn_s(x.data_ptr(), cc.data_ptr(), y.data_ptr(), ws.data_ptr(), sws.data_ptr(), N, nent, lib.stream_ptr()), "gather static")
+
     ya, yb, yc = (torch.zeros(nd, dtype=x.dtype, device=dev) for _ in range(3))
+    if sws is not None:
+        static(yc)
+        gather(yb)
+        torch.cuda.synchronize()
+        print(f"static-detJ gather vs gather: bitwise equal: {bool(torch.equal(yb, yc))}")
+        yb.zero_(), yc.zero_()
     plan(ya)
     gather(yb)
     gather(yc)
@@ -98,6 +117,8 @@ def main():
     variants = [int(v) for v in a.variants.split(",")]
     res = {"plan": []}
     res.update({f"gather:{v}": [] for v in variants})
+    if sws is not None:
+        res.update({f"static:{v}": [] for v in variants})
     for fn in (plan, gather):
         timeit(fn, ya)
     for _ in range(a.rounds):
@@ -105,6 +126,8 @@ def main():
         for v in variants:
             lib.set_tuning(lib.TUNE_MASS_VARIANT, v)
             res[f"gather:{v}"].append(timeit(gather, yb))
+            if sws is not None:
+                res[f"static:{v}"].append(timeit(static, yc))
         lib.set_tuning(lib.TUNE_MASS_VARIANT, 0)
     for k, v in res.items():
         med = float(np.median(v))

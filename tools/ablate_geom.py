@@ -31,17 +31,19 @@ def main():
     op(x, cc, y, None, dm)
     torch.cuda.synchronize()
     print(f"   one apply on y = 0: sum |y| = {float(y.abs().sum()):.15e}  y[12345] = {float(y[12345]):.15e}", flush=True)
-    for _ in range(300):
+    short = os.environ.get("ABLATE_SHORT") == "1"  # under rocprofv3 --pmc: a few launches are enough
+    for _ in range(10 if short else 300):
         op(x, cc, y, None, dm)
     ts = []
-    for _ in range(5):
+    for _ in range(1 if short else 5):
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         e0.record()
-        for _ in range(200):
+        nrep = 20 if short else 200
+        for _ in range(nrep):
             op(x, cc, y, None, dm)
         e1.record()
         torch.cuda.synchronize()
-        ts.append(e0.elapsed_time(e1) / 200 * 1e3)
+        ts.append(e0.elapsed_time(e1) / nrep * 1e3)
     print(f"P={P} {N}^3  {os.path.basename(lib_mod.LIB_PATH):28s} {np.median(ts):7.1f} us   rounds {' '.join(f'{t:.1f}' for t in ts)}", flush=True)
     phase_report(lib_mod, lambda: op(x, cc, y, None, dm), np.median(ts))
 
