@@ -207,7 +207,7 @@ def bench_rk4(args, rank, world, device):
     scat = fusgpu_loader.submodule("scatterer")
     comm = first_comm(args, scat, world, device)[0] if world > 1 else None
     out = measure_rk4(args, rank, world, device, args.mode, args.perturbed, args.in_kernel_geometry, args.steps, args.warmup, comm,
-                      cpu_leg=not args.no_cpu_baseline, single_gather=args.single_gather)
+                      cpu_leg=not args.no_cpu_baseline, single_gather=args.single_gather, check=not args.no_check)
     if rank == 0:
         emit(out)
     if world > 1:
