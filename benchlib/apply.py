@@ -256,12 +256,6 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
             op.prepare(dm_d)
         kern_ms = timed_launches(lambda: op(x_d, cc_d, y_d, G_d, dm_d))
         sched_ms = timed_launches(lambda: halo.apply_no_exchange(x_d, cc_d, y_d, G_d, dm_d))
-        if args.halo_compare:
-            try:
-                halo_compare = compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, transport, halo, kern_ms)
-            except Exception as e:  # noqa: BLE001
-                log(f"rank {rank}: --halo-compare failed: {e!r}")
-                halo_compare = {"error": repr(e)}
     else:
         kern_ms = region_ms  # N = 1: the step IS the stiffness kernel launch
 
@@ -469,22 +463,58 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
         bad_aux = failed_aux_checks(out["aux"])
         if bad_aux:
             out["valid"] = False
+    # ---- N > 1 extras: everything from here on is OPTIONAL next to the headline, which is measured and checked by now.  A phase that hangs
+    # (a transport's bring-up on a platform it has never seen, a collective whose peer is gone) must not take the line with it: a timer emits what
+    # the run has -- the headline with its check, and what the extras finished -- and leaves (every rank has its own; rank 0 prints)
+    extras_timer, extras_phase = None, ["halo_compare"]
+    if use_dist and halo is not None:
+        import threading
+
+        budget = float(os.environ.get("FUS_BENCH_EXTRAS_TIMEOUT_S", "420"))
+
+        def bail():
+            log(f"rank {rank}: the optional phases did not finish in {budget:.0f} s (in: {extras_phase[0]}): the line is emitted without the rest")
+            out["extras_timed_out"] = {"seconds": budget, "phase": extras_phase[0]}
+            if rank == 0:
+                try:
+                    out["roofline"]["secondary"] = secondary_summary(out)
+                except Exception:  # noqa: BLE001
+                    pass
+                emit(out)
+            os._exit(0 if (check is None or check["ok"]) else 3)
+
+        if budget > 0:
+            extras_timer = threading.Timer(budget, bail)
+            extras_timer.daemon = True
+            extras_timer.start()
+        if os.environ.get("FUS_BENCH_TEST_HANG_EXTRAS") == str(rank):  # test hook: this rank never reaches the optional phases
+            time.sleep(3600)
+    if use_dist and halo is not None and args.halo_compare:
+        try:
+            halo_compare = compare_transports(args, rank, world, device, scat, mesh, op, dt, x_d, cc_d, y_d, G_d, dm_d, transport, halo, kern_ms)
+        except Exception as e:  # noqa: BLE001
+            log(f"rank {rank}: halo compare failed: {e!r}")
+            halo_compare = {"error": repr(e)}
+        out["config"]["halo_compare"] = halo_compare
+    extras_phase[0] = "harvest"
     harvested = None
     if use_dist and halo is not None and not (geom or mass) and not args.no_harvest and not args.no_plan:
         # N > 1, the driver's fixed command (no extra flags): the other lines of the path on the SAME partition and communicator, after
         # the headline's timed region -- partitioned mass apply, fused RK4 steps, Westervelt P = 6 step (BASELINE config 5)
+        harvested = out["harvest"] = {}
         try:
-            harvested = harvest(args, rank, world, device, halo.comm, mesh, dt, x_d, cc_d, y_d, dm_d, dphi_g, wts3, x, cc, ops, pre,
-                                budget_s=float(os.environ.get("FUS_BENCH_HARVEST_BUDGET_S", "150")))
+            harvest(args, rank, world, device, halo.comm, mesh, dt, x_d, cc_d, y_d, dm_d, dphi_g, wts3, x, cc, ops, pre,
+                    budget_s=float(os.environ.get("FUS_BENCH_HARVEST_BUDGET_S", "150")), into=harvested)
         except Exception as e:  # noqa: BLE001
             log(f"rank {rank}: harvest failed: {e!r}")
-            harvested = {"error": repr(e)}
-        out["harvest"] = harvested
+            harvested["error"] = repr(e)
     if out.get("aux") is not None or check is not None or harvested is not None:
         try:
             out["roofline"]["secondary"] = secondary_summary(out)
         except Exception as e:  # noqa: BLE001
             log(f"roofline.secondary failed: {e!r}")
+    if extras_timer is not None:
+        extras_timer.cancel()
     if rank == 0:
         emit(out)
     failed = (check is not None and not check["ok"]) or bool(bad_aux)

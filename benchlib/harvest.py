@@ -152,13 +152,14 @@ def _step_line(r):
             "degree": cfg["degree"], "cells_per_gpu": cfg["cells_per_gpu"], "global_dofs": cfg["global_dofs"], "geometry": cfg["geometry"]}
 
 
-def harvest(args, rank, world, device, comm, mesh, dt, x_d, cc_d, y_d, dm_d, dphi_g, wts3, x, cc, ops, pre, budget_s=150.0):
-    """The secondary lines of an N > 1 run; returns ``{name: line | {"skipped": reason} | {"error": ...}, "seconds": ...}``."""
+def harvest(args, rank, world, device, comm, mesh, dt, x_d, cc_d, y_d, dm_d, dphi_g, wts3, x, cc, ops, pre, budget_s=150.0, into=None):
+    """The secondary lines of an N > 1 run; returns ``{name: line | {"skipped": reason} | {"error": ...}, "seconds": ...}`` (filled line by
+    line into ``into`` where given: a run whose optional phases are cut short keeps what was finished)."""
     import torch
     import torch.distributed as dist
 
     t_start = time.perf_counter()
-    out = {}
+    out = into if into is not None else {}
     steps = max(1, min(args.steps, 20))
     wargs = argparse.Namespace(**{**vars(args), "degree": 6, "cells": max(4, round(args.cells * 2 / 3))})  # 54 -> 36: the same dof count per GPU
 

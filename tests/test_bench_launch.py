@@ -223,6 +223,23 @@ def test_multi_rank_rehearsal_on_one_gpu(n, mode):
 
 
 @pytest.mark.gpu
+def test_hung_optional_phase_does_not_take_the_headline_with_it():
+    """N > 1: the transport comparison and the harvest are optional next to the headline, which is measured and checked before them.  A rank
+    that never reaches them (test hook) leaves the others inside a collective: every rank's timer ends the run, rank 0 prints the line it has --
+    valid headline, its check, ``extras_timed_out`` -- and the exit code is 0."""
+    import time
+
+    t0 = time.time()
+    r = subprocess.run([sys.executable, BENCH, "--gpus", "2", "--steps", "3", "--warmup", "1", "--cells", "8", "--no-cpu-baseline"],
+                       env=_env(FUS_BENCH_REHEARSAL="1", FUS_BENCH_TEST_HANG_EXTRAS="1", FUS_BENCH_EXTRAS_TIMEOUT_S="25"), capture_output=True, text=True, timeout=600)
+    assert r.returncode == 0, (r.stdout + r.stderr)[-3000:]
+    assert time.time() - t0 < 300
+    out = _one_json_line(r.stdout)
+    assert out["extras_timed_out"]["phase"] == "halo_compare" and out["check"]["ok"] is True and out["value"] > 0
+    assert out["config"]["halo_check"]["ok"] is True and "the line is emitted without the rest" in r.stderr
+
+
+@pytest.mark.gpu
 def test_halo_compare_one_run_times_every_transport():
     """``--halo-compare``: ONE run times the apply over every transport that comes up, in alternating rounds, and puts each one's
     exposed cost in ``config.halo_compare``.  1-rank world through the N > 1 code path: PEER and RCCL both come up; 2 rehearsal
