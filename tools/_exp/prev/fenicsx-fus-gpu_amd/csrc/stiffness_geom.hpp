@@ -71,50 +71,6 @@ __device__ __forceinline__ void column_g_at(T ex, T wx_s0, const T (&J0)[3], con
   gq[5] = s * (A[0][2] * A[0][2] + A[1][2] * A[1][2] + A[2][2] * A[2][2]);
 }
 
-// The flux G (vx, vy, vz) at quadrature plane qx WITHOUT forming G (round 6): with the columns of adj(J_)
-//   a = J1 x J2,   b = J2 x J0,   c = J0 x J1        (A[d][0], A[d][1], A[d][2] of column_g_at)
-// G = s [col_alpha . col_beta], so  G v = s (a . w, b . w, c . w)  with  w = a vx + b vy + c vz:  9 + 12 operations instead of the 24 of
-// the six scaled dot products + 9 of the symmetric product -- 55 instead of 67 fp64 operations per quadrature point.  The kernels that form
-// the factor INSIDE their main loop use it (in-kernel geometry from degree 6, every Westervelt cell pass with in-kernel geometry): they are
-// bound by instruction issue.  Same conventions and the same reciprocal as column_g_at; the result differs from G v in rounding only.
-template <typename T>
-__device__ __forceinline__ void column_flux_at(T ex, T wx_s0, const T (&J0)[3], const T (&Ja)[3], const T (&Jba)[3], const T (&Jc)[3],
-                                               const T (&Jdc)[3], T vx, T vy, T vz, T& fx, T& fy, T& fz) {
-  T J1[3], J2[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) {
-    J1[d] = Ja[d] + ex * Jba[d];
-    J2[d] = Jc[d] + ex * Jdc[d];
-  }
-  T a[3], b[3], c[3];
-  a[0] = J1[1] * J2[2] - J1[2] * J2[1];
-  a[1] = J1[2] * J2[0] - J1[0] * J2[2];
-  a[2] = J1[0] * J2[1] - J1[1] * J2[0];
-  b[0] = J0[2] * J2[1] - J0[1] * J2[2];
-  b[1] = J0[0] * J2[2] - J0[2] * J2[0];
-  b[2] = J0[1] * J2[0] - J0[0] * J2[1];
-  c[0] = J0[1] * J1[2] - J0[2] * J1[1];
-  c[1] = J0[2] * J1[0] - J0[0] * J1[2];
-  c[2] = J0[0] * J1[1] - J0[1] * J1[0];
-  const T det = J0[0] * a[0] + J0[1] * a[1] + J0[2] * a[2];
-  const T ad = det < T(0) ? -det : det;
-  T s;
-  if constexpr (sizeof(T) == 8) {
-    double r = __builtin_amdgcn_rcp((double)ad);
-    r = r * (2.0 - (double)ad * r);
-    r = r * (2.0 - (double)ad * r);
-    s = wx_s0 * (T)r;
-  } else {
-    s = wx_s0 / ad;
-  }
-  T w[3];
-#pragma unroll
-  for (int d = 0; d < 3; ++d) w[d] = s * (a[d] * vx + b[d] * vy + c[d] * vz);
-  fx = a[0] * w[0] + a[1] * w[1] + a[2] * w[2];
-  fy = b[0] * w[0] + b[1] * w[1] + b[2] * w[2];
-  fz = c[0] * w[0] + c[1] * w[1] + c[2] * w[2];
-}
-
 // Rows of J_ along the column (xi_y, xi_z) = (ey, ez) of a trilinear cell with vertex coordinates
 // X[(vx + 2 vy + 4 vz) * 3 + d]:  J_[0] = J0,  J_[1] = Ja + xi_x Jba,  J_[2] = Jc + xi_x Jdc.
 template <typename T>
@@ -323,17 +279,12 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int qx = 0; qx < n; ++qx) {
       T vx, vy, vz;
       plan_grad_at<T, n, n2>(qx, dphi, u, dy, dz, cu_y, cu_z, vx, vy, vz);
-      if constexpr (PREG) {
-        const T* gq = g[PREG ? qx : 0];
-        fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
-        cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
-        cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
-      } else {  // the flux without forming G (column_flux_at); pts / wts with compile-time indices: scalar loads
-        T fy, fz;
-        column_flux_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, vx, vy, vz, fx[qx], fy, fz);
-        cfy[qx * n2] = fy;
-        cfz[qx * n2] = fz;
-      }
+      T gl[6];
+      if constexpr (!PREG) column_g_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, gl);  // compile-time index: scalar loads
+      const T* gq = PREG ? g[PREG ? qx : 0] : gl;
+      fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
+      cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
+      cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
     }
   }
   __syncthreads();

@@ -9,7 +9,8 @@ N variants x M rounds on one workload; prints median / min per variant.
                         buffer, 1 LDS-aliased, 2 LDS-aliased + G ring, 30 fp32 5-waves)
           ``raw:K``     the same reading the plan's dof lists instead of its run tables (FUS_TUNE_PLAN_RUNS = 0)
           ``runs:K``    the same reading the run tables whatever the dtype (FUS_TUNE_PLAN_RUNS = 2)
-          ``geom``      geometry formed in the kernel from the 8 vertices (no G stream)
+          ``geom``      geometry formed in the kernel from the 8 vertices (no G stream); ``geom:50`` / ``geom:51``: P <= 5 with the flux formed
+                        inside the main loop (column_flux_at) at 4 / 3 waves per SIMD instead of the n x 6 factors held in registers
           ``col:V``     plan-free column kernel, workgroup variant V (0: ~256 threads, 1: ~128)
 Add ``@x`` to a cfg to run it with the XCD remap on.  Two builds of the library are compared by
 alternating runs of this tool with FUS_LIB_PATH=<other libfusgpu.so> on one box.  Results of the studies run with this tool: profiles/r0*_ab_*.log."""
@@ -81,6 +82,7 @@ def main():
                 lib.set_tuning(lib.TUNE_STIFFNESS_VARIANT, max(k, 0))
             elif kind == "geom":
                 fn = opg
+                lib.set_tuning(lib.TUNE_PLAN_VARIANT, k)  # geom:50 / geom:51: the flux formed in the main loop for P <= 5 too (dispatch_geometry.hip)
             else:
                 lib.set_tuning(lib.TUNE_PLAN_VARIANT, k)
             lib.set_tuning(lib.TUNE_PLAN_RUNS, {"raw": 0, "runs": 2}.get(kind, 1))
@@ -113,6 +115,7 @@ def main():
         gbs = mesh.ncells * bpc / (np.median(t) * 1e-3) / 1e9
         print(f"{name:12s}: median {np.median(t):.4f} ms  min {t.min():.4f} ms  {gbs:.0f} GB/s of general-G bytes "
               f"({100 * gbs / 8000:.1f}% of 8 TB/s)  {mesh.ndofs / np.median(t) / 1e6:.2f} GDOF/s")
+        print(f"{'':12s}  rounds: " + " ".join(f"{v:.4f}" for v in t))
 
 
 if __name__ == "__main__":
