@@ -48,20 +48,10 @@ int stiffness_apply_planned_geom(const T* x, const T* cc, T* y, const T* x_g, co
   hipStream_t s = static_cast<hipStream_t>(stream);
   if (!plan_check(ws, (P + 1) * (P + 1) * (P + 1), cells_per_batch(P), ncell, &ord, nullptr, &rp)) return FUS_ERR_PLAN_MISMATCH;
   hipError_t e = hipErrorInvalidValue;
-  // FUS_TUNE_PLAN_VARIANT = 50 (A/B runs): degrees <= 5 form the flux inside the main loop too (column_flux_at) instead of holding the n x 6
-  // factors in registers
-  // (50: register allocation capped at 4 waves per SIMD -- P = 4 fp64: 128 VGPRs + 12 bytes of scratch; 51: the compiler's own -- 135 VGPRs, 3 waves)
-  const int pv_ = g_plan_variant.load(std::memory_order_relaxed);
-  const bool in_loop = pv_ == 50 || pv_ == 51;
   switch (P) {
 #define FUS_CASE(PP) \
   case PP:           \
-    if (in_loop && PP <= 5 && pv_ == 50) \
-      e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, 4, false>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
-    else if (in_loop && PP <= 5) \
-      e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, 1, false>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
-    else \
-      e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
+    e = fus::launch_stiffness_plan_geom<T, PP, (PP >= 4), true, fus::geom_min_waves<T, PP>(), (PP <= 5)>(x, cc, y, x_g, x_dofs, pts, wts, ws, dphi, ncell, s, ord, plan_use_runs<T>((P + 1) * (P + 1) * (P + 1), rp)); \
     break;
     FUS_CASE(1) FUS_CASE(2) FUS_CASE(3) FUS_CASE(4) FUS_CASE(5) FUS_CASE(6) FUS_CASE(7) FUS_CASE(8) FUS_CASE(9)
     FUS_CASE(10)

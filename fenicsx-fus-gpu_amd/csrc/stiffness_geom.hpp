@@ -74,9 +74,17 @@ __device__ __forceinline__ void column_g_at(T ex, T wx_s0, const T (&J0)[3], con
 // The flux G (vx, vy, vz) at quadrature plane qx WITHOUT forming G (round 6): with the columns of adj(J_)
 //   a = J1 x J2,   b = J2 x J0,   c = J0 x J1        (A[d][0], A[d][1], A[d][2] of column_g_at)
 // G = s [col_alpha . col_beta], so  G v = s (a . w, b . w, c . w)  with  w = a vx + b vy + c vz:  9 + 12 operations instead of the 24 of
-// the six scaled dot products + 9 of the symmetric product -- 55 instead of 67 fp64 operations per quadrature point.  The kernels that form
-// the factor INSIDE their main loop use it (in-kernel geometry from degree 6, every Westervelt cell pass with in-kernel geometry): they are
-// bound by instruction issue.  Same conventions and the same reciprocal as column_g_at; the result differs from G v in rounding only.
+// the six scaled dot products + 9 of the symmetric product -- 55 instead of 67 fp64 operations per quadrature point; these kernels are bound
+// by instruction issue.  Same conventions and the same reciprocal as column_g_at; the result differs from G v in rounding only.
+// Used WHERE MEASURED FASTER (geom_flux_operator_form; profiles/r06j_*, r06k_*, r06l_*: interleaved with the build before it): the in-loop
+// builds at fp64 P = 6, 8, 9 (-2.2, -2.7, -0.5 %) and the Westervelt cell pass at fp64 P = 6 (step -1.5 %); NOT at P = 7 (+8 % in the steady
+// state: the first 100-launch burst equal, every later one slower), P = 10 (+1.4 %), fp32 from P = 5 (+4 ... +5 %).  For P <= 5 the in-loop form
+// would also win (fp64 -1.8 ... -3.4 %) but needs 128 VGPRs + 12 bytes of scratch at P = 4 to keep four waves per SIMD: those degrees keep the
+// n x 6 factors in registers (PREG), formed between the gather's barriers.
+template <typename T, int P>
+__host__ __device__ constexpr bool geom_flux_operator_form() {
+  return sizeof(T) == 8 && (P == 6 || P == 8 || P == 9);
+}
 template <typename T>
 __device__ __forceinline__ void column_flux_at(T ex, T wx_s0, const T (&J0)[3], const T (&Ja)[3], const T (&Jba)[3], const T (&Jc)[3],
                                                const T (&Jdc)[3], T vx, T vy, T vz, T& fx, T& fy, T& fz) {
@@ -323,16 +331,18 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int qx = 0; qx < n; ++qx) {
       T vx, vy, vz;
       plan_grad_at<T, n, n2>(qx, dphi, u, dy, dz, cu_y, cu_z, vx, vy, vz);
-      if constexpr (PREG) {
-        const T* gq = g[PREG ? qx : 0];
-        fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
-        cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
-        cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
-      } else {  // the flux without forming G (column_flux_at); pts / wts with compile-time indices: scalar loads
+      if constexpr (!PREG && geom_flux_operator_form<T, P>()) {  // the flux without forming G; pts / wts with compile-time indices: scalar loads
         T fy, fz;
         column_flux_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, vx, vy, vz, fx[qx], fy, fz);
         cfy[qx * n2] = fy;
         cfz[qx * n2] = fz;
+      } else {
+        T gl[6];
+        if constexpr (!PREG) column_g_at<T>(pts[qx], wts[qx] * s0, J0, Ja, Jba, Jc, Jdc, gl);
+        const T* gq = PREG ? g[PREG ? qx : 0] : gl;
+        fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
+        cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
+        cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
       }
     }
   }

@@ -161,10 +161,18 @@ __global__ void __launch_bounds__((col_block_threads<P, CPB>()), MINW)
     for (int qx = 0; qx < n; ++qx) {
       T vx, vy, vz;
       plan_grad_at<T, n, n2>(qx, dphi, w, dy, dz, cu_y, cu_z, vx, vy, vz);
-      T fy, fz;  // the flux without forming G (stiffness_geom.hpp column_flux_at: 12 fp64 operations less per quadrature point)
-      column_flux_at<T>(pts[qx], wts[qx] * wyz, J0, Ja, Jba, Jc, Jdc, vx, vy, vz, fx[qx], fy, fz);
-      cfy[qx * n2] = fy;
-      cfz[qx * n2] = fz;
+      if constexpr (sizeof(T) == 8 && P == 6) {  // the flux without forming G (stiffness_geom.hpp column_flux_at: 12 fp64 operations less per
+        T fy, fz;                                 // quadrature point); where measured: config 5's step -1.5 % (profiles/r06k_ab_flux_form_westervelt.log)
+        column_flux_at<T>(pts[qx], wts[qx] * wyz, J0, Ja, Jba, Jc, Jdc, vx, vy, vz, fx[qx], fy, fz);
+        cfy[qx * n2] = fy;
+        cfz[qx * n2] = fz;
+      } else {
+        T gq[6];
+        column_g_at<T>(pts[qx], wts[qx] * wyz, J0, Ja, Jba, Jc, Jdc, gq);
+        fx[qx] = gq[0] * vx + gq[1] * vy + gq[2] * vz;
+        cfy[qx * n2] = gq[1] * vx + gq[3] * vy + gq[4] * vz;
+        cfz[qx * n2] = gq[2] * vx + gq[4] * vy + gq[5] * vz;
+      }
     }
   }
   __syncthreads();  // B3

@@ -9,8 +9,8 @@ N variants x M rounds on one workload; prints median / min per variant.
                         buffer, 1 LDS-aliased, 2 LDS-aliased + G ring, 30 fp32 5-waves)
           ``raw:K``     the same reading the plan's dof lists instead of its run tables (FUS_TUNE_PLAN_RUNS = 0)
           ``runs:K``    the same reading the run tables whatever the dtype (FUS_TUNE_PLAN_RUNS = 2)
-          ``geom``      geometry formed in the kernel from the 8 vertices (no G stream); ``geom:50`` / ``geom:51``: P <= 5 with the flux formed
-                        inside the main loop (column_flux_at) at 4 / 3 waves per SIMD instead of the n x 6 factors held in registers
+          ``geom``      geometry formed in the kernel from the 8 vertices (no G stream); ``geom:50`` / ``geom:51`` existed in the library of
+                        commit 3e1ba31 only (P <= 5 with the flux formed inside the main loop at 4 / 3 waves per SIMD: profiles/r06j_*, r06l_*)
           ``col:V``     plan-free column kernel, workgroup variant V (0: ~256 threads, 1: ~128)
 Add ``@x`` to a cfg to run it with the XCD remap on.  Two builds of the library are compared by
 alternating runs of this tool with FUS_LIB_PATH=<other libfusgpu.so> on one box.  Results of the studies run with this tool: profiles/r0*_ab_*.log."""
