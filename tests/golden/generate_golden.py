@@ -133,6 +133,8 @@ def main():
     # the degrees between / above the reference's test set that its Q map serves (numba-cpu/time_operators.py:35-45): the generic-n path
     # of the operators at an odd and at a high degree
     cases += [(5, (2, 2, 2), 0.16, np.float64), (8, (2, 2, 2), 0.16, np.float64)]
+    # ... and the rest of its map, on fewer cells (the fixtures stay small): with these every degree 2 ... 10 is pinned by reference-held data
+    cases += [(7, (2, 2, 1), 0.16, np.float64), (9, (2, 1, 1), 0.16, np.float64), (10, (2, 1, 1), 0.16, np.float64)]
     for P, shape, perturb, dt in (cases if only in ("all", "ops") else []):
         if match and match not in f"ops_P{P}_{shape[0]}x{shape[1]}x{shape[2]}_{'pert' if perturb else 'affine'}_{np.dtype(dt).name}":
             continue
