@@ -1435,7 +1435,7 @@ def test_vector_kernels_streaming_modes(gpu, dtype, mode):
         res["muladd"] = yy.clone()
         # fused stage kernels: 12 vectors, nlocal < ntotal (ghost block of b is zeroed, nothing else touched there)
         nl = n - min(n // 7, 5)
-        for kind in (2, 0, 1, 3):
+        for kind in (2, 0, 1, 3, 4, 5, 6, 7):  # 4 ... 7: the lean set of round 6
             vs = [torch.from_numpy(rng.standard_normal(n + off).astype(dtype)).cuda()[off:] for _ in range(8)]
             minv, bb, u, v, u0, v0, ku, un = vs
             minv.abs_().add_(1.0)
@@ -1472,3 +1472,61 @@ def test_vector_kernels_streaming_modes(gpu, dtype, mode):
     assert lib_mod.get_tuning(lib_mod.TUNE_VECTOR_STREAM) == old
     with pytest.raises(lib_mod.FusGpuError):
         lib_mod.set_tuning(lib_mod.TUNE_VECTOR_STREAM, 9)
+
+
+@pytest.mark.parametrize("westervelt", [False, True], ids=["linear", "westervelt"])
+@pytest.mark.parametrize("dtype", [np.float64, np.float32], ids=["f64", "f32"])
+def test_lean_rk4_stage_kinds_equal_the_reference_sequence(gpu, dtype, westervelt):
+    """``fus_rk4_stage_*`` / ``fus_rk4_stage_nl2_*`` through the C ABI: one step's four passes with the LEAN kinds 4, 5, 6, 7 (bw = dt / 6, aw = dt / 2;
+    34 / 46 vector touches) against kinds 2, 0, 0, 3 (the reference's arithmetic operation for operation, cuda/demo_linear_box.py:491-563), fed the SAME
+    right-hand sides b_1 ... b_4: the new u is BITWISE the same (its increments are formed with the same operations in the same order), the new v agrees to
+    rounding (one re-derived term), the last stage's inputs (un, ku) are bitwise the same; ghost entries untouched, b re-zeroed; an unknown kind is refused."""
+    import torch
+
+    lib_mod = pkg("_lib")
+    lib = lib_mod.load()
+    suf = "f64" if dtype == np.float64 else "f32"
+    rng = np.random.default_rng(11)
+    n, nl = 10007, 9999
+    dt = 0.37
+    B, A = (1 / 6, 1 / 3, 1 / 3, 1 / 6), (0.0, 0.5, 0.5, 1.0)
+    t = lambda a: torch.from_numpy(np.ascontiguousarray(a.astype(dtype))).cuda()  # noqa: E731
+    u_start, v_start = rng.standard_normal(n), rng.standard_normal(n)
+    rhs = [rng.standard_normal(n) for _ in range(4)]
+    minv = 1.0 + rng.random(n)
+    m0, w2, w5 = 4.0 + rng.random(n), 0.01 * rng.standard_normal(n), rng.standard_normal(n)
+
+    def one_step(kinds, coeff):
+        u0, v0 = t(u_start), t(v_start)
+        u, v, ku, un, b = (torch.full((n,), 7.0, dtype=u0.dtype, device="cuda") for _ in range(5))
+        last_inputs = None
+        for i in range(4):
+            b.copy_(t(rhs[i]))
+            bw, aw = coeff(i)
+            if westervelt:
+                rc = getattr(lib, f"fus_rk4_stage_nl2_{suf}")(bw, aw, kinds[i], t(m0).data_ptr(), t(w2).data_ptr(), t(w5).data_ptr(), b.data_ptr(), u.data_ptr(),
+                                                           v.data_ptr(), u0.data_ptr(), v0.data_ptr(), ku.data_ptr(), un.data_ptr(), 0.0, None, nl, n, lib_mod.stream_ptr())
+            else:
+                rc = getattr(lib, f"fus_rk4_stage_{suf}")(bw, aw, kinds[i], t(minv).data_ptr(), b.data_ptr(), u.data_ptr(), v.data_ptr(), u0.data_ptr(), v0.data_ptr(),
+                                                       ku.data_ptr(), un.data_ptr(), nl, n, lib_mod.stream_ptr())
+            assert rc == 0
+            torch.cuda.synchronize()
+            assert float(b.abs().max()) == 0.0, "b is re-zeroed over owned and ghost entries"
+            if i == 2:
+                last_inputs = (un.clone(), ku.clone())
+        return u0, v0, last_inputs
+
+    ref = one_step((2, 0, 0, 3), lambda i: (B[i] * dt, 0.0 if i == 3 else A[i + 1] * dt))
+    lean = one_step((4, 5, 6, 7), lambda i: (B[0] * dt, A[1] * dt))
+    tol = 1e-14 if dtype == np.float64 else 1e-6
+    if not westervelt:  # (the Westervelt pass feeds un and ku back into kv: its u differs with v's rounding from the second stage on)
+        assert torch.equal(ref[0], lean[0]), "u: same operations in the same order"
+        assert torch.equal(ref[2][0][:nl], lean[2][0][:nl])
+    assert float((ref[0] - lean[0]).abs().max()) <= tol * float(ref[0].abs().max())
+    assert float((ref[1] - lean[1]).abs().max()) <= tol * float(ref[1].abs().max())
+    assert float((ref[2][1][:nl] - lean[2][1][:nl]).abs().max()) <= tol * float(ref[2][1].abs().max())
+    for a_, b_ in ((ref[0], t(u_start)), (ref[1], t(v_start)), (lean[0], t(u_start)), (lean[1], t(v_start))):
+        assert torch.equal(a_[nl:], b_[nl:]), "ghost entries of the solution are not touched"
+    x = t(rhs[0])
+    assert getattr(lib, f"fus_rk4_stage_{suf}")(0.1, 0.1, 8, x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(), x.data_ptr(),
+                                            x.data_ptr(), nl, n, None) == -1
