@@ -299,7 +299,7 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
         kname = "fus::muladd_kernel"
     elif mass:
         rows = halo is not None and halo.row_split(dm_d, mesh.ndofs) is not None  # partitioned: split by dof, atomic-free kernel
-        kname = ops.mass_kernel_name(dm_d, mesh.ndofs, atomic=args.mass_atomic or args.exclusive or (halo is not None and not rows))
+        kname = ops.mass_kernel_name(dm_d, mesh.ndofs, atomic=args.mass_atomic or args.exclusive or (halo is not None and not rows), static=args.mass_static)
     else:
         kname = "fus::stiffness_plan_kernel" if ops._USE_PLAN else "fus::stiffness_col_kernel"
 

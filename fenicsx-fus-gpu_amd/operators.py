@@ -380,11 +380,13 @@ def _mass_apply(x, entity_constants, y, entity_detJ, entity_dofmap, N=None, excl
     )
 
 
-def mass_kernel_name(entity_dofmap, ndofs, atomic=False):
-    """Which kernel ``mass_operator``'s apply launches for this dofmap and vector length (bench.py reports it)."""
+def mass_kernel_name(entity_dofmap, ndofs, atomic=False, static=False):
+    """Which kernel ``mass_operator``'s apply launches for this dofmap and vector length (bench.py reports it); ``static``: of an operator made
+    with ``static_detJ=True`` (it keeps the gather kernel up to more entries per dof: P = 2)."""
     nent, n_per = entity_dofmap.shape
     big = nent * n_per >= _MASS_PLAN_MIN_ENTRIES
-    if _USE_GATHER and not atomic and big and n_per <= 2048 and nent * n_per < 2**31 and _GATHER_PLANS.get(entity_dofmap, int(ndofs)) is not None:
+    if (_USE_GATHER and not atomic and big and n_per <= 2048 and nent * n_per < 2**31
+            and _GATHER_PLANS.get(entity_dofmap, int(ndofs), static=bool(static)) is not None):
         return "fus::mass_gather_kernel"
     return "fus::mass_plan_kernel" if (_USE_PLAN and 2 <= n_per <= 4096 and big) else "fus::mass_kernel"
 
