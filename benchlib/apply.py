@@ -473,15 +473,34 @@ def run_apply(args, rank, world, device, use_dist, lib, ops, boxmesh, gll, pre):
         budget = float(os.environ.get("FUS_BENCH_EXTRAS_TIMEOUT_S", "420"))
 
         def bail():
-            log(f"rank {rank}: the optional phases did not finish in {budget:.0f} s (in: {extras_phase[0]}): the line is emitted without the rest")
-            out["extras_timed_out"] = {"seconds": budget, "phase": extras_phase[0]}
-            if rank == 0:
-                try:
-                    out["roofline"]["secondary"] = secondary_summary(out)
-                except Exception:  # noqa: BLE001
-                    pass
-                emit(out)
-            os._exit(0 if (check is None or check["ok"]) else 3)
+            # (runs on a timer thread: the main thread is normally blocked by now, but it may only be SLOW and still filling ``out`` -- serialise a
+            # snapshot, retry if a dict changes underneath, and leave whatever happens: a bail-out that raises would be a hang again)
+            code = 0 if (check is None or check["ok"]) else 3
+            try:
+                log(f"rank {rank}: the optional phases did not finish in {budget:.0f} s (in: {extras_phase[0]}): the line is emitted without the rest")
+                if rank == 0:
+                    import copy
+
+                    snap = None
+                    for _ in range(5):
+                        try:
+                            snap = copy.deepcopy(out)
+                            break
+                        except RuntimeError:
+                            time.sleep(0.05)
+                    if snap is None:  # the headline alone
+                        snap = {k: out.get(k) for k in ("metric", "value", "unit", "n_gpus", "steps", "warmup", "ms_per_step", "higher_is_better", "scaling",
+                                                        "vs_baseline", "dtype", "data", "valid", "check")}
+                        snap.update(config={"workload": out["config"]["workload"]}, roofline={k: v for k, v in out["roofline"].items() if k != "secondary"},
+                                    cpu_baseline=None)
+                    snap["extras_timed_out"] = {"seconds": budget, "phase": extras_phase[0]}
+                    try:
+                        snap["roofline"]["secondary"] = secondary_summary(snap)
+                    except Exception:  # noqa: BLE001
+                        pass
+                    emit(snap)
+            finally:
+                os._exit(code)
 
         if budget > 0:
             extras_timer = threading.Timer(budget, bail)
