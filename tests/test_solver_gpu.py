@@ -553,6 +553,65 @@ def test_config3_full_size_rk4_fused_vs_reference_sequence():
     assert float(s.u.abs().max().item()) == 0.0 and float(s.v.abs().max().item()) == 0.0
 
 
+def test_config3_and_config5_default_time_loops_vs_oracle_at_full_size(oracle_c):
+    """the solvers' DEFAULT paths (fused stage, lean vector pass, G formed in the cell kernel) at the sizes their numbers are
+    quoted on, DIRECTLY against the oracle's time loops (oracle/rk4_oracle.py over oracle/fus_oracle.c, all host cores; pinned by
+    tests/golden/rk4*.npz) -- config 3: P = 4, 54^3 perturbed cells, 3 steps; config 5's shape: Westervelt, P = 6, 36^3 bowl-warped cells, 2 steps.
+    The oracle reads the reference's G array, formed by a second solver instance that keeps it (keep_G=True)."""
+    import torch
+
+    torch.cuda.set_device(0)
+    boxmesh, ls, nls = pkg("boxmesh"), pkg("linear_solver"), pkg("nonlinear_solver")
+    threads = max(1, min(32, oracle_c.max_threads()))
+    h_ = lambda t: np.ascontiguousarray(t.detach().cpu().numpy().astype(np.float64))  # noqa: E731
+    # ---- config 3, linear
+    P, N, L = 4, 54, 0.12
+    mesh = boxmesh.BoxMesh(P, N, length=L, perturb=0.16, seed=0)
+    hm = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(hm, P, 1500.0, 0.5e6, L)
+    s = ls.LinearSpectral3D(mesh, np.float64)
+    assert s.fused and s.in_kernel_geometry and s.lean_stages and s.G_array is None  # the default path
+    s.init()
+    _, steps = s.rk4(0.0, tf, dt, max_steps=3)
+    assert steps == 3
+    u_gpu, v_gpu = s.u_sol(), s.v_sol()
+    del s
+    g = ls.LinearSpectral3D(mesh, np.float64, in_kernel_geometry=False)
+    geo = (h_(g.G_array), h_(g.detJ), h_(g.detJ_f1), h_(g.detJ_f2))
+    del g
+    torch.cuda.empty_cache()
+    u_ref, v_ref = rk4_oracle.solve(mesh, 3, dt, oracle_c=oracle_c, threads=threads, geometry=geo)
+    assert np.max(np.abs(u_ref)) > 0
+    assert rel_l2(u_gpu, u_ref[: mesh.nlocal]) < 1e-11 and rel_l2(v_gpu, v_ref[: mesh.nlocal]) < 1e-11
+    del geo, u_ref, v_ref
+    # ---- config 5's shape, Westervelt
+    P, N = 6, 36
+
+    def bowl(xg):
+        out = xg.copy()
+        yy, zz = xg[:, 1] / L - 0.5, xg[:, 2] / L - 0.5
+        out[:, 0] = xg[:, 0] + 0.15 * (L / N) * 4 * (yy * yy + zz * zz) * (1.0 - xg[:, 0] / L)
+        return out
+
+    mesh = boxmesh.BoxMesh(P, N, length=(L, L, L), warp=bowl)
+    hm = ls.time_step_parameters(mesh, P, 1500.0, 0.5e6, L)
+    dt, tf, _ = ls.snap_time_step(hm, P, 1500.0, 0.5e6, L)
+    s = nls.WesterveltSpectral3D(mesh, np.float64, speed_of_sound=1500.0, source_frequency=0.5e6, fused=True)
+    assert s.in_kernel_geometry and s.lean_stages and s.kappa is None and s.G is None  # default: two-gather pass, G formed in the kernel
+    s.init()
+    _, steps = s.rk4(0.0, tf, dt, max_steps=2)
+    assert steps == 2
+    u_gpu, v_gpu = s.u_sol(), s.v_sol()
+    del s
+    g = nls.WesterveltSpectral3D(mesh, np.float64, speed_of_sound=1500.0, source_frequency=0.5e6, fused=True, in_kernel_geometry=False)
+    geo = (h_(g.G), h_(g.detJ), h_(g.dF1), h_(g.dF2))
+    del g
+    torch.cuda.empty_cache()
+    u_ref, v_ref = rk4_oracle.solve_westervelt(mesh, 2, dt, c0=1500.0, f0=0.5e6, oracle_c=oracle_c, threads=threads, geometry=geo)
+    assert np.max(np.abs(u_ref)) > 0
+    assert rel_l2(u_gpu, u_ref[: mesh.nlocal]) < 1e-11 and rel_l2(v_gpu, v_ref[: mesh.nlocal]) < 1e-11
+
+
 def test_config5_full_degree_westervelt_fused_vs_reference_sequence():
     """BASELINE config 5's operator shape at a size one GPU holds comfortably (demo_nonlinear_bowl: Westervelt, P = 6, bowl-warped
     trilinear cells; 36^3 cells = 10 077 696 dofs): 3 RK4 steps of the fused path -- general G and G formed in the kernel --
