@@ -39,7 +39,7 @@ namespace fus {
 // LEAN kinds 4, 5, 6, 7 (round 6; one per stage of a step, used as a set; bw = b_runge[0] dt = dt / 6, aw = a_runge[1] dt = dt / 2, the
 // other coefficients are their exact doubles): 34 touches.  The floor argument: b must be complete before kv = b / m, so
 // every pass reads b, minv and re-zeroes b (3); passes 1-3 must write the next stage's (un, vn) (2) and need (u0, v0) for them (2);
-// passes 2-4 read vn of their own stage (1).  What is left is the traffic of the two accumulators, and it shrinks because
+// passes 2, 3 read vn of their own stage (1): 26.  What is left is the traffic of the two accumulators (15 of the 41), and it shrinks because
 //   * u's increments are the vn's, each KNOWN ONE PASS EARLY (vn_{i+1} is formed in pass i): pass 2 writes u0 + b1 v0 + b2 vn2 + b3 vn3,
 //     pass 3 adds b4 vn4 and writes the NEW u straight into u0 (u0 is dead once un4 has been formed) -- pass 4 does not touch u at all;
 //   * pass 1 writes neither accumulator: pass 2 reads u0, v0, vn2 anyway and re-derives u0 + b1 v0 and b1 kv1 = (vn2 - v0) b1 / a2 (a

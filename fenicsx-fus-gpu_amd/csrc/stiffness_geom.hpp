@@ -78,12 +78,18 @@ __device__ __forceinline__ void column_g_at(T ex, T wx_s0, const T (&J0)[3], con
 // by instruction issue.  Same conventions and the same reciprocal as column_g_at; the result differs from G v in rounding only.
 // Used WHERE MEASURED FASTER (geom_flux_operator_form; profiles/r06j_*, r06k_*, r06l_*: interleaved with the build before it): the in-loop
 // builds at fp64 P = 6, 8, 9 (-2.2, -2.7, -0.5 %) and the Westervelt cell pass at fp64 P = 6 (step -1.5 %); NOT at P = 7 (+8 % in the steady
-// state: the first 100-launch burst equal, every later one slower), P = 10 (+1.4 %), fp32 from P = 5 (+4 ... +5 %).  For P <= 5 the in-loop form
-// would also win (fp64 -1.8 ... -3.4 %) but needs 128 VGPRs + 12 bytes of scratch at P = 4 to keep four waves per SIMD: those degrees keep the
-// n x 6 factors in registers (PREG), formed between the gather's barriers.
+// state: the first 100-launch burst equal, every later one slower), P = 10 (+1.4 %), fp32 from P = 5 (+4 ... +5 %).  Below degree 6 the kernel
+// holds the n x 6 factors in registers (PREG) unless geom_factors_in_registers says otherwise.
 template <typename T, int P>
 __host__ __device__ constexpr bool geom_flux_operator_form() {
-  return sizeof(T) == 8 && (P == 6 || P == 8 || P == 9);
+  return sizeof(T) == 8 ? (P == 2 || P == 3 || P == 6 || P == 8 || P == 9) : (P == 2 || P == 3 || P == 4);
+}
+// PREG of stiffness_plan_geom_kernel per degree and scalar type: the n x 6 factors of the column held in registers (formed between the gather's
+// barriers) up to degree 5 -- except where the in-loop flux form is measured faster at the SAME occupancy without scratch (fp64 P = 2, 3: -2.7, -3.4 %;
+// fp32 P = 2, 3, 4: -4.4, -2.9, -2.6 %; profiles/r06j_*, r06l_*).  fp64 P = 4, 5 would gain 1.8 / 2.8 % only with 12 / 36 bytes of scratch: they stay.
+template <typename T, int P>
+__host__ __device__ constexpr bool geom_factors_in_registers() {
+  return P <= 5 && !(P >= 2 && geom_flux_operator_form<T, P>());
 }
 template <typename T>
 __device__ __forceinline__ void column_flux_at(T ex, T wx_s0, const T (&J0)[3], const T (&Ja)[3], const T (&Jba)[3], const T (&Jc)[3],

@@ -52,7 +52,8 @@ SHIPPED = [
     # in-kernel geometry
     (r"stiffness_plan_geom_kernel<double, 4, 10, true, true, 1, true, false, true>", 128, 4),
     (r"stiffness_plan_geom_kernel<double, 6, 5, true, true, 1, false, false, true>", 168, 3),
-    (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, 1, true, false, true>", 96, 5),
+    (r"stiffness_plan_geom_kernel<float, 4, 10, true, true, 1, false, false, true>", 96, 5),   # fp32 P = 4: the flux formed in the main loop (round 6), same occupancy
+    (r"stiffness_plan_geom_kernel<double, 3, 16, false, true, 1, false, false, true>", 128, 4),  # fp64 P = 2, 3 likewise
     (r"westervelt_cell_geom_kernel<double, 6, 5, 1, false, false, true>", 168, 3),
     # affine fast path
     (r"stiffness_plan_affine_kernel<double, 4, 10, true, false, 5, false, true>", 96, 5),
