@@ -2,11 +2,11 @@
 numba-cpu/demo_linear_box.py:302-455 (f0 / f1 / RK4 loop, source evaluated at tn) and the Westervelt
 solver of cuda/demo_nonlinear_bowl.py:357-374,458-475,540-650 on one rank, restated with the oracle's
 operators.  Pinned against the reference-driven fixtures tests/golden/rk4_*.npz / rk4nl_*.npz
-(tests/test_rk4_golden.py).  Used to check the GPU solvers' pressure fields, and by bench.py's
-``cpu_baseline`` leg of the RK4-step line (the reference prints "Solve time per step" of exactly this
-loop, numba-cpu/demo_linear_box.py:472-473).
+(tests/test_rk4_golden.py).  Used to check the GPU solvers' pressure fields -- in tests/ and, since round 6, as the CHECKER of every RK4 /
+Westervelt step line of bench.py (benchlib/cpu_legs.py oracle_step_field) -- and by bench.py's ``cpu_baseline`` leg of the RK4-step line
+(the reference prints "Solve time per step" of exactly this loop, numba-cpu/demo_linear_box.py:472-473).
 
-Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline legs import this.  The mesh / table builders
+Only tests/, __graft_entry__.smoke() and bench.py's checker / cpu_baseline legs (benchlib/) import this: never the product.  The mesh / table builders
 it takes from the package (gll, precompute: host-side numpy, the counterparts of what the reference takes from
 basix / dolfinx) are inputs, not the operators under test."""
 
